@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (/root/reference, Python) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box).  It puts
+/root/reference and three import-time stand-ins (torchvision / cv2 / natsort, which the
+reference imports but never touches on the numeric path) on sys.path, drives the reference's own
+classes, and writes small .npz fixtures to tests/golden/.  Fixtures are data only (inputs and
+expected outputs); no reference source is stored.
+
+    python oracle/tools/gen_golden.py            # rewrites tests/golden/*.npz
+
+Sections (SURVEY.md section 8c recipe):
+  schedules.npz   float64 tables of create_sampler for T' in {1000, 250, 10}
+  blocks.npz      GroupNorm32 / timestep_embedding / ResBlock{plain,skip,up,down} /
+                  AttentionBlock{legacy,new}: inputs, params, outputs, input-gradients
+  tiny_unet.npz   create_model(tiny) with oracle.unet_ref.seeded_state_dict weights: y, dL/dx
+  loop_<op>.npz   10-step guided p_sample_loop for each of the 3 physical operators with the
+                  exact noise tensors the reference drew, per-step traces
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from guided_diffusion import unet as R_unet  # noqa: E402
+from guided_diffusion import nn as R_nn  # noqa: E402
+from guided_diffusion import gaussian_diffusion as R_gd  # noqa: E402
+from guided_diffusion.measurements import get_operator, get_noise  # noqa: E402
+from guided_diffusion.condition_methods import get_conditioning_method  # noqa: E402
+
+from oracle.unet_ref import UNetConfig, seeded_state_dict  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(8)
+
+TINY_KW = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2",
+               attention_resolutions="128,64", num_head_channels=16, num_heads=4,
+               learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+               pretrain_model="osmosis")
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def randomize_(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.ndim == 1:
+                v = torch.randn(p.shape, generator=g)
+                if "norm" in name or name.endswith("layers.0.weight") or name.endswith("layers.0.bias"):
+                    p.copy_(1.0 + 0.1 * v if name.endswith("weight") else 0.05 * v)
+                else:
+                    p.copy_(0.05 * v)
+            else:
+                fan = int(np.prod(p.shape[1:]))
+                p.copy_(torch.randn(p.shape, generator=g) * (0.5 / np.sqrt(fan)))
+
+
+def gen_schedules():
+    out = {}
+    for tag, kw in {"T1000": dict(steps=1000, timestep_respacing=1000),
+                    "T250": dict(steps=1000, timestep_respacing="250"),
+                    "T10": dict(steps=1000, timestep_respacing=[10])}.items():
+        s = R_gd.create_sampler(sampler="ddpm", noise_schedule="linear", model_mean_type="epsilon",
+                                model_var_type="learned_range", dynamic_threshold=False,
+                                clip_denoised=False, rescale_timesteps=False, **kw)
+        out[f"{tag}.betas"] = s.betas
+        out[f"{tag}.timestep_map"] = np.array(s.timestep_map, dtype=np.int64)
+        out[f"{tag}.alphas_cumprod"] = s.alphas_cumprod
+        out[f"{tag}.sqrt_recip_alphas_cumprod"] = s.mean_processor.sqrt_recip_alphas_cumprod
+        out[f"{tag}.sqrt_recipm1_alphas_cumprod"] = s.mean_processor.sqrt_recipm1_alphas_cumprod
+        out[f"{tag}.posterior_mean_coef1"] = s.mean_processor.posterior_mean_coef1
+        out[f"{tag}.posterior_mean_coef2"] = s.mean_processor.posterior_mean_coef2
+        out[f"{tag}.posterior_log_variance_clipped"] = s.var_processor.posterior_log_variance_clipped
+        out[f"{tag}.log_betas"] = np.log(s.var_processor.betas)
+    out["cosine50.betas"] = R_gd.get_named_beta_schedule("cosine", 50)
+    out["space_1000_10_15_20"] = np.array(sorted(R_gd.space_timesteps(300, [10, 15, 20])), dtype=np.int64)
+    out["space_ddim25"] = np.array(sorted(R_gd.space_timesteps(1000, "ddim25")), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+
+
+def gen_blocks():
+    out = {}
+    g = torch.Generator().manual_seed(11)
+
+    # timestep embedding
+    t = torch.tensor([0.0, 1.0, 37.0, 999.0])
+    out["temb.t"] = npy(t)
+    out["temb.out64"] = npy(R_nn.timestep_embedding(t, 64))
+    out["temb.out256"] = npy(R_nn.timestep_embedding(t, 256))
+
+    # GroupNorm32
+    gn = R_nn.normalization(64)
+    randomize_(gn, 21)
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.1 * torch.randn(64, generator=g))
+        gn.bias.copy_(0.05 * torch.randn(64, generator=g))
+    x = (torch.randn(2, 64, 8, 8, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    y = gn(x)
+    w = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad((y * w).sum(), x)
+    out.update({"gn.x": npy(x), "gn.weight": npy(gn.weight), "gn.bias": npy(gn.bias),
+                "gn.y": npy(y), "gn.dy": npy(w), "gn.dx": npy(gx)})
+
+    # ResBlocks
+    emb_ch = 128
+    variants = {"res_plain": dict(channels=64, out_channels=64),
+                "res_skip": dict(channels=96, out_channels=64),
+                "res_up": dict(channels=64, out_channels=64, up=True),
+                "res_down": dict(channels=64, out_channels=64, down=True)}
+    for i, (tag, kw) in enumerate(variants.items()):
+        blk = R_unet.ResBlock(emb_channels=emb_ch, dropout=0.0, use_scale_shift_norm=True, **kw)
+        randomize_(blk, 100 + i)
+        blk.eval()
+        x = torch.randn(2, kw["channels"], 8, 8, generator=g).requires_grad_(True)
+        emb = torch.randn(2, emb_ch, generator=g)
+        y = blk(x, emb)
+        w = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad((y * w).sum(), x)
+        out.update({f"{tag}.x": npy(x), f"{tag}.emb": npy(emb), f"{tag}.y": npy(y),
+                    f"{tag}.dy": npy(w), f"{tag}.dx": npy(gx)})
+        for k, v in blk.state_dict().items():
+            out[f"{tag}.sd.{k}"] = npy(v)
+
+    # Attention blocks (always checkpointed in the reference: exercises CheckpointFunction too)
+    for tag, new in {"attn_legacy": False, "attn_new": True}.items():
+        blk = R_unet.AttentionBlock(64, num_head_channels=16, use_new_attention_order=new)
+        randomize_(blk, 200 + int(new))
+        x = torch.randn(2, 64, 8, 8, generator=g).requires_grad_(True)
+        y = blk(x)
+        w = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad((y * w).sum(), x)
+        out.update({f"{tag}.x": npy(x), f"{tag}.y": npy(y), f"{tag}.dy": npy(w), f"{tag}.dx": npy(gx)})
+        for k, v in blk.state_dict().items():
+            out[f"{tag}.sd.{k}"] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+
+
+def tiny_model():
+    m = R_unet.create_model(**TINY_KW)
+    cfg = UNetConfig.from_create_model_kwargs(**TINY_KW)
+    sd = seeded_state_dict(cfg, seed=1234)
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.eval(), cfg, sd
+
+
+def gen_tiny_unet():
+    m, cfg, sd = tiny_model()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 32, 32, generator=g).requires_grad_(True)
+    t = torch.tensor([3, 250])
+    y = m(x, t)
+    (gx,) = torch.autograd.grad((y[:, :4] ** 2).sum(), x)
+    chk = float(sum(v.double().abs().sum() for v in sd.values()))
+    np.savez_compressed(os.path.join(OUT, "tiny_unet.npz"), x=npy(x), t=npy(t), y=npy(y), dx=npy(gx),
+                        weight_abs_sum=np.array(chk), n_params=np.array(sum(v.numel() for v in sd.values())))
+
+
+OPERATORS = {
+    "underwater_physical_revised": dict(
+        operator=dict(name="underwater_physical_revised", optimizer="sgd", depth_type="gamma", value="1.4,1.4,1",
+                      phi_a="1.1,0.95,0.95", phi_a_eta="1e-5", phi_a_learn_flag=True,
+                      phi_b="0.95, 0.8, 0.8", phi_b_eta="1e-5", phi_b_learn_flag=True,
+                      phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5", phi_inf_learn_flag=True),
+        cond=dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                  scale="7,7,7,0.9", gradient_x_prev=True, gradient_clip="True,0.005"),
+        aux=dict(aux_loss={"avrg_loss": 0.5, "val_loss": 20})),
+    "underwater_physical": dict(
+        operator=dict(name="underwater_physical", optimizer="sgd", depth_type="original", value="1.4,1.4,1",
+                      phi_ab="1.1,0.95,0.95", phi_ab_eta="1e-5", phi_ab_learn_flag=True,
+                      phi_inf="0.2,0.4,0.7", phi_inf_eta="1e-5", phi_inf_learn_flag=True),
+        cond=dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                  scale="4,4,4,1", gradient_x_prev=True, gradient_clip="True,0.001"),
+        aux=dict(aux_loss={"val_loss": 40})),
+    "haze_physical": dict(
+        operator=dict(name="haze_physical", optimizer="sgd", depth_type="gamma", value="1.4,1.4,1",
+                      phi_ab="1.0", phi_ab_eta="1e-5", phi_ab_learn_flag=True,
+                      phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5", phi_inf_learn_flag=True),
+        cond=dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                  scale="7,7,7,0.9", gradient_x_prev=True, gradient_clip="True,0.005"),
+        aux=dict(aux_loss={"avrg_loss": 0.5, "val_loss": 20})),
+}
+PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0,
+               n_iter=20, start_guidance=1, stop_guidance=0)
+
+
+def gen_loops():
+    m, cfg, sd = tiny_model()
+    for opname, spec in OPERATORS.items():
+        operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
+        noiser = get_noise(name="clean")
+        cond = get_conditioning_method("osmosis", operator, noiser, **spec["cond"], **PATTERN, **spec["aux"])
+        sampler = R_gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10),
+                                           betas=R_gd.get_named_beta_schedule("linear", 1000),
+                                           model_mean_type="epsilon", model_var_type="learned_range",
+                                           dynamic_threshold=False, clip_denoised=False,
+                                           rescale_timesteps=False)
+        x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(0))
+        y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
+
+        trace = []
+        orig_cond = cond.conditioning
+
+        def traced(**kw):
+            rec = {"x_in": kw["x_prev"].detach().clone(), "x0": kw["x_0_hat"].detach().clone(),
+                   "mean": kw["x_t"].detach().clone()}
+            ret = orig_cond(**kw)
+            rec["x_guided"] = ret[0].detach().clone()
+            rec["loss"] = np.array(ret[1], dtype=np.float32)
+            rec["phi"] = {k: v.detach().clone() for k, v in ret[2].items()}
+            rec["grad"] = ret[3].clone()
+            trace.append(rec)
+            return ret
+
+        draws = []
+        orig_randn_like = torch.randn_like
+
+        def logged_randn_like(t, **kw):
+            r = orig_randn_like(t, **kw)
+            draws.append(r.clone())
+            return r
+
+        torch.manual_seed(0)
+        torch.randn_like = logged_randn_like
+        try:
+            img, variables, loss, x0 = sampler.p_sample_loop(
+                model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced,
+                record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+                sample_pattern=PATTERN)
+        finally:
+            torch.randn_like = orig_randn_like
+        # draws alternate: randn_like(measurement) [unused], randn_like(img) [used]  
+        assert len(draws) == 2 * len(trace)
+        used = [d for d in draws if d.shape[1] == 4]
+        out = {"x_T": npy(x_T), "y": npy(y), "final_img": npy(img), "final_x0": npy(x0),
+               "final_loss": np.array(loss, dtype=np.float32),
+               "noise": np.stack([npy(n) for n in used]),
+               "timestep_map": np.array(sampler.timestep_map, dtype=np.int64)}
+        for k, v in variables.items():
+            out[f"final.{k}"] = npy(v)
+        for key in ("x_in", "x0", "mean", "x_guided", "grad"):
+            out[f"trace.{key}"] = np.stack([npy(r[key]) for r in trace])
+        out["trace.loss"] = np.stack([r["loss"] for r in trace])
+        for k in trace[0]["phi"]:
+            out[f"trace.{k}"] = np.stack([npy(r["phi"][k]) for r in trace])
+        np.savez_compressed(os.path.join(OUT, f"loop_{opname}.npz"), **out)
+        print(opname, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_schedules()
+    gen_blocks()
+    gen_tiny_unet()
+    gen_loops()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,144 @@
+"""Pins the CPU oracle (oracle/) to golden vectors captured from the real reference
+(oracle/tools/gen_golden.py).  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_ref as D
+from oracle import unet_ref as U
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TINY_KW = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2",
+               attention_resolutions="128,64", num_head_channels=16, num_heads=4,
+               learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+               pretrain_model="osmosis")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("tag,kw", [("T1000", dict(timestep_respacing=1000)),
+                                     ("T250", dict(timestep_respacing="250")),
+                                     ("T10", dict(timestep_respacing=[10]))])
+def test_schedule_tables_bit_exact(tag, kw):
+    g = load("schedules.npz")
+    tb = D.make_tables(1000, "linear", **kw)
+    assert np.array_equal(tb.betas, g[f"{tag}.betas"])
+    assert np.array_equal(np.array(tb.timestep_map), g[f"{tag}.timestep_map"])
+    for name in ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                 "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
+                 "log_betas"):
+        assert np.array_equal(getattr(tb, name), g[f"{tag}.{name}"]), name
+
+
+def test_schedule_misc():
+    g = load("schedules.npz")
+    assert np.array_equal(D.named_beta_schedule("cosine", 50), g["cosine50.betas"])
+    assert sorted(D.space_timesteps(300, [10, 15, 20])) == list(g["space_1000_10_15_20"])
+    assert sorted(D.space_timesteps(1000, "ddim25")) == list(g["space_ddim25"])
+    with pytest.raises(NotImplementedError):
+        D.named_beta_schedule("nope", 10)
+    with pytest.raises(ValueError):
+        D.space_timesteps(10, [20])
+
+
+def test_timestep_embedding():
+    g = load("blocks.npz")
+    t = T(g["temb.t"])
+    assert torch.equal(U.timestep_embedding(t, 64), T(g["temb.out64"]))
+    assert torch.equal(U.timestep_embedding(t, 256), T(g["temb.out256"]))
+
+
+def test_group_norm():
+    g = load("blocks.npz")
+    x = T(g["gn.x"]).requires_grad_(True)
+    y = U.group_norm32(x, T(g["gn.weight"]), T(g["gn.bias"]))
+    (dx,) = torch.autograd.grad((y * T(g["gn.dy"])).sum(), x)
+    assert torch.allclose(y, T(g["gn.y"]), atol=1e-6)
+    assert torch.allclose(dx, T(g["gn.dx"]), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,kw", [("res_plain", {}), ("res_skip", {}), ("res_up", dict(up=True)),
+                                     ("res_down", dict(down=True))])
+def test_res_block(tag, kw):
+    g = load("blocks.npz")
+    sd = {k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    x = T(g[f"{tag}.x"]).requires_grad_(True)
+    y = U.res_block(sd, "", x, T(g[f"{tag}.emb"]), **kw)
+    (dx,) = torch.autograd.grad((y * T(g[f"{tag}.dy"])).sum(), x)
+    assert torch.allclose(y, T(g[f"{tag}.y"]), atol=2e-6)
+    assert torch.allclose(dx, T(g[f"{tag}.dx"]), atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,new", [("attn_legacy", False), ("attn_new", True)])
+def test_attention_block(tag, new):
+    g = load("blocks.npz")
+    sd = {k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    x = T(g[f"{tag}.x"]).requires_grad_(True)
+    y = U.attention_block(sd, "", x, 4, new)
+    (dx,) = torch.autograd.grad((y * T(g[f"{tag}.dy"])).sum(), x)
+    assert torch.allclose(y, T(g[f"{tag}.y"]), atol=2e-6)
+    assert torch.allclose(dx, T(g[f"{tag}.dx"]), atol=2e-6)
+
+
+def tiny():
+    cfg = U.UNetConfig.from_create_model_kwargs(**TINY_KW)
+    return cfg, U.seeded_state_dict(cfg, 1234)
+
+
+def test_tiny_unet_forward_and_input_grad():
+    g = load("tiny_unet.npz")
+    cfg, sd = tiny()
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    chk = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(chk - float(g["weight_abs_sum"])) < 1e-6 * chk
+    x = T(g["x"]).requires_grad_(True)
+    y = U.unet_forward(sd, cfg, x, T(g["t"]))
+    (dx,) = torch.autograd.grad((y[:, :4] ** 2).sum(), x)
+    assert torch.allclose(y, T(g["y"]), atol=1e-5), (y - T(g["y"])).abs().max()
+    assert torch.allclose(dx, T(g["dx"]), atol=1e-5 * float(T(g["dx"]).abs().max()) + 1e-6)
+
+
+OPS = {
+    "underwater_physical_revised": (
+        dict(depth_type="gamma", value="1.4,1.4,1", phi_a="1.1,0.95,0.95", phi_b="0.95, 0.8, 0.8",
+             phi_inf="0.14, 0.29, 0.49"),
+        dict(scale="7,7,7,0.9", gradient_clip="True,0.005", aux={"avrg_loss": 0.5, "val_loss": 20})),
+    "underwater_physical": (
+        dict(depth_type="original", value="1.4,1.4,1", phi_ab="1.1,0.95,0.95", phi_inf="0.2,0.4,0.7"),
+        dict(scale="4,4,4,1", gradient_clip="True,0.001", aux={"val_loss": 40})),
+    "haze_physical": (
+        dict(depth_type="gamma", value="1.4,1.4,1", phi_ab="1.0", phi_inf="0.14, 0.29, 0.49"),
+        dict(scale="7,7,7,0.9", gradient_clip="True,0.005", aux={"avrg_loss": 0.5, "val_loss": 20})),
+}
+PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, start_guidance=1, stop_guidance=0)
+
+
+@pytest.mark.parametrize("opname", list(OPS))
+def test_guided_loop_10_steps(opname):
+    g = load(f"loop_{opname}.npz")
+    cfg, sd = tiny()
+    okw, ckw = OPS[opname]
+    op = D.PhysOperator(opname, batch_size=1, **okw)
+    guide = D.OsmosisGuidance(op, n_iter=20, **ckw)
+    tb = D.Tables(D.named_beta_schedule("linear", 1000), range(0, 100, 10))
+    assert tb.timestep_map == list(g["timestep_map"])
+    trace = []
+    model = lambda x, t: U.unet_forward(sd, cfg, x, t)  # noqa: E731
+    img, variables, loss, x0 = D.p_sample_loop(model, tb, T(g["x_T"]), T(g["y"]), guide, PATTERN,
+                                               [T(n) for n in g["noise"]], trace)
+    # teacher-free 10-step run: same torch kernels as the reference -> tight agreement
+    for k, rec in enumerate(trace):
+        assert torch.allclose(rec["x0"], T(g["trace.x0"][k]), atol=5e-5), (k, "x0")
+        assert np.allclose(rec["loss"], g["trace.loss"][k], rtol=1e-5), (k, "loss")
+    assert torch.allclose(img, T(g["final_img"]), atol=5e-5)
+    assert torch.allclose(x0, T(g["final_x0"]), atol=5e-5)
+    for n, v in variables.items():
+        assert torch.allclose(v, T(g[f"final.{n}"]), atol=1e-6), n
