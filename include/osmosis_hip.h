@@ -1,0 +1,176 @@
+/* osmosis_hip.h -- C ABI of libosmosis_hip.so (MI355X / gfx950 kernels for the Osmosis
+ * guided-diffusion p_sample_loop hot path).
+ *
+ * The reference (osmosis-diffusion/osmosis-diffusion-code) is pure Python/PyTorch and has no
+ * FFI of its own; its device work is stock ATen.  Each entry point below therefore cites the
+ * reference Python call site whose ATen ops it replaces (paths relative to the reference repo).
+ * The reference-side binding (ctypes) is shown in INTEGRATION.md and implemented in
+ * osmosis_diffusion_code_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative osm_status on failure and never throws;
+ *     osm_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers (fp32 unless stated), owned by the caller; the library
+ *     allocates nothing persistent.  `stream` is a hipStream_t (NULL = default stream).
+ *   - activations are NHWC "matrix views": row m = pixel (b*H+h)*W+w, `ld*` = row stride in
+ *     floats (>= channels, multiple of 4), so channel slices / concatenations are zero-copy.
+ *   - entry points are re-entrant; no global mutable state.
+ */
+#ifndef OSMOSIS_HIP_H
+#define OSMOSIS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum osm_status {
+  OSM_OK = 0,
+  OSM_ERR_INVALID = -1,   /* bad argument (shape / alignment / null pointer) */
+  OSM_ERR_LAUNCH = -2,    /* HIP launch failure */
+  OSM_ERR_UNSUPPORTED = -3
+} osm_status;
+
+int osm_version(void);                 /* (major<<16)|(minor<<8)|patch */
+const char* osm_last_error(void);
+
+/* ------------------------------------------------------------------ dense contraction
+ * One kernel family (fp32 MFMA v_mfma_f32_32x32x2_f32, 128x128x32 LDS-staged tiles) serves
+ *   3x3 conv  (nn.py:22-32 conv_nd; unet.py:264,290,561,694)      ksize=3
+ *   1x1 conv  (unet.py:301 skip_connection; unet.py:365,373 qkv/proj_out conv1d)  ksize=1
+ *   batched attention GEMMs (unet.py:428,432 einsum)               osm_gemm
+ * and, with the dgrad weight packing, their input-gradients (autograd of the above).
+ */
+typedef struct osm_conv_desc {
+  const float* x;      /* [B*H*W][ldx] input, Cin channels used                       */
+  const float* w;      /* packed weights [ksize*ksize][Cout][Cin] (osm_pack_conv_weight) */
+  const float* bias;   /* [Cout] or NULL                                               */
+  const float* res;    /* optional residual [B*H*W][ldr] added in the epilogue, or NULL */
+  float* y;            /* [B*H*W][ldy] output                                          */
+  float* splitk_ws;    /* workspace of splitk*B*H*W*Cout floats when splitk>1, else NULL */
+  int B, H, W, Cin, Cout;
+  int ksize;           /* 1 or 3; stride 1, zero padding ksize/2                       */
+  int splitk;          /* >=1: number of K slices                                      */
+  int accumulate;      /* !=0: y += result                                             */
+  long long ldx, ldy, ldr;
+} osm_conv_desc;
+int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
+
+/* OIHW [Cout][Cin][k][k] -> forward pack [k*k][Cout][Cin] and data-gradient pack
+ * [k*k][Cin][Cout] (taps flipped, channels transposed).  Either output may be NULL. */
+int osm_pack_conv_weight(const float* w_oihw, float* w_fwd, float* w_dgrad,
+                         int Cout, int Cin, int ksize, void* stream);
+
+typedef struct osm_gemm_desc {
+  const float* A;      /* [M][lda], K contiguous                                       */
+  const float* Bm;     /* b_kn==0: [N][ldb] (K contiguous);  b_kn==1: [K][ldb] (N contiguous) */
+  const float* bias;   /* [N] or NULL                                                  */
+  const float* res;    /* [M][ldr] or NULL                                             */
+  float* C;            /* [M][ldc]                                                     */
+  int M, N, K;
+  int b_kn;
+  int nb1, nb2;        /* two-level batch (e.g. heads, images); >=1                    */
+  int accumulate;
+  float alpha;         /* C = alpha*A*B (+bias +res)                                   */
+  long long lda, ldb, ldc, ldr;
+  long long sA1, sB1, sC1, sA2, sB2, sC2;   /* batch strides in floats (res uses sC*)  */
+} osm_gemm_desc;
+int osm_gemm(const osm_gemm_desc* d, void* stream);
+/* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
+int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
+
+/* ------------------------------------------------------------------ GroupNorm(32)+SiLU(+FiLM)
+ * nn.py:17-19,93-100 GroupNorm32; unet.py:263,287 SiLU; unet.py:327-331 scale-shift.
+ * stats: [B][G][2] = (mean, rstd).  part: workspace of B*nchunk*G*2 floats,
+ * nchunk = osm_gn_nchunk(HW).  film: row b at film + b*ldfilm holds (scale[C] | shift[C]), or NULL. */
+int osm_gn_nchunk(int HW);
+int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C, int G, float eps,
+                 float* part, float* stats, void* stream);
+int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G,
+                 const float* stats, const float* gamma, const float* beta, const float* film,
+                 long long ldfilm, int silu, void* stream);
+/* dx = dGN(dy) (+ addend).  part: workspace as above. */
+int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
+               const float* addend, long long ldadd, int B, int HW, int C, int G,
+               const float* stats, const float* gamma, const float* beta, const float* film,
+               long long ldfilm, int silu, float* part, float* gstats, void* stream);
+
+/* ------------------------------------------------------------------ resampling (unet.py:186, 215)
+ * y[B][H/2][W/2][C] = scale * sum_{2x2} x   (avg-pool: scale=0.25; upsample-backward: scale=1)
+ * y[B][2H][2W][C]   = scale * x[h/2][w/2]   (nearest-upsample: scale=1; avg-pool-backward: 0.25) */
+int osm_pool2x2(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
+                float scale, void* stream);
+int osm_upsample2x(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
+                   float scale, void* stream);
+
+/* ------------------------------------------------------------------ attention pieces
+ * unet.py:431 softmax over the last dim (rows of length T); P and optionally P^T are written.
+ * bwd: dS = P*(dP - rowsum(dP*P)); dS and optionally dS^T written.  nmat = B*heads matrices. */
+int osm_softmax_rows(const float* S, float* P, float* PT, int nmat, int T, void* stream);
+int osm_softmax_rows_bwd(const float* P, const float* dP, float* dS, float* dST, int nmat, int T,
+                         void* stream);
+
+/* ------------------------------------------------------------------ embeddings (nn.py:103-121, unet.py:550-554, 278-284)
+ * temb: out[B][dim] = [cos(t*f) | sin(t*f)].  t: device floats [B].
+ * linear: y[B][N] = act(x)[B][K] @ W[N][K]^T + b, act = SiLU if silu_in. silu_out applies SiLU to y. */
+int osm_timestep_embedding(const float* t, float* out, int B, int dim, float max_period, void* stream);
+int osm_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N,
+               int silu_in, int silu_out, void* stream);
+
+/* ------------------------------------------------------------------ layout / elementwise */
+int osm_nchw_to_nhwc(const float* x, float* y, long long ldy, int B, int C, int HW, void* stream);
+int osm_nhwc_to_nchw(const float* x, long long ldx, float* y, int B, int C, int HW, void* stream);
+int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long M, int C,
+               int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ sampler step (NCHW [B,4,H,W])
+ * coef: device float[8] = {sqrt_recip_ac, sqrt_recipm1_ac, post_coef1, post_coef2,
+ *                          min_log(posterior_log_variance_clipped), max_log(log beta), noise_on, t}
+ * posterior (posterior_mean_variance.py:127-136, 246-258; gaussian_diffusion.py:345-365):
+ *   x0 = c0*x - c1*eps ; mean = c2*x0 + c3*x ; logvar = f*c5 + (1-f)*c4, f=(v+1)/2 */
+int osm_posterior(const float* model_out /*[B,8,HW]*/, const float* x /*[B,4,HW]*/, const float* coef,
+                  float* x0, float* mean, float* logvar, int B, int HW, void* stream);
+
+/* physical forward model + guidance loss (measurements.py:138-151,251-264,363-376;
+ * condition_methods.py:109-144; losses.py:29-83; utils.py:544-566,674-700) */
+typedef struct osm_phys_desc {
+  int kind;            /* 0 underwater_physical_revised, 1 underwater_physical, 2 haze_physical */
+  int depth_type;      /* 0 original, 1 gamma, 2 move                                  */
+  float dval[3];       /* depth params (gamma: v0,v1,v2 ; move: v0)                    */
+  int weight_type;     /* 0 none, 1 depth                                              */
+  int wdepth_type;     /* depth_type of the loss weight function                       */
+  float wval[3];
+  int loss_type;       /* 0 norm, 1 mse                                                */
+  float gamma_avrg;    /* aux avrg_loss coefficient (0 = off)                          */
+  float gamma_val;     /* aux val_loss coefficient (0 = off)                           */
+  float eta[3];        /* SGD step for phi_a(phi_ab), phi_b, phi_inf                   */
+  int B, HW;
+} osm_phys_desc;
+/* phi: device float [B][9] = phi_a[3] | phi_b[3] | phi_inf[3]  (kinds 1,2 use phi_a as phi_ab;
+ * haze uses phi_a[0] only).  part: workspace B*nblk*16 floats, nblk = osm_phys_nblk(HW).
+ * red: device float [B][16]: 0 sum r^2, 1..9 raw phi-gradient sums, 10..12 sum rgb_c, 13 val-loss sum.
+ * loss_out: [B] data-term loss per image (the reference's sep_loss). */
+int osm_phys_nblk(int HW);
+int osm_phys_reduce(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
+                    float* part, void* stream);
+int osm_phys_finalize(const osm_phys_desc* d, const float* part, float* red, float* phi, int do_update,
+                      float* loss_out, void* stream);
+/* g[B,4,HW] = d(total loss)/d(x0) for the current phi and the reductions in `red`. */
+int osm_phys_grad(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
+                  const float* red, float* g, void* stream);
+
+/* d_out[B,8,HW]: channels 0..3 = -c1*g, 4..7 = 0   (chain rule through x0 = c0*x - c1*eps) */
+int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream);
+/* condition_methods.py:211-224 + gaussian_diffusion.py:266-268:
+ *   grad = c0*g + dx_unet ; x_t = mean - scale[c]*clamp(grad,+-clip) ; x_next = x_t + exp(.5*logvar)*noise*noise_on
+ * grad_out (optional) receives the unclipped gradient. clip<=0 disables clipping. */
+int osm_guide_update(const float* mean, const float* logvar, const float* g, const float* dx_unet,
+                     const float* noise, const float* coef, const float* scale4, float clip,
+                     float* x_next, float* grad_out, int B, int HW, void* stream);
+/* coef_out[8] = table[*step][8]; t_out[b] = coef_out[7]; then *step += delta (graph-replayable) */
+int osm_fetch_coefs(const float* table, int* step, int delta, float* coef_out, float* t_out, int B,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSMOSIS_HIP_H */

@@ -1,0 +1,183 @@
+"""ctypes binding of libosmosis_hip.so (the C ABI declared in include/osmosis_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every kernel is reached through a
+plain C call with raw device pointers.  There is NO CPU / eager fallback: if the library is not
+built, or a tensor is not a CUDA(HIP) fp32 tensor, the call raises.
+
+A `Recorder` captures the exact sequence of C calls (function + marshalled arguments) issued while
+it is active, so a whole UNet forward/backward or sampler step can be replayed with near-zero Python
+overhead (and captured into a hipGraph through torch.cuda.CUDAGraph).
+"""
+import ctypes as C
+import os
+import threading
+from typing import List, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libosmosis_hip.so")
+
+c_float_p = C.c_void_p  # device pointers travel as opaque addresses
+
+
+class OsmosisHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("y", C.c_void_p), ("splitk_ws", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("ksize", C.c_int), ("splitk", C.c_int), ("accumulate", C.c_int),
+                ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("Bm", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("b_kn", C.c_int),
+                ("nb1", C.c_int), ("nb2", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_float),
+                ("lda", C.c_longlong), ("ldb", C.c_longlong), ("ldc", C.c_longlong), ("ldr", C.c_longlong),
+                ("sA1", C.c_longlong), ("sB1", C.c_longlong), ("sC1", C.c_longlong),
+                ("sA2", C.c_longlong), ("sB2", C.c_longlong), ("sC2", C.c_longlong)]
+
+
+class PhysDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("depth_type", C.c_int), ("dval", C.c_float * 3),
+                ("weight_type", C.c_int), ("wdepth_type", C.c_int), ("wval", C.c_float * 3),
+                ("loss_type", C.c_int), ("gamma_avrg", C.c_float), ("gamma_val", C.c_float),
+                ("eta", C.c_float * 3), ("B", C.c_int), ("HW", C.c_int)]
+
+
+# name -> argtypes (restype is int unless listed in _SPECIAL)
+_LL = C.c_longlong
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_SIGS = {
+    "osm_conv2d_nhwc": [C.POINTER(ConvDesc), _P],
+    "osm_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _P],
+    "osm_gemm": [C.POINTER(GemmDesc), _P],
+    "osm_splitk_hint": [_I, _I, _I, _I, _I],
+    "osm_gn_nchunk": [_I],
+    "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
+    "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P],
+    "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P],
+    "osm_pool2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
+    "osm_upsample2x": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
+    "osm_softmax_rows": [_P, _P, _P, _I, _I, _P],
+    "osm_softmax_rows_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "osm_timestep_embedding": [_P, _P, _I, _I, _F, _P],
+    "osm_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "osm_nchw_to_nhwc": [_P, _P, _LL, _I, _I, _I, _P],
+    "osm_nhwc_to_nchw": [_P, _LL, _P, _I, _I, _I, _P],
+    "osm_copy2d": [_P, _LL, _P, _LL, _LL, _I, _I, _P],
+    "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "osm_phys_nblk": [_I],
+    "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
+    "osm_phys_finalize": [C.POINTER(PhysDesc), _P, _P, _P, _I, _P, _P],
+    "osm_phys_grad": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P, _P],
+    "osm_posterior_bwd": [_P, _P, _P, _I, _I, _P],
+    "osm_guide_update": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
+    "osm_fetch_coefs": [_P, _P, _I, _P, _P, _I, _P],
+    "osm_version": [],
+}
+EXPORTS = sorted(list(_SIGS) + ["osm_last_error"])
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise OsmosisHipError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C osmosis_diffusion_code_amd/csrc` (hipcc, --offload-arch=gfx950). "
+                    "There is no CPU fallback for the product path.")
+            lib = C.CDLL(LIB_PATH)
+            for name, argtypes in _SIGS.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = C.c_int
+            lib.osm_last_error.argtypes = []
+            lib.osm_last_error.restype = C.c_char_p
+            _lib = lib
+    return _lib
+
+
+# ----------------------------------------------------------------------------- recording
+class Recorder:
+    """Collects (cfunc, args) of every kernel call made while active; keeps referenced tensors alive."""
+
+    def __init__(self):
+        self.calls: List[Tuple] = []
+        self.keep: List = []
+
+    def __enter__(self):
+        _state.recorders.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _state.recorders.pop()
+        return False
+
+    def replay(self):
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc != 0:
+                raise OsmosisHipError(f"{fn.__name__} failed ({rc}): {load().osm_last_error().decode()}")
+
+    def __len__(self):
+        return len(self.calls)
+
+
+class _State(threading.local):
+    def __init__(self):
+        self.recorders: List[Recorder] = []
+        self.stream: Optional[int] = None
+
+
+_state = _State()
+
+
+def current_stream_ptr() -> int:
+    if _state.stream is not None:
+        return _state.stream
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args, keep=()):
+    """Invoke a status-returning entry point; raise on failure; record if a Recorder is active."""
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*args)
+    if rc != 0:
+        raise OsmosisHipError(f"{name} failed ({rc}): {lib.osm_last_error().decode()}")
+    for r in _state.recorders:
+        r.calls.append((fn, args))
+        r.keep.extend(keep)
+        r.keep.extend(a for a in args if isinstance(a, C.Structure) or hasattr(a, "_obj"))
+
+
+def query(name: str, *args) -> int:
+    """Value-returning helpers (osm_splitk_hint, osm_gn_nchunk, osm_phys_nblk, osm_version)."""
+    return getattr(load(), name)(*args)
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address of a CUDA fp32/int32 tensor (None -> NULL).  Fails loudly on CPU tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise OsmosisHipError("osmosis_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
+                              "(there is no CPU fallback on the product path)")
+    if t.dtype not in (torch.float32, torch.int32):
+        raise OsmosisHipError(f"osmosis_hip kernels are fp32; got {t.dtype}")
+    return t.data_ptr()

@@ -1,0 +1,325 @@
+// HBM-bound helpers of the UNet: resampling, layout conversion, softmax rows, timestep embedding,
+// small linear layers.  All operate on NHWC matrix views (row = pixel, ld = row stride).
+#include "osm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- 2x2 sum-pool (avg-pool / upsample-bwd)
+// reference: Downsample(use_conv=False) = AvgPool2d(2,2)  (unet.py:213-215)
+template <int VEC>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ x, long long ldx,
+                                                       float* __restrict__ y, long long ldy, int B, int H,
+                                                       int W, int C, float scale) {
+  const int Ho = H / 2, Wo = W / 2, vpr = C / VEC;
+  const long long total = (long long)B * Ho * Wo * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vpr);
+    long long r = i / vpr;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const long long in0 = ((long long)(b * H + 2 * ho) * W + 2 * wo);
+    const long long out = ((long long)(b * Ho + ho) * Wo + wo);
+    const int c = v * VEC;
+    if (VEC == 4) {
+      const float4 a0 = *reinterpret_cast<const float4*>(x + in0 * ldx + c);
+      const float4 a1 = *reinterpret_cast<const float4*>(x + (in0 + 1) * ldx + c);
+      const float4 a2 = *reinterpret_cast<const float4*>(x + (in0 + W) * ldx + c);
+      const float4 a3 = *reinterpret_cast<const float4*>(x + (in0 + W + 1) * ldx + c);
+      float4 o;
+      o.x = ((a0.x + a1.x) + (a2.x + a3.x)) * scale;
+      o.y = ((a0.y + a1.y) + (a2.y + a3.y)) * scale;
+      o.z = ((a0.z + a1.z) + (a2.z + a3.z)) * scale;
+      o.w = ((a0.w + a1.w) + (a2.w + a3.w)) * scale;
+      *reinterpret_cast<float4*>(y + out * ldy + c) = o;
+    } else {
+      const float s = (x[in0 * ldx + c] + x[(in0 + 1) * ldx + c]) +
+                      (x[(in0 + W) * ldx + c] + x[(in0 + W + 1) * ldx + c]);
+      y[out * ldy + c] = s * scale;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- nearest 2x upsample (/ avg-pool-bwd)
+// reference: Upsample(use_conv=False) = F.interpolate(scale_factor=2, mode="nearest") (unet.py:186)
+template <int VEC>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, long long ldx,
+                                                          float* __restrict__ y, long long ldy, int B, int H,
+                                                          int W, int C, float scale) {
+  const int Ho = 2 * H, Wo = 2 * W, vpr = C / VEC;
+  const long long total = (long long)B * Ho * Wo * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vpr);
+    long long r = i / vpr;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const long long in = ((long long)(b * H + ho / 2) * W + wo / 2);
+    const long long out = ((long long)(b * Ho + ho) * Wo + wo);
+    const int c = v * VEC;
+    if (VEC == 4) {
+      float4 a = *reinterpret_cast<const float4*>(x + in * ldx + c);
+      a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+      *reinterpret_cast<float4*>(y + out * ldy + c) = a;
+    } else {
+      y[out * ldy + c] = x[in * ldx + c] * scale;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- layout
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            long long ldy, int B, int C, int HW) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;  // b*HW + p
+    const int p = (int)(row % HW);
+    const int b = (int)(row / HW);
+    y[row * ldy + c] = x[((long long)b * C + c) * HW + p];
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, long long ldx,
+                                                            float* __restrict__ y, int B, int C, int HW) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const long long bc = i / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    y[i] = x[((long long)b * HW + p) * ldx + c];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, long long ldx,
+                                                      float* __restrict__ y, long long ldy, long long M, int C,
+                                                      int accumulate) {
+  const int vpr = C / VEC;
+  const long long total = M * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / vpr;
+    const int c = (int)(i - row * vpr) * VEC;
+    if (VEC == 4) {
+      float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+      float4* d = reinterpret_cast<float4*>(y + row * ldy + c);
+      if (accumulate) {
+        const float4 o = *d;
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *d = a;
+    } else {
+      float a = x[row * ldx + c];
+      if (accumulate) a += y[row * ldy + c];
+      y[row * ldy + c] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- softmax over rows (one wave per row)
+// reference: th.softmax(weight.float(), dim=-1) (unet.py:431)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                            float* __restrict__ PT, long long nrows, int T) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const float* s = S + row * T;
+  float mx = -INFINITY;
+  for (int i = lane; i < T; i += 64) mx = fmaxf(mx, s[i]);
+  mx = osm::wave_max(mx);
+  float sum = 0.f;
+  for (int i = lane; i < T; i += 64) sum += expf(s[i] - mx);
+  sum = osm::wave_sum(sum);
+  const float inv = 1.0f / sum;
+  const long long mat = row / T;
+  const int t = (int)(row - mat * T);
+  for (int i = lane; i < T; i += 64) {
+    const float pv = expf(s[i] - mx) * inv;
+    P[row * T + i] = pv;
+    if (PT) PT[(mat * T + i) * T + t] = pv;
+  }
+}
+
+// dS = P * (dP - sum_s dP*P)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P,
+                                                                const float* __restrict__ dP,
+                                                                float* __restrict__ dS, float* __restrict__ dST,
+                                                                long long nrows, int T) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const float* pr = P + row * T;
+  const float* dp = dP + row * T;
+  float dot = 0.f;
+  for (int i = lane; i < T; i += 64) dot += pr[i] * dp[i];
+  dot = osm::wave_sum(dot);
+  const long long mat = row / T;
+  const int t = (int)(row - mat * T);
+  for (int i = lane; i < T; i += 64) {
+    const float v = pr[i] * (dp[i] - dot);
+    dS[row * T + i] = v;
+    if (dST) dST[(mat * T + i) * T + t] = v;
+  }
+}
+
+// ---------------------------------------------------------------- timestep embedding (nn.py:103-121)
+__global__ void temb_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim,
+                            float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float freq = expf(-logf(max_period) * (float)k / (float)half);
+  const float arg = t[b] * freq;
+  out[(long long)b * dim + k] = cosf(arg);
+  out[(long long)b * dim + half + k] = sinf(arg);
+  if ((dim & 1) && k == 0) out[(long long)b * dim + dim - 1] = 0.f;
+}
+
+// ---------------------------------------------------------------- y[B][N] = act(x)[B][K] W[N][K]^T + b
+// one wave per output feature n; W streamed once with 16-byte loads (weight-bandwidth bound).
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int B, int K, int N, int silu_in, int silu_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* w = Wt + (long long)n * K;
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x + (long long)b * K;
+    float acc = 0.f;
+    if (VEC == 4) {
+      for (int k = 4 * lane; k < K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+        float4 xv = *reinterpret_cast<const float4*>(xb + k);
+        if (silu_in) {
+          xv.x = osm::silu_f(xv.x); xv.y = osm::silu_f(xv.y);
+          xv.z = osm::silu_f(xv.z); xv.w = osm::silu_f(xv.w);
+        }
+        acc += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+      }
+    } else {
+      for (int k = lane; k < K; k += 64) {
+        float xv = xb[k];
+        if (silu_in) xv = osm::silu_f(xv);
+        acc += w[k] * xv;
+      }
+    }
+    acc = osm::wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + (bias ? bias[n] : 0.f);
+      if (silu_out) v = osm::silu_f(v);
+      y[(long long)b * N + n] = v;
+    }
+  }
+}
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int osm_pool2x2(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
+                           float scale, void* stream) {
+  OSM_REQUIRE(x && y, "osm_pool2x2: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "osm_pool2x2: H, W must be even");
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / (v4 ? 4 : 1));
+  if (v4)
+    hipLaunchKernelGGL((pool2x2_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
+  else
+    hipLaunchKernelGGL((pool2x2_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
+  return osm::check_launch("pool2x2_kernel");
+}
+
+extern "C" int osm_upsample2x(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W,
+                              int C, float scale, void* stream) {
+  OSM_REQUIRE(x && y, "osm_upsample2x: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "osm_upsample2x: bad shape");
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const long long total = (long long)B * (2 * H) * (2 * W) * (C / (v4 ? 4 : 1));
+  if (v4)
+    hipLaunchKernelGGL((upsample2x_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
+  else
+    hipLaunchKernelGGL((upsample2x_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
+  return osm::check_launch("upsample2x_kernel");
+}
+
+extern "C" int osm_nchw_to_nhwc(const float* x, float* y, long long ldy, int B, int C, int HW, void* stream) {
+  OSM_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && ldy >= C, "osm_nchw_to_nhwc: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, ldy, B, C, HW);
+  return osm::check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int osm_nhwc_to_nchw(const float* x, long long ldx, float* y, int B, int C, int HW, void* stream) {
+  OSM_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && ldx >= C, "osm_nhwc_to_nchw: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, y, B, C, HW);
+  return osm::check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long M, int C,
+                          int accumulate, void* stream) {
+  OSM_REQUIRE(x && y && M > 0 && C > 0, "osm_copy2d: bad argument");
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const long long total = M * (C / (v4 ? 4 : 1));
+  if (v4)
+    hipLaunchKernelGGL((copy2d_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, accumulate);
+  else
+    hipLaunchKernelGGL((copy2d_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, accumulate);
+  return osm::check_launch("copy2d_kernel");
+}
+
+extern "C" int osm_softmax_rows(const float* S, float* P, float* PT, int nmat, int T, void* stream) {
+  OSM_REQUIRE(S && P && nmat > 0 && T > 0, "osm_softmax_rows: bad argument");
+  const long long nrows = (long long)nmat * T;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     S, P, PT, nrows, T);
+  return osm::check_launch("softmax_rows_kernel");
+}
+
+extern "C" int osm_softmax_rows_bwd(const float* P, const float* dP, float* dS, float* dST, int nmat, int T,
+                                    void* stream) {
+  OSM_REQUIRE(P && dP && dS && nmat > 0 && T > 0, "osm_softmax_rows_bwd: bad argument");
+  const long long nrows = (long long)nmat * T;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, P, dP, dS, dST, nrows, T);
+  return osm::check_launch("softmax_rows_bwd_kernel");
+}
+
+extern "C" int osm_timestep_embedding(const float* t, float* out, int B, int dim, float max_period,
+                                      void* stream) {
+  OSM_REQUIRE(t && out && B > 0 && dim >= 2, "osm_timestep_embedding: bad argument");
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(temb_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim,
+                     max_period);
+  return osm::check_launch("temb_kernel");
+}
+
+extern "C" int osm_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N,
+                          int silu_in, int silu_out, void* stream) {
+  OSM_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "osm_linear: bad argument");
+  const bool v4 = K % 4 == 0 && osm::aligned16(x) && osm::aligned16(W);
+  if (v4)
+    hipLaunchKernelGGL((linear_kernel<4>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, K, N, silu_in, silu_out);
+  else
+    hipLaunchKernelGGL((linear_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, K, N, silu_in, silu_out);
+  return osm::check_launch("linear_kernel");
+}
+
+extern "C" int osm_version(void) { return (0 << 16) | (1 << 8) | 0; }
+extern "C" const char* osm_last_error(void) { return osm::err_buf(); }

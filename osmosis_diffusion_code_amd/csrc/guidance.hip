@@ -1,0 +1,339 @@
+// Per-step sampler math outside the UNet (NCHW [B,4,H,W] like the reference's tensors):
+//   posterior mean / x0 / log-variance            posterior_mean_variance.py:127-136, 246-258
+//   physical image-formation model + guidance loss  measurements.py:138-151, 251-264, 363-376;
+//                                                   condition_methods.py:109-144; losses.py:29-83
+//   analytic gradient of that loss w.r.t. x0 and phi, on-device SGD on phi (measurements.py:266-303)
+//   guidance update + ancestral noise               condition_methods.py:211-224; gaussian_diffusion.py:266-268
+// All HBM/latency bound and tiny (a few MB per step); the point of doing them here is that the
+// 20-iteration phi loop runs with no host synchronisation (the reference syncs 4+20 times a step).
+// Batch semantics: every reduction is PER IMAGE (equal to B=1 reference runs image by image,
+// SURVEY.md F1/F2).
+#include "osm_common.h"
+
+namespace {
+
+constexpr int PPB = 1024;  // pixels per reduce workgroup
+constexpr int NRED = 16;
+
+__device__ __forceinline__ float conv_depth(float D, int type, const float* v, float& dd) {
+  if (type == 1) {  // gamma: ((D + v0) * v1) ^ v2
+    const float base = (D + v[0]) * v[1];
+    if (v[2] == 1.0f) {
+      dd = v[1];
+      return base;
+    }
+    const float pw = powf(base, v[2]);
+    dd = v[1] * v[2] * powf(base, v[2] - 1.0f);
+    return pw;
+  }
+  if (type == 2) {  // move
+    dd = 1.0f;
+    return D + v[0];
+  }
+  dd = 0.5f;  // original
+  return 0.5f * (D + 1.0f);
+}
+
+struct Pix {
+  float rgb[3], D, y[3];
+  float d, dd, w;
+  float Ea[3], Eb[3], J[3], r[3];
+};
+
+__device__ __forceinline__ void eval_pixel(const osm_phys_desc& ds, const float* __restrict__ x0,
+                                           const float* __restrict__ y, const float* __restrict__ phi,
+                                           int b, int p, Pix& q) {
+  const long long base = (long long)b * 4 * ds.HW + p;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    q.rgb[c] = x0[base + (long long)c * ds.HW];
+    q.y[c] = y[(long long)b * 3 * ds.HW + (long long)c * ds.HW + p];
+  }
+  q.D = x0[base + 3LL * ds.HW];
+  q.d = conv_depth(q.D, ds.depth_type, ds.dval, q.dd);
+  float wdd;
+  q.w = ds.weight_type == 1 ? conv_depth(q.D, ds.wdepth_type, ds.wval, wdd) : 1.0f;
+  const float* ph = phi + b * 9;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float pa = ds.kind == 2 ? ph[0] : ph[c];
+    const float pb = ds.kind == 0 ? ph[3 + c] : pa;
+    const float pinf = ph[6 + c];
+    q.Ea[c] = expf(-pa * q.d);
+    q.Eb[c] = expf(-pb * q.d);
+    q.J[c] = 0.5f * (q.rgb[c] + 1.0f);
+    const float I = q.J[c] * q.Ea[c] + pinf * (1.0f - q.Eb[c]);
+    q.r[c] = (q.y[c] - (2.0f * I - 1.0f)) * q.w;
+  }
+}
+
+__global__ __launch_bounds__(256) void phys_reduce_kernel(osm_phys_desc ds, const float* __restrict__ x0,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ phi,
+                                                           float* __restrict__ part, int nblk) {
+  __shared__ float red[4][NRED];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  float s[NRED];
+#pragma unroll
+  for (int k = 0; k < NRED; ++k) s[k] = 0.f;
+  const int pend = min(ds.HW, (blk + 1) * PPB);
+  const float* ph = phi + b * 9;
+  for (int p = blk * PPB + threadIdx.x; p < pend; p += 256) {
+    Pix q;
+    eval_pixel(ds, x0, y, phi, b, p, q);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float pinf = ph[6 + c];
+      const float k2 = -2.0f * q.w * q.r[c];                 // r_c * d r_c / d I_c
+      s[0] += q.r[c] * q.r[c];
+      s[1 + c] += k2 * (-q.d * q.J[c] * q.Ea[c]);            // d I / d phi_a
+      s[4 + c] += k2 * (pinf * q.d * q.Eb[c]);               // d I / d phi_b
+      s[7 + c] += k2 * (1.0f - q.Eb[c]);                     // d I / d phi_inf
+      s[10 + c] += q.rgb[c];
+      const float e = fmaxf(fabsf(q.rgb[c]) - 0.7f, 0.0f);
+      s[13] += e * e;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NRED; ++k) {
+    const float t = osm::wave_sum(s[k]);
+    if (lane == 0) red[wv][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NRED) {
+    const int k = threadIdx.x;
+    part[((long long)b * nblk + blk) * NRED + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+__global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__ part, float* __restrict__ red,
+                                     float* __restrict__ phi, int do_update, float* __restrict__ loss_out,
+                                     int nblk) {
+  __shared__ double tot[NRED];
+  const int b = blockIdx.x;
+  if (threadIdx.x < NRED) {
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += (double)part[((long long)b * nblk + k) * NRED + threadIdx.x];
+    tot[threadIdx.x] = a;
+    red[b * NRED + threadIdx.x] = (float)a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = 3.0 * (double)ds.HW;
+    double L, gscale;
+    if (ds.loss_type == 0) {
+      L = sqrt(tot[0]);
+      gscale = 1.0 / L;
+    } else {
+      L = tot[0] / n;
+      gscale = 2.0 / n;
+    }
+    if (loss_out) loss_out[b] = (float)L;
+    if (do_update) {
+      float* ph = phi + b * 9;
+      if (ds.kind == 0) {
+        for (int c = 0; c < 3; ++c) {
+          ph[c] -= ds.eta[0] * (float)(tot[1 + c] * gscale);
+          ph[3 + c] -= ds.eta[1] * (float)(tot[4 + c] * gscale);
+        }
+      } else if (ds.kind == 1) {
+        for (int c = 0; c < 3; ++c) ph[c] -= ds.eta[0] * (float)((tot[1 + c] + tot[4 + c]) * gscale);
+      } else {
+        double g = 0.0;
+        for (int c = 0; c < 3; ++c) g += tot[1 + c] + tot[4 + c];
+        const float nv = ph[0] - ds.eta[0] * (float)(g * gscale);
+        ph[0] = ph[1] = ph[2] = nv;
+      }
+      for (int c = 0; c < 3; ++c) ph[6 + c] -= ds.eta[2] * (float)(tot[7 + c] * gscale);
+    }
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void phys_grad_kernel(osm_phys_desc ds, const float* __restrict__ x0,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ phi,
+                                                         const float* __restrict__ red, float* __restrict__ g) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= ds.HW) return;
+  Pix q;
+  eval_pixel(ds, x0, y, phi, b, p, q);
+  const float* rd = red + b * NRED;
+  const float n = 3.0f * (float)ds.HW;
+  const float gscale = ds.loss_type == 0 ? 1.0f / sqrtf(rd[0]) : 2.0f / n;
+  const float* ph = phi + b * 9;
+  float gD = 0.f;
+  const long long base = (long long)b * 4 * ds.HW + p;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float pa = ds.kind == 2 ? ph[0] : ph[c];
+    const float pb = ds.kind == 0 ? ph[3 + c] : pa;
+    const float pinf = ph[6 + c];
+    const float dLdI = -2.0f * q.w * (q.r[c] * gscale);
+    float grgb = dLdI * 0.5f * q.Ea[c];
+    if (ds.gamma_avrg != 0.f) grgb += ds.gamma_avrg * sgn(rd[10 + c]) / (float)ds.HW;
+    if (ds.gamma_val != 0.f) {
+      const float e = fmaxf(fabsf(q.rgb[c]) - 0.7f, 0.0f);
+      grgb += ds.gamma_val * 2.0f * e * sgn(q.rgb[c]) / n;
+    }
+    g[base + (long long)c * ds.HW] = grgb;
+    gD += dLdI * (-pa * q.J[c] * q.Ea[c] + pinf * pb * q.Eb[c]) * q.dd;
+  }
+  g[base + 3LL * ds.HW] = gD;
+}
+
+// ---------------------------------------------------------------- posterior
+__global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ mo, const float* __restrict__ x,
+                                                         const float* __restrict__ coef, float* __restrict__ x0,
+                                                         float* __restrict__ mean, float* __restrict__ logvar,
+                                                         int B, int HW) {
+  const long long total = (long long)B * 4 * HW;
+  const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], mn = coef[4], mxl = coef[5];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / (4LL * HW);
+    const long long rem = i - b * 4LL * HW;
+    const float eps = mo[b * 8LL * HW + rem];
+    const float v = mo[b * 8LL * HW + 4LL * HW + rem];
+    const float xv = x[i];
+    const float xs = c0 * xv - c1 * eps;
+    x0[i] = xs;
+    mean[i] = c2 * xs + c3 * xv;
+    const float frac = (v + 1.0f) / 2.0f;
+    logvar[i] = frac * mxl + (1.0f - frac) * mn;
+  }
+}
+
+__global__ __launch_bounds__(256) void posterior_bwd_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ coef,
+                                                             float* __restrict__ d_out, int B, int HW) {
+  const long long total = (long long)B * 8 * HW;
+  const float c1 = coef[1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / (8LL * HW);
+    const long long rem = i - b * 8LL * HW;
+    d_out[i] = rem < 4LL * HW ? -c1 * g[b * 4LL * HW + rem] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void guide_update_kernel(const float* __restrict__ mean,
+                                                            const float* __restrict__ logvar,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ dxu,
+                                                            const float* __restrict__ noise,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ scale4, float clip,
+                                                            float* __restrict__ x_next,
+                                                            float* __restrict__ grad_out, int B, int HW) {
+  const long long total = (long long)B * 4 * HW;
+  const float c0 = coef[0], noise_on = coef[6];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % 4);
+    float grad = 0.f;
+    if (g) grad = c0 * g[i] + (dxu ? dxu[i] : 0.f);
+    if (grad_out) grad_out[i] = grad;
+    float gc = grad;
+    if (clip > 0.f) gc = fminf(fmaxf(grad, -clip), clip);
+    float xt = mean[i] - (g ? scale4[c] * gc : 0.f);
+    if (noise_on != 0.f && noise) xt += expf(0.5f * logvar[i]) * noise[i];
+    x_next[i] = xt;
+  }
+}
+
+__global__ void fetch_coefs_kernel(const float* __restrict__ table, int* __restrict__ step, int delta,
+                                   float* __restrict__ coef_out, float* __restrict__ t_out, int B) {
+  const int s = *step;
+  if (threadIdx.x < 8) coef_out[threadIdx.x] = table[s * 8 + threadIdx.x];
+  if (threadIdx.x < B) t_out[threadIdx.x] = table[s * 8 + 7];
+  __syncthreads();
+  if (threadIdx.x == 0) *step = s + delta;
+}
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int check_desc(const osm_phys_desc* d, const char* who) {
+  OSM_REQUIRE(d, "%s: null descriptor", who);
+  OSM_REQUIRE(d->kind >= 0 && d->kind <= 2, "%s: unknown operator kind %d", who, d->kind);
+  OSM_REQUIRE(d->depth_type >= 0 && d->depth_type <= 2, "%s: unknown depth_type %d", who, d->depth_type);
+  OSM_REQUIRE(d->loss_type == 0 || d->loss_type == 1, "%s: unknown loss_type %d", who, d->loss_type);
+  OSM_REQUIRE(d->B > 0 && d->HW > 0, "%s: bad shape", who);
+  return OSM_OK;
+}
+
+}  // namespace
+
+extern "C" int osm_phys_nblk(int HW) { return (HW + PPB - 1) / PPB; }
+
+extern "C" int osm_phys_reduce(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
+                               float* part, void* stream) {
+  int rc = check_desc(d, "osm_phys_reduce");
+  if (rc) return rc;
+  OSM_REQUIRE(x0 && y && phi && part, "osm_phys_reduce: null pointer");
+  const int nblk = osm_phys_nblk(d->HW);
+  hipLaunchKernelGGL(phys_reduce_kernel, dim3(nblk, d->B), dim3(256), 0, (hipStream_t)stream, *d, x0, y, phi,
+                     part, nblk);
+  return osm::check_launch("phys_reduce_kernel");
+}
+
+extern "C" int osm_phys_finalize(const osm_phys_desc* d, const float* part, float* red, float* phi,
+                                 int do_update, float* loss_out, void* stream) {
+  int rc = check_desc(d, "osm_phys_finalize");
+  if (rc) return rc;
+  OSM_REQUIRE(part && red && phi, "osm_phys_finalize: null pointer");
+  hipLaunchKernelGGL(phys_finalize_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, *d, part, red, phi,
+                     do_update, loss_out, osm_phys_nblk(d->HW));
+  return osm::check_launch("phys_finalize_kernel");
+}
+
+extern "C" int osm_phys_grad(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
+                             const float* red, float* g, void* stream) {
+  int rc = check_desc(d, "osm_phys_grad");
+  if (rc) return rc;
+  OSM_REQUIRE(x0 && y && phi && red && g, "osm_phys_grad: null pointer");
+  hipLaunchKernelGGL(phys_grad_kernel, dim3((d->HW + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d,
+                     x0, y, phi, red, g);
+  return osm::check_launch("phys_grad_kernel");
+}
+
+extern "C" int osm_posterior(const float* model_out, const float* x, const float* coef, float* x0, float* mean,
+                             float* logvar, int B, int HW, void* stream) {
+  OSM_REQUIRE(model_out && x && coef && x0 && mean && logvar && B > 0 && HW > 0, "osm_posterior: bad argument");
+  hipLaunchKernelGGL(posterior_kernel, dim3(grid_for((long long)B * 4 * HW)), dim3(256), 0, (hipStream_t)stream,
+                     model_out, x, coef, x0, mean, logvar, B, HW);
+  return osm::check_launch("posterior_kernel");
+}
+
+extern "C" int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream) {
+  OSM_REQUIRE(g && coef && d_out && B > 0 && HW > 0, "osm_posterior_bwd: bad argument");
+  hipLaunchKernelGGL(posterior_bwd_kernel, dim3(grid_for((long long)B * 8 * HW)), dim3(256), 0,
+                     (hipStream_t)stream, g, coef, d_out, B, HW);
+  return osm::check_launch("posterior_bwd_kernel");
+}
+
+extern "C" int osm_guide_update(const float* mean, const float* logvar, const float* g, const float* dx_unet,
+                                const float* noise, const float* coef, const float* scale4, float clip,
+                                float* x_next, float* grad_out, int B, int HW, void* stream) {
+  OSM_REQUIRE(mean && logvar && coef && x_next && B > 0 && HW > 0, "osm_guide_update: bad argument");
+  OSM_REQUIRE(!g || scale4, "osm_guide_update: guidance needs the per-channel scale");
+  hipLaunchKernelGGL(guide_update_kernel, dim3(grid_for((long long)B * 4 * HW)), dim3(256), 0,
+                     (hipStream_t)stream, mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, grad_out, B,
+                     HW);
+  return osm::check_launch("guide_update_kernel");
+}
+
+extern "C" int osm_fetch_coefs(const float* table, int* step, int delta, float* coef_out, float* t_out, int B,
+                               void* stream) {
+  OSM_REQUIRE(table && step && coef_out && t_out && B > 0 && B <= 256, "osm_fetch_coefs: bad argument");
+  hipLaunchKernelGGL(fetch_coefs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, step, delta, coef_out,
+                     t_out, B);
+  return osm::check_launch("fetch_coefs_kernel");
+}

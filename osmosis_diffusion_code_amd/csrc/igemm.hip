@@ -1,0 +1,402 @@
+// Implicit-GEMM convolution / batched GEMM for gfx950 (MI355X), exact fp32 on the matrix cores.
+//
+//   out[m][n] = alpha * sum_{tap} sum_{c} A[pix(m)+off(tap)][c] * Bp[tap][n][c]  (+bias[n] +res[m][n])
+//
+// m = NHWC pixel row, n = output channel, (tap,c) = reduction.  One kernel family covers the
+// reference's 3x3 convs, 1x1 convs / conv1d projections, the attention einsums and -- with the
+// flipped/transposed weight packing -- every data-gradient of those (guidance back-propagates
+// through the whole UNet: condition_methods.py:186-194).
+//
+// CDNA4 mapping
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/instr/SIMD, 157 TFLOP/s chip peak).
+//   * 256 threads = 4 waves (one per SIMD), 2x2 waves over a 128x128 output tile, each wave 2x2
+//     MFMA tiles of 32x32 -> 64 accumulator VGPRs; 2 workgroups per CU so one workgroup's
+//     global->LDS staging overlaps the other's MFMA stream.
+//   * K is consumed in chunks of 32 channels of one tap; chunk order is channel-major / tap-minor so
+//     the 9 taps of a channel slab re-hit the XCD's L2.  Tiles are staged global->VGPR->LDS with
+//     16-byte accesses, double-buffered in LDS (one barrier per chunk), rows padded to 36 floats so
+//     both the ds_write_b128 staging stores and the ds_read_b128 fragment loads are conflict-free.
+//   * Each lane feeds the MFMA from a float4 of 4 consecutive k; lanes 0-31 / 32-63 hold k-offsets
+//     0-3 / 4-7 of every 8-wide k group, so step j contracts k={j, j+4}: A and B use the same
+//     permutation, hence the sum is unchanged and every LDS fragment read is a single b128.
+//   * blockIdx -> tile mapping is XCD-aware (bijective remap, N-tiles fastest) so workgroups that
+//     share an input slab share an L2.
+//   * Small-M layers (8x8..32x32) are weight-bandwidth bound: split-K over grid.y with fp32
+//     partials and a deterministic reduce.
+#include "osm_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_STRIDE = 36;      // floats per staged row (32 + 4 pad)
+constexpr int LDS_KN_STRIDE = 132;  // floats per k-row of a [k][n] staged B tile
+
+struct IGemmParams {
+  const float* A;
+  const float* Bm;
+  const float* bias;
+  const float* res;
+  float* C;
+  float* ws;
+  int M, N, K;
+  int H, W;
+  int splitk;
+  int accumulate;
+  float alpha;
+  long long lda, ldb, ldc, ldr;
+  long long tapstrideB;
+  int nb1;
+  long long sA1, sB1, sC1, sA2, sB2, sC2;
+  int mtiles, ntiles;
+  int nchunks;
+  int nbatch;
+};
+
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+template <int TAPS, bool B_KN>
+__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restrict__ Aglob,
+                                                            const float* __restrict__ Bglob,
+                                                            IGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_STRIDE];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LDS_STRIDE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- XCD-aware tile mapping (bijective for any tile count)
+  const int nt = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const int b1 = z % p.nb1, b2 = z / p.nb1;
+  const float* __restrict__ A = Aglob + b1 * p.sA1 + b2 * p.sA2;
+  const float* __restrict__ Bm = Bglob + b1 * p.sB1 + b2 * p.sB2;
+
+  const int ks = blockIdx.y;
+  const int per = (p.nchunks + p.splitk - 1) / p.splitk;
+  const int kc0 = ks * per;
+  const int kc1 = min(p.nchunks, kc0 + per);
+
+  // ---- per-thread staging coordinates
+  const int cg = tid & 7;   // float4 column group inside the 32-wide chunk
+  const int r0 = tid >> 3;  // 0..31
+  long long arow[4];
+  unsigned amask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    arow[i] = (long long)m * p.lda;
+    unsigned mk = 0;
+    if (m < p.M) {
+      if (TAPS == 9) {
+        const int w = m % p.W;
+        const int h = (m / p.W) % p.H;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+          if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) mk |= 1u << t;
+        }
+      } else {
+        mk = 1u;
+      }
+    }
+    amask[i] = mk;
+  }
+  long long brow[4];
+  bool bvalid[4];
+  if (!B_KN) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      brow[i] = (long long)n * p.ldb;
+      bvalid[i] = n < p.N;
+    }
+  } else {
+    const int n = n0 + 4 * (tid & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      brow[i] = n;
+      bvalid[i] = n < p.N;
+    }
+  }
+
+  float4 ra[4], rb[4];
+  unsigned okm = 0;  // validity bits of the staged registers (applied at LDS-store time)
+
+  // unconditional 16-byte loads from a selected (always valid) offset, zeroed afterwards:
+  // keeps the staging loads branch-free so they stay in flight under the MFMA stream.
+#define OSM_LOAD_CHUNK(kc_)                                                                     \
+  {                                                                                             \
+    okm = 0;                       \
+    const int cc_ = (kc_) / TAPS;                                                               \
+    const int tap_ = (kc_) - cc_ * TAPS;                                                        \
+    const int c0_ = cc_ * BK;                                                                   \
+    long long toff_ = 0;                                                                        \
+    if (TAPS == 9) toff_ = ((long long)(tap_ / 3 - 1) * p.W + (tap_ % 3 - 1)) * p.lda;          \
+    const int c_ = c0_ + 4 * cg;                                                                \
+    const bool cok_ = c_ < p.K;                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+      const bool ok_ = cok_ && ((amask[i] >> tap_) & 1u);                                       \
+      const float4 v_ = *reinterpret_cast<const float4*>(A + (ok_ ? arow[i] + toff_ + c_ : 0)); \
+      ra[i] = v_; okm |= (ok_ ? 1u : 0u) << i;                                                                \
+    }                                                                                           \
+    if (!B_KN) {                                                                                \
+      const long long boff_ = (long long)tap_ * p.tapstrideB + c_;                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+        const bool ok_ = cok_ && bvalid[i];                                                     \
+        const float4 v_ = *reinterpret_cast<const float4*>(Bm + (ok_ ? boff_ + brow[i] : 0));   \
+        rb[i] = v_; okm |= (ok_ ? 16u : 0u) << i;                                                              \
+      }                                                                                         \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+        const int k_ = c0_ + (tid >> 5) + 8 * i;                                                \
+        const bool ok_ = (k_ < p.K) && bvalid[i];                                               \
+        const float4 v_ =                                                                       \
+            *reinterpret_cast<const float4*>(Bm + (ok_ ? (long long)k_ * p.ldb + brow[i] : 0)); \
+        rb[i] = v_; okm |= (ok_ ? 16u : 0u) << i;                                                              \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  auto store_chunk = [&](int buf) {
+    float* a = As + buf * BM * LDS_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(a + (r0 + 32 * i) * LDS_STRIDE + 4 * cg) = sel4((okm >> i) & 1u, ra[i]);
+    if (!B_KN) {
+      float* b = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(b + (r0 + 32 * i) * LDS_STRIDE + 4 * cg) = sel4((okm >> (4 + i)) & 1u, rb[i]);
+    } else {
+      float* b = Bs + buf * BK * LDS_KN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(b + ((tid >> 5) + 8 * i) * LDS_KN_STRIDE + 4 * (tid & 31)) =
+            sel4((okm >> (4 + i)) & 1u, rb[i]);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  auto compute = [&](int buf) {
+    const float* a = As + buf * BM * LDS_STRIDE + (64 * wm + lr) * LDS_STRIDE + 4 * lk;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float4 af[2], bf[2];
+      af[0] = *reinterpret_cast<const float4*>(a + 8 * kk);
+      af[1] = *reinterpret_cast<const float4*>(a + 32 * LDS_STRIDE + 8 * kk);
+      if (!B_KN) {
+        const float* b = Bs + buf * BN * LDS_STRIDE + (64 * wn + lr) * LDS_STRIDE + 4 * lk;
+        bf[0] = *reinterpret_cast<const float4*>(b + 8 * kk);
+        bf[1] = *reinterpret_cast<const float4*>(b + 32 * LDS_STRIDE + 8 * kk);
+      } else {
+        const float* b = Bs + buf * BK * LDS_KN_STRIDE + (8 * kk + 4 * lk) * LDS_KN_STRIDE + 64 * wn + lr;
+        bf[0] = make_float4(b[0], b[LDS_KN_STRIDE], b[2 * LDS_KN_STRIDE], b[3 * LDS_KN_STRIDE]);
+        bf[1] = make_float4(b[32], b[LDS_KN_STRIDE + 32], b[2 * LDS_KN_STRIDE + 32],
+                            b[3 * LDS_KN_STRIDE + 32]);
+      }
+      const float a0[4] = {af[0].x, af[0].y, af[0].z, af[0].w};
+      const float a1[4] = {af[1].x, af[1].y, af[1].z, af[1].w};
+      const float b0[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
+      const float b1v[4] = {bf[1].x, bf[1].y, bf[1].z, bf[1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1v[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[j], acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: register-staged, LDS double-buffered, one barrier per chunk
+  const int nk = kc1 - kc0;
+  if (nk > 0) {
+    OSM_LOAD_CHUNK(kc0);
+    store_chunk(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = it + 1 < nk;
+      if (more) OSM_LOAD_CHUNK(kc0 + it + 1);
+      compute(cur);
+      if (more) store_chunk(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool partial = p.splitk > 1;
+  float* Cb = partial ? p.ws + ((long long)(ks * p.nbatch + z) * p.M) * p.N
+                      : p.C + b1 * p.sC1 + b2 * p.sC2;
+  const float* Rb = (p.res && !partial) ? p.res + b1 * p.sC1 + b2 * p.sC2 : nullptr;
+  const long long ldc = partial ? (long long)p.N : p.ldc;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + 64 * wn + 32 * tn + lr;
+    if (n >= p.N) continue;
+    const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + 64 * wm + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (m >= p.M) continue;
+        float v = acc[tm][tn][e];
+        if (!partial) {
+          v = v * p.alpha + bv;
+          if (Rb) v += Rb[(long long)m * p.ldr + n];
+          if (p.accumulate) v += Cb[(long long)m * ldc + n];
+        }
+        Cb[(long long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
+// C = alpha * sum_s ws[s] + bias + res (+ C)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
+  const long long total = (long long)p.nbatch * p.M * p.N;
+  const long long slice = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % p.N);
+    const long long mz = i / p.N;
+    const int m = (int)(mz % p.M);
+    const int z = (int)(mz / p.M);
+    float s = 0.f;
+    for (int k = 0; k < p.splitk; ++k) s += p.ws[k * slice + i];
+    const int b1 = z % p.nb1, b2 = z / p.nb1;
+    const long long coff = b1 * p.sC1 + b2 * p.sC2;
+    float v = s * p.alpha + (p.bias ? p.bias[n] : 0.f);
+    if (p.res) v += p.res[coff + (long long)m * p.ldr + n];
+    float* c = p.C + coff + (long long)m * p.ldc + n;
+    if (p.accumulate) v += *c;
+    *c = v;
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                   float* __restrict__ wd, int Cout, int Cin, int k) {
+  const long long total = (long long)Cout * Cin * k * k;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int kw = (int)(i % k);
+    const int kh = (int)((i / k) % k);
+    const int ci = (int)((i / (k * k)) % Cin);
+    const int co = (int)(i / ((long long)k * k * Cin));
+    const float v = w[i];
+    if (wf) wf[((long long)(kh * k + kw) * Cout + co) * Cin + ci] = v;
+    if (wd) wd[((long long)((k - 1 - kh) * k + (k - 1 - kw)) * Cin + ci) * Cout + co] = v;
+  }
+}
+
+int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st) {
+  p.mtiles = (p.M + BM - 1) / BM;
+  p.ntiles = (p.N + BN - 1) / BN;
+  p.nchunks = taps * ((p.K + BK - 1) / BK);
+  if (p.splitk < 1) p.splitk = 1;
+  if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+  dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
+  if (taps == 9) {
+    if (b_kn) return osm::fail(OSM_ERR_UNSUPPORTED, "3x3 conv needs [n][k] weights");
+    hipLaunchKernelGGL((igemm_f32_kernel<9, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
+  } else if (b_kn) {
+    hipLaunchKernelGGL((igemm_f32_kernel<1, true>), grid, dim3(256), 0, st, p.A, p.Bm, p);
+  } else {
+    hipLaunchKernelGGL((igemm_f32_kernel<1, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
+  }
+  int rc = osm::check_launch("igemm_f32_kernel");
+  if (rc) return rc;
+  if (p.splitk > 1) {
+    const long long total = (long long)p.nbatch * p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    rc = osm::check_launch("splitk_reduce_kernel");
+  }
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
+  const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (nbatch > 0 ? nbatch : 1);
+  const int nchunks = taps * ((K + BK - 1) / BK);
+  if (tiles >= 256) return 1;
+  long long s = (512 + tiles - 1) / tiles;  // aim at ~2 workgroups per CU
+  const int max_by_chunks = nchunks / 4 > 0 ? nchunks / 4 : 1;  // >= 4 chunks per slice
+  if (s > max_by_chunks) s = max_by_chunks;
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
+  OSM_REQUIRE(d && d->x && d->w && d->y, "osm_conv2d_nhwc: null pointer");
+  OSM_REQUIRE(d->ksize == 1 || d->ksize == 3, "osm_conv2d_nhwc: ksize must be 1 or 3 (got %d)", d->ksize);
+  OSM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "osm_conv2d_nhwc: bad shape");
+  OSM_REQUIRE(d->Cin % 4 == 0 && d->ldx % 4 == 0, "osm_conv2d_nhwc: Cin and ldx must be multiples of 4");
+  OSM_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout, "osm_conv2d_nhwc: ld smaller than channels");
+  OSM_REQUIRE(osm::aligned16(d->x) && osm::aligned16(d->w), "osm_conv2d_nhwc: x/w must be 16-byte aligned");
+  OSM_REQUIRE(d->splitk <= 1 || d->splitk_ws, "osm_conv2d_nhwc: splitk>1 needs a workspace");
+  OSM_REQUIRE(!d->res || d->ldr >= d->Cout, "osm_conv2d_nhwc: ldr smaller than Cout");
+  IGemmParams p{};
+  p.A = d->x; p.Bm = d->w; p.bias = d->bias; p.res = d->res; p.C = d->y; p.ws = d->splitk_ws;
+  p.M = d->B * d->H * d->W; p.N = d->Cout; p.K = d->Cin; p.H = d->H; p.W = d->W;
+  p.splitk = d->splitk; p.accumulate = d->accumulate; p.alpha = 1.f;
+  p.lda = d->ldx; p.ldb = d->Cin; p.ldc = d->ldy; p.ldr = d->ldr;
+  p.tapstrideB = (long long)d->Cout * d->Cin;
+  p.nb1 = 1; p.nbatch = 1;
+  return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream);
+}
+
+extern "C" int osm_gemm(const osm_gemm_desc* d, void* stream) {
+  OSM_REQUIRE(d && d->A && d->Bm && d->C, "osm_gemm: null pointer");
+  OSM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->nb1 > 0 && d->nb2 > 0, "osm_gemm: bad shape");
+  OSM_REQUIRE(d->K % 4 == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0, "osm_gemm: K, lda, ldb must be multiples of 4");
+  OSM_REQUIRE(!d->b_kn || d->N % 4 == 0, "osm_gemm: [k][n] B needs N %% 4 == 0");
+  OSM_REQUIRE(osm::aligned16(d->A) && osm::aligned16(d->Bm), "osm_gemm: A/B must be 16-byte aligned");
+  OSM_REQUIRE(d->sA1 % 4 == 0 && d->sB1 % 4 == 0 && d->sA2 % 4 == 0 && d->sB2 % 4 == 0,
+              "osm_gemm: batch strides of A/B must be multiples of 4");
+  IGemmParams p{};
+  p.A = d->A; p.Bm = d->Bm; p.bias = d->bias; p.res = d->res; p.C = d->C; p.ws = nullptr;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.H = 1; p.W = d->M;
+  p.splitk = 1; p.accumulate = d->accumulate; p.alpha = d->alpha;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.tapstrideB = 0;
+  p.nb1 = d->nb1; p.nbatch = d->nb1 * d->nb2;
+  p.sA1 = d->sA1; p.sB1 = d->sB1; p.sC1 = d->sC1; p.sA2 = d->sA2; p.sB2 = d->sB2; p.sC2 = d->sC2;
+  return launch(p, 1, d->b_kn != 0, (hipStream_t)stream);
+}
+
+extern "C" int osm_pack_conv_weight(const float* w, float* wf, float* wd, int Cout, int Cin, int k,
+                                    void* stream) {
+  OSM_REQUIRE(w && (wf || wd), "osm_pack_conv_weight: null pointer");
+  OSM_REQUIRE(k == 1 || k == 3, "osm_pack_conv_weight: ksize must be 1 or 3");
+  const long long total = (long long)Cout * Cin * k * k;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wf, wd, Cout, Cin, k);
+  return osm::check_launch("pack_weight_kernel");
+}

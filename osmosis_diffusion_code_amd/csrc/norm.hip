@@ -1,0 +1,313 @@
+// GroupNorm(32) (+FiLM scale/shift) (+SiLU), forward and data-gradient, on NHWC matrix views.
+// Reference: nn.py:17-19,93-100 (GroupNorm32, fp32, eps 1e-5), unet.py:263,287 (SiLU),
+// unet.py:327-331 (out_norm(h) * (1 + scale) + shift).
+//
+// HBM-bound.  NHWC makes a group's channels contiguous inside a pixel row, so one workgroup sweeps a
+// slab of full pixel rows with 16-byte coalesced loads and keeps per-thread partial sums for the
+// (fixed) channel vector(s) it owns; a structured (deterministic, atomics-free) LDS pass folds
+// threads into the 32 groups; chunk partials are combined in fp64 by a finalize kernel.
+//   pass 1 (stats / grad-stats):  read x (and dy)         -> [B][chunk][G][2] partials -> [B][G][2]
+//   pass 2 (apply / grad-apply):  read x (and dy), write y / dx
+#include "osm_common.h"
+
+namespace {
+
+constexpr int PPC = 64;   // pixel rows per chunk (one workgroup)
+constexpr int NJMAX = 4;  // channel vectors per thread (C <= 4096)
+
+struct GNArgs {
+  const float* x;
+  const float* dy;
+  const float* stats;   // [B][G][2] mean, rstd
+  const float* gstats;  // [B][G][2] m1, m2 (backward)
+  const float* gamma;
+  const float* beta;
+  const float* film;    // [B][2C] or null
+  const float* addend;
+  float* out;
+  float* part;
+  long long ldx, lddy, ldo, ldadd, ldf;
+  int B, HW, C, G, gs, nchunk, silu;
+  float eps;
+};
+
+__device__ __forceinline__ void gn_fwd_elem(float x, float mean, float rstd, float ga, float be,
+                                            bool film, float sc, float sh, float& xh, float& z) {
+  xh = (x - mean) * rstd;
+  z = xh * ga + be;
+  if (film) z = z * (1.0f + sc) + sh;
+}
+
+// MODE 0: sums of (x, x^2).   MODE 1: sums of (dxh, dxh*xh) for the backward.
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
+  __shared__ float red[256 * NJMAX * 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int vpr = a.C / VEC;
+  const int colT = vpr < 256 ? vpr : 256;
+  const int rowT = 256 / colT;
+  const int nj = (vpr + 255) / 256;
+  const int tc = tid % colT, tr = tid / colT;
+  const int p0 = chunk * PPC;
+  const int p1 = min(a.HW, p0 + PPC);
+
+  float s1[NJMAX], s2[NJMAX];
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) s1[j] = s2[j] = 0.f;
+
+  if (tr < rowT) {
+#pragma unroll
+    for (int j = 0; j < NJMAX; ++j) {
+      const int v = tc + colT * j;
+      if (j >= nj || v >= vpr) break;
+      const int c = v * VEC;
+      const int g = c / a.gs;
+      float mean = 0.f, rstd = 0.f;
+      float ga[VEC], be[VEC], sc[VEC], sh[VEC];
+      if (MODE == 1) {
+        mean = a.stats[(b * a.G + g) * 2];
+        rstd = a.stats[(b * a.G + g) * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          ga[e] = a.gamma[c + e];
+          be[e] = a.beta[c + e];
+          sc[e] = a.film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
+          sh[e] = a.film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
+        }
+      }
+      for (int p = p0 + tr; p < p1; p += rowT) {
+        const long long row = (long long)b * a.HW + p;
+        float xv[VEC], dv[VEC];
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+          if (MODE == 1) {
+            const float4 u = *reinterpret_cast<const float4*>(a.dy + row * a.lddy + c);
+            dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
+          }
+        } else {
+          xv[0] = a.x[row * a.ldx + c];
+          if (MODE == 1) dv[0] = a.dy[row * a.lddy + c];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (MODE == 0) {
+            s1[j] += xv[e];
+            s2[j] += xv[e] * xv[e];
+          } else {
+            float xh, z;
+            gn_fwd_elem(xv[e], mean, rstd, ga[e], be[e], a.film != nullptr, sc[e], sh[e], xh, z);
+            float dz = dv[e] * (a.silu ? osm::dsilu_f(z) : 1.0f);
+            if (a.film) dz *= (1.0f + sc[e]);
+            const float dxh = dz * ga[e];
+            s1[j] += dxh;
+            s2[j] += dxh * xh;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) {
+    red[(tid * NJMAX + j) * 2] = s1[j];
+    red[(tid * NJMAX + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  if (tid < a.G) {
+    const int g = tid;
+    const int v0 = g * a.gs / VEC, v1 = (g + 1) * a.gs / VEC;
+    float t1 = 0.f, t2 = 0.f;
+    for (int v = v0; v < v1; ++v) {
+      const int c_t = v % colT, j = v / colT;
+      for (int r = 0; r < rowT; ++r) {
+        const int t = r * colT + c_t;
+        t1 += red[(t * NJMAX + j) * 2];
+        t2 += red[(t * NJMAX + j) * 2 + 1];
+      }
+    }
+    float* o = a.part + (((long long)b * a.nchunk + chunk) * a.G + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+template <int MODE>
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int G,
+                                   int nchunk, double n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * G) return;
+  const int b = i / G, g = i % G;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* pp = part + (((long long)b * nchunk + k) * G + g) * 2;
+    s1 += (double)pp[0];
+    s2 += (double)pp[1];
+  }
+  if (MODE == 0) {
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[i * 2] = (float)mean;
+    out[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out[i * 2] = (float)(s1 / n);
+    out[i * 2 + 1] = (float)(s2 / n);
+  }
+}
+
+// MODE 0: y = act(GN(x)).   MODE 1: dx = dGN(dy) (+ addend)
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
+  const int vpr = a.C / VEC;
+  const long long total = (long long)a.B * a.HW * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / vpr;
+    const int v = (int)(i - row * vpr);
+    const int c = v * VEC;
+    const int b = (int)(row / a.HW);
+    const int g = c / a.gs;
+    const float mean = a.stats[(b * a.G + g) * 2];
+    const float rstd = a.stats[(b * a.G + g) * 2 + 1];
+    float m1 = 0.f, m2 = 0.f;
+    if (MODE == 1) {
+      m1 = a.gstats[(b * a.G + g) * 2];
+      m2 = a.gstats[(b * a.G + g) * 2 + 1];
+    }
+    float xv[VEC], dv[VEC], ov[VEC], av[VEC];
+    if (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      if (MODE == 1) {
+        const float4 u = *reinterpret_cast<const float4*>(a.dy + row * a.lddy + c);
+        dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
+        if (a.addend) {
+          const float4 w = *reinterpret_cast<const float4*>(a.addend + row * a.ldadd + c);
+          av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
+        }
+      }
+    } else {
+      xv[0] = a.x[row * a.ldx + c];
+      if (MODE == 1) {
+        dv[0] = a.dy[row * a.lddy + c];
+        if (a.addend) av[0] = a.addend[row * a.ldadd + c];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float ga = a.gamma[c + e], be = a.beta[c + e];
+      const float sc = a.film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
+      const float sh = a.film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
+      float xh, z;
+      gn_fwd_elem(xv[e], mean, rstd, ga, be, a.film != nullptr, sc, sh, xh, z);
+      if (MODE == 0) {
+        ov[e] = a.silu ? osm::silu_f(z) : z;
+      } else {
+        float dz = dv[e] * (a.silu ? osm::dsilu_f(z) : 1.0f);
+        if (a.film) dz *= (1.0f + sc);
+        const float dxh = dz * ga;
+        float r = rstd * (dxh - m1 - xh * m2);
+        if (a.addend) r += av[e];
+        ov[e] = r;
+      }
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+      a.out[row * a.ldo + c] = ov[0];
+    }
+  }
+}
+
+bool use_vec4(const GNArgs& a) {
+  return a.gs % 4 == 0 && a.ldx % 4 == 0 && osm::aligned16(a.x) &&
+         (!a.dy || (a.lddy % 4 == 0 && osm::aligned16(a.dy))) &&
+         (!a.out || (a.ldo % 4 == 0 && osm::aligned16(a.out))) &&
+         (!a.addend || (a.ldadd % 4 == 0 && osm::aligned16(a.addend)));
+}
+
+int check_common(const GNArgs& a, const char* who) {
+  OSM_REQUIRE(a.B > 0 && a.HW > 0 && a.C > 0 && a.G > 0, "%s: bad shape", who);
+  OSM_REQUIRE(a.C % a.G == 0, "%s: C (%d) not divisible by G (%d)", who, a.C, a.G);
+  OSM_REQUIRE(a.G <= 256, "%s: G must be <= 256", who);
+  OSM_REQUIRE(a.C <= 256 * NJMAX * 4, "%s: C too large", who);
+  return OSM_OK;
+}
+
+template <int MODE>
+int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
+  a.nchunk = (a.HW + PPC - 1) / PPC;
+  a.gs = a.C / a.G;
+  dim3 grid(a.nchunk, a.B);
+  const bool v4 = use_vec4(a);
+  if (!v4) OSM_REQUIRE(a.C <= 256 * NJMAX, "GroupNorm scalar path: C too large");
+  if (v4)
+    hipLaunchKernelGGL((gn_reduce_kernel<4, MODE>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gn_reduce_kernel<1, MODE>), grid, dim3(256), 0, st, a);
+  int rc = osm::check_launch("gn_reduce_kernel");
+  if (rc) return rc;
+  const int n = a.B * a.G;
+  hipLaunchKernelGGL((gn_finalize_kernel<MODE>), dim3((n + 63) / 64), dim3(64), 0, st, a.part, finalized, a.B,
+                     a.G, a.nchunk, (double)a.HW * a.gs, a.eps);
+  return osm::check_launch("gn_finalize_kernel");
+}
+
+template <int MODE>
+int run_apply(GNArgs& a, hipStream_t st) {
+  a.gs = a.C / a.G;
+  const bool v4 = use_vec4(a);
+  const long long total = (long long)a.B * a.HW * (a.C / (v4 ? 4 : 1));
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (v4)
+    hipLaunchKernelGGL((gn_apply_kernel<4, MODE>), dim3((int)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<1, MODE>), dim3((int)blocks), dim3(256), 0, st, a);
+  return osm::check_launch("gn_apply_kernel");
+}
+
+}  // namespace
+
+extern "C" int osm_gn_nchunk(int HW) { return (HW + PPC - 1) / PPC; }
+
+extern "C" int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C, int G, float eps,
+                            float* part, float* stats, void* stream) {
+  OSM_REQUIRE(x && part && stats, "osm_gn_stats: null pointer");
+  GNArgs a{};
+  a.x = x; a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
+  int rc = check_common(a, "osm_gn_stats");
+  if (rc) return rc;
+  return run_reduce<0>(a, stats, (hipStream_t)stream);
+}
+
+extern "C" int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C,
+                            int G, const float* stats, const float* gamma, const float* beta,
+                            const float* film, long long ldfilm, int silu, void* stream) {
+  OSM_REQUIRE(x && y && stats && gamma && beta, "osm_gn_apply: null pointer");
+  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_apply: ldfilm smaller than 2*C");
+  GNArgs a{};
+  a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
+  int rc = check_common(a, "osm_gn_apply");
+  if (rc) return rc;
+  return run_apply<0>(a, (hipStream_t)stream);
+}
+
+extern "C" int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx,
+                          long long lddx, const float* addend, long long ldadd, int B, int HW, int C, int G,
+                          const float* stats, const float* gamma, const float* beta, const float* film,
+                          long long ldfilm, int silu, float* part, float* gstats, void* stream) {
+  OSM_REQUIRE(x && dy && dx && stats && gamma && beta && part && gstats, "osm_gn_bwd: null pointer");
+  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd: ldfilm smaller than 2*C");
+  GNArgs a{};
+  a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.addend = addend; a.ldadd = ldadd;
+  a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
+  a.film = film; a.ldf = ldfilm; a.silu = silu; a.part = part;
+  int rc = check_common(a, "osm_gn_bwd");
+  if (rc) return rc;
+  rc = run_reduce<1>(a, gstats, (hipStream_t)stream);
+  if (rc) return rc;
+  return run_apply<1>(a, (hipStream_t)stream);
+}

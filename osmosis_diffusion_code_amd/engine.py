@@ -1,0 +1,507 @@
+"""UNetEngine: the reference UNet (guided_diffusion/unet.py:713-742) as a recorded plan of gfx950
+kernel launches over persistent NHWC buffers, forward and data-gradient.
+
+Design (MI355X-first, not a module-by-module translation):
+  * activations are NHWC matrices [B*H*W][C] in HBM; every kernel takes a row stride, so the
+    UNet's skip concatenations (`th.cat([h, hs.pop()], dim=1)`, unet.py:739) are ZERO-COPY: an
+    input block writes its output straight into the right-hand columns of the buffer the matching
+    output block will read, and the split of the concat gradient in backward is a pair of views;
+  * weights are repacked once per engine into two images per conv -- [tap][Cout][Cin] for forward
+    and the flipped/transposed [tap][Cin][Cout] for the data gradient -- so forward and backward
+    run the SAME implicit-GEMM kernel (csrc/igemm.hip); 288 GB of HBM makes the 2x weight copy and
+    the un-recomputed activation stash (~8 GB / image at 256x256) a non-issue;
+  * guidance needs d(out)/d(x) only (condition_methods.py:186-194): no weight gradients exist;
+  * attention (T <= 1024, 64-wide heads) keeps P = softmax(QK^T) instead of re-running the block
+    in backward (the reference checkpoints it, unet.py:376 / nn.py:142-170 -- same values);
+  * the first forward/backward executes the kernels while a Recorder captures the (function, args)
+    list; later steps replay that list (no Python per-op work) and can be captured in a hipGraph.
+
+Per ResBlock (unet.py:315-335):   GN+SiLU -> [pool|upsample] -> conv3x3 -> GN*(1+s)+t, SiLU -> conv3x3 (+skip)
+Per AttentionBlock (:378-433):    GN -> qkv 1x1 -> per-head softmax(q k^T / sqrt(ch)) v -> proj 1x1 (+x)
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import OsmosisHipError, Recorder, current_stream_ptr
+from .ops import Mat
+
+G = 32  # GroupNorm32 groups (nn.py:93-100)
+
+
+class _Conv:
+    def __init__(self, slot, dev):
+        w = slot.weight.detach().to(dev, torch.float32)
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.k = w.shape[2] if w.dim() == 4 else 1
+        self.wf, self.wd = ops.pack_conv_weight(w)
+        self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
+
+
+class _Norm:
+    def __init__(self, slot, dev):
+        self.g = slot.weight.detach().to(dev, torch.float32).contiguous()
+        self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
+
+
+class _Res:
+    def __init__(self, p, dev):
+        self.cin, self.cout, self.up, self.down = p.cin, p.cout, p.up, p.down
+        self.n1 = _Norm(p.in_layers.at(0), dev)
+        self.c1 = _Conv(p.in_layers.at(2), dev)
+        e = p.emb_layers.at(1)
+        self.ew = e.weight.detach().to(dev, torch.float32).contiguous()
+        self.eb = e.bias.detach().to(dev, torch.float32).contiguous()
+        self.n2 = _Norm(p.out_layers.at(0), dev)
+        self.c2 = _Conv(p.out_layers.at(3), dev)
+        self.skip = _Conv(p.skip_connection, dev) if p.skip_connection is not None else None
+        self.saved = None
+
+
+class _Attn:
+    def __init__(self, p, dev):
+        self.ch, self.heads, self.new_order = p.ch, p.heads, p.new_order
+        self.norm = _Norm(p.norm, dev)
+        self.qkv = _Conv(p.qkv, dev)
+        self.proj = _Conv(p.proj_out, dev)
+        self.saved = None
+
+
+class UNetEngine:
+    def __init__(self, model, B: int, H: int, W: int, dev):
+        self.B, self.H, self.W, self.dev = B, H, W, dev
+        self.mc = model.model_channels
+        self.ted = 4 * self.mc
+        self.cin, self.cout = model.in_channels, model.out_channels
+        nlev = len(model.channel_mult)
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
+            raise ValueError(f"H, W must be divisible by {1 << (nlev - 1)}")
+        self.ticket = 0
+        self.params_version = None
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self._fwd_plan: Optional[Recorder] = None
+        self._bwd_plan: Optional[Recorder] = None
+        self._plan_stream = None
+        self._splitk_ws = None
+
+        def wrap(m):
+            from .guided_diffusion.unet import AttentionParams, ResBlockParams
+            if isinstance(m, ResBlockParams):
+                return _Res(m, dev)
+            if isinstance(m, AttentionParams):
+                return _Attn(m, dev)
+            return _Conv(m, dev)
+
+        def seq(s):
+            return [wrap(m) for _, m in sorted(((int(k), v) for k, v in s._modules.items()), key=lambda kv: kv[0])]
+
+        te = model.time_embed
+        self.te0 = (te.at(0).weight.detach().to(dev).contiguous(), te.at(0).bias.detach().to(dev).contiguous())
+        self.te2 = (te.at(2).weight.detach().to(dev).contiguous(), te.at(2).bias.detach().to(dev).contiguous())
+        self.inp = [seq(s) for s in model.input_blocks]
+        self.mid = seq(model.middle_block)
+        self.outb = [seq(s) for s in model.output_blocks]
+        self.out_norm = _Norm(model.out.at(0), dev)
+        self.out_conv = _Conv(model.out.at(2), dev)
+
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.x_in = torch.zeros(B, self.cin, H, W, **f32)
+        self.t_dev = torch.zeros(B, **f32)
+        self.out = torch.zeros(B, self.cout, H, W, **f32)
+        self.d_out = torch.zeros(B, self.cout, H, W, **f32)
+        self.dx = torch.zeros(B, self.cin, H, W, **f32)
+        self.gn_part = torch.empty(B * ops.gn_nchunk(H * W) * G * 2, **f32)
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, rows, cols) -> Mat:
+        return Mat.of(torch.empty(rows, cols, device=self.dev, dtype=torch.float32))
+
+    def _small(self, n) -> torch.Tensor:
+        return torch.empty(n, device=self.dev, dtype=torch.float32)
+
+    def _scr(self, slot: str, rows: int, cols: int) -> Mat:
+        """Scratch matrix (contents live only until the next use of the same slot)."""
+        need = rows * cols
+        t = self._scratch.get(slot)
+        if t is None or t.numel() < need:
+            t = torch.empty(max(need, 1), device=self.dev, dtype=torch.float32)
+            self._scratch[slot] = t
+        return Mat.of(t[:need].view(rows, cols))
+
+    def _scr_flat(self, slot: str, n: int) -> torch.Tensor:
+        t = self._scratch.get(slot)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 1), device=self.dev, dtype=torch.float32)
+            self._scratch[slot] = t
+        return t[:n]
+
+    def _conv(self, x: Mat, cv: _Conv, y: Mat, hw: Tuple[int, int], dgrad=False, res: Optional[Mat] = None,
+              accumulate=False):
+        H, W = hw
+        M = self.B * H * W
+        cin = cv.cout if dgrad else cv.cin
+        cout = cv.cin if dgrad else cv.cout
+        assert x.cols == cin and y.cols == cout and x.rows == M and y.rows == M, (x.cols, cin, y.cols, cout)
+        sk = ops.splitk_hint(M, cout, cin, cv.k * cv.k, 1)
+        ws = None
+        if sk > 1:
+            ws = self._scr_flat("splitk", sk * M * cout)
+        ops.conv2d(x, cv.wd if dgrad else cv.wf, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
+                   accumulate=accumulate, splitk=sk, splitk_ws=ws)
+
+    # ------------------------------------------------------------------ ResBlock
+    def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):
+        B = self.B
+        H, W = hw
+        HW = H * W
+        M = B * HW
+        st1 = self._small(B * G * 2)
+        ops.gn_stats(x, B, HW, G, self.gn_part, st1)
+        a1 = self._scr("a", M, blk.cin)
+        ops.gn_apply(x, a1, B, HW, G, st1, blk.n1.g, blk.n1.b, silu=True)
+        if blk.up:
+            ho, wo = 2 * H, 2 * W
+            a1r = self._scr("b", B * ho * wo, blk.cin)
+            ops.upsample2x(a1, a1r, B, H, W, 1.0)
+            xs = self._scr("c", B * ho * wo, blk.cin)
+            ops.upsample2x(x, xs, B, H, W, 1.0)
+        elif blk.down:
+            ho, wo = H // 2, W // 2
+            a1r = self._scr("b", B * ho * wo, blk.cin)
+            ops.pool2x2(a1, a1r, B, H, W, 0.25)
+            xs = self._scr("c", B * ho * wo, blk.cin)
+            ops.pool2x2(x, xs, B, H, W, 0.25)
+        else:
+            ho, wo = H, W
+            a1r, xs = a1, x
+        Mo = B * ho * wo
+        h1 = self._buf(Mo, blk.cout)
+        self._conv(a1r, blk.c1, h1, (ho, wo))
+        film = torch.empty(B, 2 * blk.cout, device=self.dev, dtype=torch.float32)
+        ops.linear(self.emb, blk.ew, blk.eb, film, B, self.ted, 2 * blk.cout, silu_in=True)
+        st2 = self._small(B * G * 2)
+        ops.gn_stats(h1, B, ho * wo, G, self.gn_part, st2)
+        a2 = self._scr("a", Mo, blk.cout)
+        ops.gn_apply(h1, a2, B, ho * wo, G, st2, blk.n2.g, blk.n2.b, film=film, silu=True)
+        if blk.skip is not None:
+            self._conv(xs, blk.skip, dst, (ho, wo))
+            res = dst
+        else:
+            res = xs
+        self._conv(a2, blk.c2, dst, (ho, wo), res=res)
+        blk.saved = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo))
+        return (ho, wo)
+
+    def _res_bwd(self, blk: _Res, dy: Mat, dx_dst: Mat, accumulate: bool):
+        s = blk.saved
+        B = self.B
+        H, W = s["hw"]
+        ho, wo = s["hwo"]
+        M, Mo = B * H * W, B * ho * wo
+        dh2 = self._scr("a", Mo, blk.cout)
+        self._conv(dy, blk.c2, dh2, (ho, wo), dgrad=True)
+        dh1 = self._scr("b", Mo, blk.cout)
+        gst = self._small(B * G * 2)
+        ops.gn_bwd(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], blk.n2.g, blk.n2.b, self.gn_part, gst,
+                   film=s["film"], silu=True)
+        da1r = self._scr("a", Mo, blk.cin)
+        self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True)
+        if blk.up:      # forward: nearest 2x upsample  -> backward: 2x2 sum
+            da1 = self._scr("b", M, blk.cin)
+            ops.pool2x2(da1r, da1, B, ho, wo, 1.0)
+        elif blk.down:  # forward: 2x2 average          -> backward: replicate / 4
+            da1 = self._scr("b", M, blk.cin)
+            ops.upsample2x(da1r, da1, B, ho, wo, 0.25)
+        else:
+            da1 = da1r
+        # skip path gradient into dx_dst, then dx_dst = dGN(da1) + dx_dst
+        if blk.up or blk.down:
+            assert blk.skip is None
+            t = self._scr("c", M, blk.cin)
+            if blk.up:
+                ops.pool2x2(dy, t, B, ho, wo, 1.0)
+            else:
+                ops.upsample2x(dy, t, B, ho, wo, 0.25)
+            if accumulate:
+                ops.copy2d(t, dx_dst, accumulate=True)
+                add = dx_dst
+            else:
+                add = t
+        elif blk.skip is not None:
+            self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate)
+            add = dx_dst
+        else:
+            if accumulate:
+                ops.copy2d(dy, dx_dst, accumulate=True)
+                add = dx_dst
+            else:
+                add = dy
+        gst1 = self._small(B * G * 2)
+        ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
+                   silu=True, addend=add)
+
+    # ------------------------------------------------------------------ Attention
+    def _attn_offsets(self, blk: _Attn):
+        C, nh = blk.ch, blk.heads
+        ch = C // nh
+        if blk.new_order:   # q,k,v = qkv.chunk(3) then heads       (unet.py:459-467)
+            return ch, (0, C, 2 * C), ch
+        return ch, (0, ch, 2 * ch), 3 * ch      # legacy: per head [q|k|v]  (unet.py:426)
+
+    def _attn_fwd(self, blk: _Attn, x: Mat, dst: Mat, hw):
+        B = self.B
+        T = hw[0] * hw[1]
+        M = B * T
+        C, nh = blk.ch, blk.heads
+        ch, (qo, ko, vo), hs = self._attn_offsets(blk)
+        st = self._small(B * G * 2)
+        ops.gn_stats(x, B, T, G, self.gn_part, st)
+        xn = self._scr("a", M, C)
+        ops.gn_apply(x, xn, B, T, G, st, blk.norm.g, blk.norm.b, silu=False)
+        qkv = self._buf(M, 3 * C)
+        self._conv(xn, blk.qkv, qkv, hw)
+        nmat = B * nh
+        S = self._scr_flat("s0", nmat * T * T)
+        alpha = 1.0 / math.sqrt(ch)     # (q*ch^-1/4)·(k*ch^-1/4)
+        ops.gemm(qkv.t, 3 * C, qkv.t, 3 * C, S, T, T, T, ch, b_kn=False, alpha=alpha, nb1=nh, nb2=B,
+                 sA=(hs, T * 3 * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), a_off=qo, b_off=ko)
+        P = self._small(nmat * T * T)
+        PT = self._small(nmat * T * T)
+        ops.softmax_rows(S, P, PT, nmat, T)
+        a = self._scr("b", M, C)
+        ops.gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+                 sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
+        self._conv(a, blk.proj, dst, hw, res=x)
+        blk.saved = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw)
+        return hw
+
+    def _attn_bwd(self, blk: _Attn, dy: Mat, dx_dst: Mat, accumulate: bool):
+        s = blk.saved
+        B = self.B
+        hw = s["hw"]
+        T = hw[0] * hw[1]
+        M = B * T
+        C, nh = blk.ch, blk.heads
+        ch, (qo, ko, vo), hs = self._attn_offsets(blk)
+        nmat = B * nh
+        qkv, P, PT = s["qkv"], s["P"], s["PT"]
+        alpha = 1.0 / math.sqrt(ch)
+        da = self._scr("a", M, C)
+        self._conv(dy, blk.proj, da, hw, dgrad=True)
+        dP = self._scr_flat("s0", nmat * T * T)
+        ops.gemm(da.t, C, qkv.t, 3 * C, dP, T, T, T, ch, b_kn=False, nb1=nh, nb2=B,
+                 sA=(ch, T * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), b_off=vo)
+        dS = self._scr_flat("s1", nmat * T * T)
+        dST = self._scr_flat("s2", nmat * T * T)
+        ops.softmax_rows_bwd(P, dP, dS, dST, nmat, T)
+        dqkv = self._scr("b", M, 3 * C)
+        sQ = (hs, T * 3 * C)
+        # dq = alpha * dS k ; dk = alpha * dS^T q ; dv = P^T da
+        ops.gemm(dS, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+                 sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=ko, c_off=qo)
+        ops.gemm(dST, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+                 sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=qo, c_off=ko)
+        ops.gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+                 sA=(T * T, nh * T * T), sB=(ch, T * C), sC=sQ, c_off=vo)
+        dxn = self._scr("a", M, C)
+        self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
+        if accumulate:
+            ops.copy2d(dy, dx_dst, accumulate=True)
+            add = dx_dst
+        else:
+            add = dy
+        gst = self._small(B * G * 2)
+        ops.gn_bwd(s["x"], dxn, dx_dst, B, T, G, s["st"], blk.norm.g, blk.norm.b, self.gn_part, gst,
+                   silu=False, addend=add)
+
+    # ------------------------------------------------------------------ whole network
+    @staticmethod
+    def _out_ch(layers, cin):
+        c = cin
+        for l in layers:
+            if isinstance(l, _Res):
+                c = l.cout
+        return c
+
+    def _run_layers_fwd(self, layers, h: Mat, hw, dst: Mat):
+        for i, l in enumerate(layers):
+            last = i == len(layers) - 1
+            if isinstance(l, _Res):
+                ho = (hw[0] * 2, hw[1] * 2) if l.up else ((hw[0] // 2, hw[1] // 2) if l.down else hw)
+                d = dst if last else self._buf(self.B * ho[0] * ho[1], l.cout)
+                hw = self._res_fwd(l, h, d, hw)
+            elif isinstance(l, _Attn):
+                d = dst if last else self._buf(h.rows, l.ch)
+                hw = self._attn_fwd(l, h, d, hw)
+            else:
+                raise AssertionError
+            h = d
+        return h, hw
+
+    def _run_layers_bwd(self, layers, dy: Mat, dx_dst: Mat, accumulate: bool):
+        for i in range(len(layers) - 1, -1, -1):
+            l = layers[i]
+            first = i == 0
+            x_saved = l.saved["x"]
+            d = dx_dst if first else self._buf(x_saved.rows, x_saved.cols)
+            acc = accumulate if first else False
+            if isinstance(l, _Res):
+                self._res_bwd(l, dy, d, acc)
+            else:
+                self._attn_bwd(l, dy, d, acc)
+            dy = d
+
+    def _forward_impl(self):
+        B, H, W = self.B, self.H, self.W
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        # ---- timestep embedding MLP (nn.py:103-121, unet.py:550-554, 727)
+        temb = torch.empty(B, self.mc, **f32)
+        ops.timestep_embedding(self.t_dev, temb, B, self.mc)
+        e1 = torch.empty(B, self.ted, **f32)
+        ops.linear(temb, self.te0[0], self.te0[1], e1, B, self.mc, self.ted, silu_out=True)
+        self.emb = torch.empty(B, self.ted, **f32)
+        ops.linear(e1, self.te2[0], self.te2[1], self.emb, B, self.ted, self.ted)
+
+        # ---- channel bookkeeping for the zero-copy concatenations
+        stem: _Conv = self.inp[0][0]
+        chans = [stem.cout]
+        c = stem.cout
+        for layers in self.inp[1:]:
+            c = self._out_ch(layers, c)
+            chans.append(c)
+        n_in = len(self.inp)
+        c_mid = self._out_ch(self.mid, c)
+        # output block i reads cat(h_i, hs[n_in-1-i]); h_0 = middle output
+        hws = []           # resolution of each input block output
+        hw = (H, W)
+        for layers in self.inp:
+            for l in layers:
+                if isinstance(l, _Res) and l.down:
+                    hw = (hw[0] // 2, hw[1] // 2)
+            hws.append(hw)
+        c_h = c_mid
+        self.cat: List[Mat] = []
+        self.cat_split: List[int] = []
+        for i, layers in enumerate(self.outb):
+            j = n_in - 1 - i
+            rows = B * hws[j][0] * hws[j][1]
+            self.cat.append(self._buf(rows, c_h + chans[j]))
+            self.cat_split.append(c_h)
+            assert layers[0].cin == c_h + chans[j], (layers[0].cin, c_h, chans[j])
+            c_h = self._out_ch(layers, c_h + chans[j])
+
+        def skip_dst(j):
+            i = n_in - 1 - j
+            return self.cat[i].cols_slice(self.cat_split[i], self.cat[i].cols)
+
+        # ---- input blocks
+        x_nhwc = self._buf(B * H * W, self.cin)
+        ops.nchw_to_nhwc(self.x_in, x_nhwc, B, self.cin, H * W)
+        h = skip_dst(0)
+        self._conv(x_nhwc, stem, h, (H, W))
+        hw = (H, W)
+        for j in range(1, n_in):
+            h, hw = self._run_layers_fwd(self.inp[j], h, hw, skip_dst(j))
+        # ---- middle, writing into the left columns of the first concat buffer
+        h, hw = self._run_layers_fwd(self.mid, h, hw, self.cat[0].cols_slice(0, self.cat_split[0]))
+        # ---- output blocks
+        for i, layers in enumerate(self.outb):
+            if i + 1 < len(self.outb):
+                dst = self.cat[i + 1].cols_slice(0, self.cat_split[i + 1])
+            else:
+                dst = self._buf(B * H * W, c_h)
+            h, hw = self._run_layers_fwd(layers, self.cat[i], hw, dst)
+        assert hw == (H, W)
+        # ---- head: GN, SiLU, conv3x3 -> NCHW
+        self.h_last = h
+        self.st_out = self._small(B * G * 2)
+        ops.gn_stats(h, B, H * W, G, self.gn_part, self.st_out)
+        a = self._scr("a", B * H * W, h.cols)
+        ops.gn_apply(h, a, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, silu=True)
+        o = self._buf(B * H * W, self.cout)
+        self._conv(a, self.out_conv, o, (H, W))
+        ops.nhwc_to_nchw(o, self.out, B, self.cout, H * W)
+        self.x_nhwc = x_nhwc
+
+    def _backward_impl(self):
+        B, H, W = self.B, self.H, self.W
+        n_in = len(self.inp)
+        do = self._buf(B * H * W, self.cout)
+        ops.nchw_to_nhwc(self.d_out, do, B, self.cout, H * W)
+        da = self._scr("a", B * H * W, self.h_last.cols)
+        self._conv(do, self.out_conv, da, (H, W), dgrad=True)
+        dy = self._buf(B * H * W, self.h_last.cols)
+        gst = self._small(B * G * 2)
+        ops.gn_bwd(self.h_last, da, dy, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, self.gn_part,
+                   gst, silu=True)
+        # ---- output blocks in reverse; dcat[i] receives d/d(cat_i) at full width
+        dcat: List[Optional[Mat]] = [None] * len(self.outb)
+        for i in range(len(self.outb) - 1, -1, -1):
+            dcat[i] = self._buf(self.cat[i].rows, self.cat[i].cols)
+            self._run_layers_bwd(self.outb[i], dy, dcat[i], accumulate=False)
+            dy = dcat[i].cols_slice(0, self.cat_split[i])
+
+        def dskip(j):
+            i = n_in - 1 - j
+            return dcat[i].cols_slice(self.cat_split[i], dcat[i].cols)
+
+        # ---- middle: its input is hs[n_in-1], which already holds the concat contribution
+        self._run_layers_bwd(self.mid, dy, dskip(n_in - 1), accumulate=True)
+        for j in range(n_in - 1, 0, -1):
+            self._run_layers_bwd(self.inp[j], dskip(j), dskip(j - 1), accumulate=True)
+        dxn = self._buf(B * H * W, self.cin)
+        self._conv(dskip(0), self.inp[0][0], dxn, (H, W), dgrad=True)
+        ops.nhwc_to_nchw(dxn, self.dx, B, self.cin, H * W)
+
+    # ------------------------------------------------------------------ public
+    def _check_stream(self):
+        s = current_stream_ptr()
+        if self._plan_stream is not None and s != self._plan_stream:
+            # plans are bound to the stream they were recorded on
+            self._fwd_plan = self._bwd_plan = None
+        self._plan_stream = s
+
+    def load_inputs(self, x: torch.Tensor, timesteps: torch.Tensor):
+        self.x_in.copy_(x.detach())
+        self.t_dev.copy_(timesteps.detach().to(torch.float32))
+
+    def run_forward(self):
+        """Launch the forward plan on the current stream (inputs already in x_in / t_dev)."""
+        self._check_stream()
+        self.ticket += 1
+        if self._fwd_plan is None:
+            self._bwd_plan = None
+            with Recorder() as rec:
+                self._forward_impl()
+            self._fwd_plan = rec
+        else:
+            self._fwd_plan.replay()
+
+    def run_backward(self):
+        """Launch the data-gradient plan (d_out holds dL/d(out), result lands in dx)."""
+        self._check_stream()
+        if self._fwd_plan is None:
+            raise OsmosisHipError("backward before forward")
+        if self._bwd_plan is None:
+            with Recorder() as rec:
+                self._backward_impl()
+            self._bwd_plan = rec
+        else:
+            self._bwd_plan.replay()
+
+    def forward(self, x, timesteps, need_grad=True):
+        if not x.is_cuda:
+            raise OsmosisHipError("UNet input must live on the HIP device (no CPU fallback)")
+        self.load_inputs(x, timesteps)
+        self.run_forward()
+        return self.out
+
+    def backward(self, grad_out):
+        self.d_out.copy_(grad_out)
+        self.run_backward()
+        return self.dx
+
+    def n_launches(self):
+        return (len(self._fwd_plan) if self._fwd_plan else 0, len(self._bwd_plan) if self._bwd_plan else 0)

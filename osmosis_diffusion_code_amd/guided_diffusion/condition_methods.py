@@ -1,0 +1,232 @@
+"""Conditioning (guidance) methods -- registry surface of the reference's
+guided_diffusion/condition_methods.py (register/get_conditioning_method :11-24).
+
+`PosteriorSamplingOsmosis` ('osmosis', reference :61-231) is re-designed around three fused HIP
+kernels (csrc/guidance.hip):
+    osm_phys_reduce    forward model + weighted residual + all per-image reductions   (:109-144)
+    osm_phys_finalize  loss value, dL/dphi, in-place SGD on phi                        (:185-197)
+    osm_phys_grad      analytic dL/dx0 (data term + auxiliary losses)                  (:176-194)
+so the n_iter(=20) inner phi-optimisation runs back-to-back on the device with no host sync (the
+reference copies the residual to the host every inner iteration, :130).  Reductions are per image,
+which equals the reference at its only working batch size (1) and defines B>1 as independent images.
+
+Two ways in:
+  * `loss_grad_x0(x0, y, freeze_phi)` -- used by the fused sampler step
+    (gaussian_diffusion.GaussianDiffusion.p_sample_loop fast path);
+  * `conditioning(x_prev=, x_t=, x_0_hat=, measurement=, ...)` -- the reference signature and
+    5-tuple; works with any autograd graph from x_prev to x_0_hat (our UNet is an autograd.Function).
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import PhysDesc
+from ..osmosis_utils import losses as losseso
+from ..osmosis_utils import utils as utilso
+
+__CONDITIONING_METHOD__ = {}
+
+
+def register_conditioning_method(name: str):
+    def wrapper(cls):
+        if __CONDITIONING_METHOD__.get(name, None):
+            raise NameError(f"Name {name} is already registered!")
+        __CONDITIONING_METHOD__[name] = cls
+        return cls
+    return wrapper
+
+
+def get_conditioning_method(name: str, operator, noiser, **kwargs):
+    if __CONDITIONING_METHOD__.get(name, None) is None:
+        raise NameError(f"Name {name} is not defined!")
+    return __CONDITIONING_METHOD__[name](operator=operator, noiser=noiser, **kwargs)
+
+
+def _parse_scale(s):
+    try:
+        return torch.tensor([float(s)])
+    except ValueError:
+        return torch.tensor([float(p.strip()) for p in s.split(",")])
+
+
+class ConditioningMethod(ABC):
+    def __init__(self, operator, noiser, **kwargs):
+        self.operator = operator
+        self.noiser = noiser
+
+    def project(self, data, noisy_measurement, **kwargs):
+        return self.operator.project(data=data, measurement=noisy_measurement, **kwargs)
+
+    def grad_and_value(self, x_prev, x_0_hat, measurement, **kwargs):
+        """DPS data term for the rgb-guidance variant (reference :35-53); torch autograd."""
+        if self.noiser.__name__ == "gaussian":
+            diff = measurement - self.operator.forward(x_0_hat[:, 0:3], **kwargs)
+            loss = torch.linalg.norm(diff)
+        elif self.noiser.__name__ == "poisson":
+            diff = measurement - self.operator.forward(x_0_hat, **kwargs)
+            loss = (torch.linalg.norm(diff) / measurement.abs()).mean()
+        else:
+            raise NotImplementedError
+        return torch.autograd.grad(outputs=loss, inputs=x_prev)[0], loss
+
+    @abstractmethod
+    def conditioning(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
+        pass
+
+
+@register_conditioning_method(name="osmosis")
+class PosteriorSamplingOsmosis(ConditioningMethod):
+    def __init__(self, operator, noiser, **kwargs):
+        super().__init__(operator, noiser)
+        self.scale = _parse_scale(kwargs.get("scale", 1.0))
+        self.gradient_x_prev = kwargs.get("gradient_x_prev", False)
+        self.pattern_name = kwargs.get("pattern", "original")
+        self.global_N = kwargs.get("global_N", 1)
+        self.local_M = kwargs.get("local_M", 1)
+        self.n_iter = kwargs.get("n_iter", 1)
+        self.update_start = kwargs.get("update_start", 1.0)
+
+        aux = kwargs.get("aux_loss", None)
+        if aux is not None:
+            self.aux_loss = losseso.AuxiliaryLoss({k: float(v) for k, v in aux.items()})
+        else:
+            self.aux_loss = None
+
+        self.loss_function = kwargs.get("loss_function", "norm")
+        self.loss_weight = kwargs.get("loss_weight", None)
+        self.weight_function = kwargs.get("weight_function", None)
+
+        clip = [p for p in kwargs.get("gradient_clip", "False").split(",")]
+        self.gradient_clip = utilso.str2bool(clip[0])
+        self.gradient_clip_value = float(clip[1].strip()) if self.gradient_clip else None
+        self._state = None
+
+    # ---------------------------------------------------------------- device state
+    @property
+    def clip_value(self) -> float:
+        return float(self.gradient_clip_value) if self.gradient_clip else 0.0
+
+    def scale4(self, device):
+        s = self.scale.to(torch.float32)
+        if s.numel() == 1:
+            s = s.repeat(4)
+        if s.numel() != 4:
+            raise ValueError("scale must have 1 or 4 entries (RGBD)")
+        return s.to(device).contiguous()
+
+    def _prepare(self, B, HW, device):
+        st = self._state
+        if st is not None and st["key"] == (B, HW, str(device)):
+            return st
+        op = self.operator
+        if not hasattr(op, "fill_desc"):
+            raise NotImplementedError(f"operator {type(op).__name__} has no HIP physics kernels")
+        if self.loss_function not in ("norm", "mse"):
+            raise NotImplementedError
+        d = PhysDesc()
+        op.fill_desc(d)
+        if self.loss_weight in (None, "none"):
+            d.weight_type, d.wdepth_type = 0, 0
+        elif self.loss_weight == "depth":
+            fn, value = utilso.parse_weight_function(self.weight_function)
+            code, vals = utilso.depth_code_and_values(fn if fn != "none" else None, value)
+            d.weight_type, d.wdepth_type = 1, code
+            for i in range(3):
+                d.wval[i] = vals[i]
+        else:
+            raise NotImplementedError
+        d.loss_type = 0 if self.loss_function == "norm" else 1
+        coefs = self.aux_loss.kernel_coefficients() if self.aux_loss is not None else {"gamma_avrg": 0.0, "gamma_val": 0.0}
+        d.gamma_avrg, d.gamma_val = coefs["gamma_avrg"], coefs["gamma_val"]
+        d.B, d.HW = B, HW
+        nblk = ops.phys_nblk(HW)
+        st = {"key": (B, HW, str(device)), "desc": d,
+              "part": torch.empty(B * nblk * 16, device=device, dtype=torch.float32),
+              "red": torch.zeros(B * 16, device=device, dtype=torch.float32),
+              "loss": torch.zeros(B, device=device, dtype=torch.float32),
+              "g": torch.empty(B, 4, HW, device=device, dtype=torch.float32)}
+        self._state = st
+        return st
+
+    def loss_grad_x0(self, x0, y, freeze_phi=False, g_out=None):
+        """Inner phi-optimisation + dL/dx0.  x0 [B,4,H,W], y [B,3,H,W] contiguous device fp32.
+        Returns (g [B,4,H,W] view of an internal buffer (or g_out), per-image data loss [B] (device))."""
+        B, HW = x0.shape[0], x0.shape[2] * x0.shape[3]
+        if y.shape[0] != B or y.shape[1] != 3 or x0.shape[1] != 4:
+            raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
+        st = self._prepare(B, HW, x0.device)
+        d, part, red, loss = st["desc"], st["part"], st["red"], st["loss"]
+        phi = self.operator.phi
+        g = g_out if g_out is not None else st["g"]
+        x0c, yc = x0.contiguous(), y.contiguous()
+        n_inner = 1 if freeze_phi else self.n_iter
+        for it in range(n_inner):
+            ops.phys_reduce(d, x0c, yc, phi, part)
+            last = it == n_inner - 1
+            if last:
+                # loss and dL/dx0 use the phi of THIS iteration; phi is stepped afterwards
+                ops.phys_finalize(d, part, red, phi, False, loss)
+                ops.phys_grad(d, x0c, yc, phi, red, g)
+                if not freeze_phi:
+                    ops.phys_finalize(d, part, red, phi, True, None)
+            else:
+                ops.phys_finalize(d, part, red, phi, True, loss)
+        return g.view(x0.shape), loss
+
+    def aux_values(self):
+        """{'avrg_loss': [B], 'val_loss': [B]} from the last reduction (device tensors, no sync)."""
+        st = self._state
+        if st is None or self.aux_loss is None:
+            return None
+        B, HW = st["key"][0], st["key"][1]
+        red = st["red"].view(B, 16)
+        out = {}
+        for name in self.aux_loss.losses_dictionary:
+            if name == "avrg_loss":
+                out[name] = (red[:, 10:13] / HW).abs().sum(dim=1)
+            elif name == "val_loss":
+                out[name] = red[:, 13] / (3 * HW)
+        return out
+
+    # ---------------------------------------------------------------- reference API
+    def grad_and_value(self, x_prev, x_0_hat, measurement, **kwargs):
+        g, loss = self.loss_grad_x0(x_0_hat.detach(), measurement, freeze_phi=True)
+        I = self.operator.forward(x_0_hat.detach())
+        return loss.detach().cpu().numpy(), loss.sum(), I
+
+    def conditioning(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
+        freeze_phi = kwargs.get("freeze_phi", False)
+        self.operator.set_variable_gradients(value=not freeze_phi)
+        g, loss = self.loss_grad_x0(x_0_hat.detach(), measurement, freeze_phi=freeze_phi)
+        with torch.no_grad():
+            scale = self.scale4(x_t.device)[None, :, None, None]
+        if self.gradient_x_prev:
+            if x_prev.grad is not None:
+                x_prev.grad = None
+            x_0_hat.backward(gradient=g.clone(), inputs=[x_prev])
+            grad = x_prev.grad
+        else:
+            grad = g
+        with torch.no_grad():
+            gc = torch.clamp(grad, -self.gradient_clip_value, self.gradient_clip_value) if self.gradient_clip else grad
+            x_t -= scale * gc
+        aux = self.aux_values()
+        aux = {k: v.detach().cpu().sum() for k, v in aux.items()} if aux is not None else None
+        return x_t, loss.detach().cpu().numpy(), self.operator.optimize(freeze_phi=freeze_phi), grad.detach().cpu(), aux
+
+
+@register_conditioning_method(name="ps")
+class PosteriorSampling(ConditioningMethod):
+    """rgb-guidance DPS variant (reference :234-251); secondary path, torch autograd over our UNet op."""
+
+    def __init__(self, operator, noiser, **kwargs):
+        super().__init__(operator, noiser)
+        self.scale = _parse_scale(kwargs.get("scale", 1.0))
+
+    def conditioning(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
+        norm_grad, norm = self.grad_and_value(x_prev=x_prev, x_0_hat=x_0_hat, measurement=measurement, **kwargs)
+        with torch.no_grad():
+            x_t -= norm_grad * self.scale[None, ..., None, None].to(x_prev.device)
+        return x_t, norm

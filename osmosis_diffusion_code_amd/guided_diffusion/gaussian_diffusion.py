@@ -1,0 +1,394 @@
+"""Samplers -- registry surface of the reference's guided_diffusion/gaussian_diffusion.py
+(register_sampler/get_sampler/create_sampler :19-62, GaussianDiffusion :65-370, space_timesteps
+:373-426, SpacedDiffusion :429-474, DDPM :492-502, DDIM :505-535, get_named_beta_schedule :542-566).
+
+`p_sample_loop` keeps the reference signature and return values.  For the Osmosis configuration
+(pretrain_model == 'osmosis', our UNetModel, the 'osmosis' conditioning method with
+gradient_x_prev, epsilon / learned_range processors) every step runs as ONE device-resident
+sequence with no host synchronisation:
+
+    fetch_coefs -> UNet forward plan -> osm_posterior -> [osm_phys_reduce/finalize x n_iter ->
+    osm_phys_grad] -> osm_posterior_bwd -> UNet data-gradient plan -> osm_guide_update
+
+(the reference performs 4 + n_iter device->host copies per step: gaussian_diffusion.py:216,276,288,
+condition_methods.py:130,224).  Per-timestep coefficients live in a device table indexed by a
+device-side step counter, so the whole step can be replayed from a hipGraph.  Any other
+combination falls back to a generic loop that follows the reference control flow on top of the
+same kernels through torch.autograd.
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..osmosis_utils import utils as utilso
+from .posterior_mean_variance import get_mean_processor, get_var_processor
+
+__SAMPLER__ = {}
+
+
+def register_sampler(name: str):
+    def wrapper(cls):
+        if __SAMPLER__.get(name, None):
+            raise NameError(f"Name {name} is already registered!")
+        __SAMPLER__[name] = cls
+        return cls
+    return wrapper
+
+
+def get_sampler(name: str):
+    if __SAMPLER__.get(name, None) is None:
+        raise NameError(f"Name {name} is not defined!")
+    return __SAMPLER__[name]
+
+
+def create_sampler(sampler, steps, noise_schedule, model_mean_type, model_var_type, dynamic_threshold,
+                   clip_denoised, rescale_timesteps, timestep_respacing="", **kwargs):
+    cls = get_sampler(name=sampler)
+    betas = get_named_beta_schedule(noise_schedule, steps)
+    if not timestep_respacing:
+        timestep_respacing = [steps]
+    return cls(use_timesteps=space_timesteps(steps, timestep_respacing), betas=betas,
+               model_mean_type=model_mean_type, model_var_type=model_var_type,
+               dynamic_threshold=dynamic_threshold, clip_denoised=clip_denoised,
+               rescale_timesteps=rescale_timesteps, annealing_time=kwargs.get("annealing_time", False))
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
+    T = num_diffusion_timesteps
+    if schedule_name == "linear":
+        k = 1000 / T
+        return np.linspace(k * 0.0001, k * 0.02, T, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(T, lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    T = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / T) / alpha_bar(i / T), max_beta) for i in range(T)])
+
+
+def space_timesteps(num_timesteps, section_counts):
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[len("ddim"):])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    elif isinstance(section_counts, int):
+        section_counts = [section_counts]
+    base, extra = divmod(num_timesteps, len(section_counts))
+    start, picked = 0, []
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            picked.append(start + round(pos))   # Python round (banker's), as the reference
+            pos += stride
+        start += size
+    return set(picked)
+
+
+def extract_and_expand(array, time, target):
+    a = torch.from_numpy(np.asarray(array)).to(target.device)[time].float()
+    while a.ndim < target.ndim:
+        a = a.unsqueeze(-1)
+    return a.expand_as(target)
+
+
+class GaussianDiffusion:
+    def __init__(self, betas, model_mean_type, model_var_type, dynamic_threshold, clip_denoised,
+                 rescale_timesteps, **kwargs):
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert betas.ndim == 1, "betas must be 1-D"
+        assert (0 < betas).all() and (betas <= 1).all(), "betas must be in (0..1]"
+        self.num_timesteps = int(betas.shape[0])
+        self.rescale_timesteps = rescale_timesteps
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self.mean_processor = get_mean_processor(model_mean_type, betas=betas, dynamic_threshold=dynamic_threshold,
+                                                 clip_denoised=clip_denoised)
+        self.var_processor = get_var_processor(model_var_type, betas=betas)
+        self._fast = None
+
+    # ------------------------------------------------------------------ reference tensor API
+    def q_mean_variance(self, x_start, t):
+        return (extract_and_expand(self.sqrt_alphas_cumprod, t, x_start) * x_start,
+                extract_and_expand(1.0 - self.alphas_cumprod, t, x_start),
+                extract_and_expand(self.log_one_minus_alphas_cumprod, t, x_start))
+
+    def q_sample(self, x_start, t):
+        noise = torch.randn_like(x_start)
+        return (extract_and_expand(self.sqrt_alphas_cumprod, t, x_start) * x_start
+                + extract_and_expand(self.sqrt_one_minus_alphas_cumprod, t, x_start) * noise)
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        assert x_start.shape == x_t.shape
+        mean = (extract_and_expand(self.posterior_mean_coef1, t, x_start) * x_start
+                + extract_and_expand(self.posterior_mean_coef2, t, x_t) * x_t)
+        return (mean, extract_and_expand(self.posterior_variance, t, x_t),
+                extract_and_expand(self.posterior_log_variance_clipped, t, x_t))
+
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1000.0 / self.num_timesteps)
+        return t
+
+    def _model_timesteps(self, idx: int) -> float:
+        """What the network is fed for loop index idx (base class: no respacing)."""
+        return float(idx) * (1000.0 / self.num_timesteps) if self.rescale_timesteps else float(idx)
+
+    def p_mean_variance(self, model, x, t):
+        model_output = model(x, self._scale_timesteps(t))
+        if model_output.shape[1] == 2 * x.shape[1]:
+            model_output, model_var_values = torch.split(model_output, x.shape[1], dim=1)
+        else:
+            model_var_values = model_output
+        mean, x0 = self.mean_processor.get_mean_and_xstart(x, t, model_output)
+        var, logvar = self.var_processor.get_variance(model_var_values, t)
+        assert mean.shape == logvar.shape == x0.shape == x.shape
+        return {"mean": mean, "variance": var, "log_variance": logvar, "pred_xstart": x0}
+
+    def p_sample(self, model, x, t):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ fused (HIP) loop
+    def _fast_path_ok(self, model, cond_fn, pretrain_model, rgb_guidance, sample_pattern):
+        from .condition_methods import PosteriorSamplingOsmosis
+        from .unet import UNetModel
+        cond = getattr(cond_fn, "__self__", None)
+        if pretrain_model != "osmosis" or rgb_guidance:
+            return None
+        if not isinstance(model, UNetModel) or not isinstance(cond, PosteriorSamplingOsmosis):
+            return None
+        if not cond.gradient_x_prev or not hasattr(cond.operator, "fill_desc"):
+            return None
+        if self.mean_processor.hip_kernel != "osm_posterior" or self.var_processor.hip_kernel != "osm_posterior":
+            return None
+        if self.mean_processor.dynamic_threshold or self.mean_processor.clip_denoised:
+            return None
+        if sample_pattern is not None and sample_pattern.get("pattern") not in (None, "original"):
+            if sample_pattern.get("local_M", 1) != 1:
+                return None
+        return cond
+
+    def coef_table(self) -> np.ndarray:
+        """[T][8] fp32: c0,c1,c2,c3 (mean processor), min_log,max_log (variance), noise_on, t_model."""
+        T = self.num_timesteps
+        tab = np.zeros((T, 8), dtype=np.float32)
+        for i in range(T):
+            tab[i, 0:4] = self.mean_processor.kernel_coefs(i)
+            tab[i, 4:6] = self.var_processor.kernel_coefs(i)
+            tab[i, 6] = 0.0 if i == 0 else 1.0
+            tab[i, 7] = self._model_timesteps(i)
+        return tab
+
+    def _guidance_flag(self, sample_pattern, idx):
+        if sample_pattern is None or sample_pattern["pattern"] == "original" or sample_pattern["pattern"] is None:
+            return True
+        T = self.num_timesteps
+        return sample_pattern["start_guidance"] * T >= idx >= sample_pattern["stop_guidance"] * T
+
+    def _fused_loop(self, model, cond, x_start, measurement, sample_pattern, kwargs):
+        dev = x_start.device
+        B, C, H, W = x_start.shape
+        HW = H * W
+        T = self.num_timesteps
+        eng = model.engine(B, H, W)
+        f32 = dict(device=dev, dtype=torch.float32)
+        table = torch.from_numpy(self.coef_table()).to(dev)
+        step = torch.tensor([T - 1], device=dev, dtype=torch.int32)
+        coef = torch.zeros(8, **f32)
+        x0, mean, logvar = (torch.empty(B, 4, H, W, **f32) for _ in range(3))
+        g = torch.empty(B, 4, H, W, **f32)
+        noise = torch.zeros(B, 4, H, W, **f32)
+        scale4 = cond.scale4(dev)
+        y = measurement.detach().to(dev, torch.float32).contiguous()
+        eng.x_in.copy_(x_start.detach())
+        noise_fn = kwargs.get("noise_fn", None)           # (k, shape) -> tensor : injected noise (parity runs)
+        trace = kwargs.get("trace", None)                 # list collecting per-step tensors (tests)
+        draw_measurement_noise = kwargs.get("reference_rng_order", noise_fn is None)
+        loss = None
+        for k, idx in enumerate(range(T - 1, -1, -1)):
+            guided = self._guidance_flag(sample_pattern, idx)
+            freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
+            if draw_measurement_noise:
+                torch.randn_like(y)                       # q_sample's unused draw (reference :241) keeps RNG order
+            if noise_fn is not None:
+                noise.copy_(noise_fn(k, noise.shape))
+            else:
+                noise.normal_()
+            ops.fetch_coefs(table, step, -1, coef, eng.t_dev, B)
+            eng.run_forward()
+            ops.posterior(eng.out, eng.x_in, coef, x0, mean, logvar, B, HW)
+            if trace is not None:
+                rec = {"x_in": eng.x_in.clone(), "x0": x0.clone(), "mean": mean.clone()}
+            if guided:
+                _, loss = cond.loss_grad_x0(x0, y, freeze_phi=freeze, g_out=g)
+                ops.posterior_bwd(g, coef, eng.d_out, B, HW)
+                eng.run_backward()
+                grad_out = None
+                if trace is not None:
+                    grad_out = rec["grad"] = torch.empty_like(g)
+                ops.guide_update(mean, logvar, g, eng.dx, noise, coef, scale4, cond.clip_value, eng.x_in,
+                                 grad_out, B, HW)
+            else:
+                ops.guide_update(mean, logvar, None, None, noise, coef, None, 0.0, eng.x_in, None, B, HW)
+            if trace is not None:
+                rec["x_out"] = eng.x_in.clone()
+                rec["loss"] = loss.clone() if loss is not None else None
+                rec["phi"] = cond.operator.phi.clone()
+                trace.append(rec)
+        img = eng.x_in.clone()
+        variables = cond.operator.optimize(freeze_phi=True)
+        loss_np = loss.detach().cpu().numpy() if loss is not None else None
+        return img, variables, loss_np, x0.detach().cpu()
+
+    # ------------------------------------------------------------------ public loop
+    def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root,
+                      pretrain_model=None, image_idx=None, record_every=150, rgb_guidance=False,
+                      sample_pattern=None, **kwargs):
+        cond = self._fast_path_ok(model, measurement_cond_fn, pretrain_model, rgb_guidance, sample_pattern)
+        if cond is not None and not record:
+            return self._fused_loop(model, cond, x_start, measurement, sample_pattern, kwargs)
+        return self._generic_loop(model, x_start, measurement, measurement_cond_fn, pretrain_model,
+                                  rgb_guidance, sample_pattern, kwargs)
+
+    def _generic_loop(self, model, x_start, measurement, cond_fn, pretrain_model, rgb_guidance, sample_pattern,
+                      kwargs):
+        """Reference control flow (gaussian_diffusion.py:213-340) on top of the same kernels via
+        torch.autograd.  Recording of intermediate images is a driver concern and not done here."""
+        img = x_start
+        device = x_start.device
+        T = self.num_timesteps
+        loss = variable_dict = out = None
+        for idx in range(T - 1, -1, -1):
+            time = torch.tensor([idx] * img.shape[0], device=device)
+            guided = self._guidance_flag(sample_pattern, idx) if sample_pattern is not None else True
+            alt = utilso.set_alternate_length(sample_pattern, idx, T) if sample_pattern is not None else 1
+            for _ in range(alt):
+                img = img.detach().requires_grad_(bool(guided))
+                if rgb_guidance:
+                    out = self.p_sample(x=img, t=time, model=model)
+                else:
+                    out = self.p_mean_variance(model=model, x=img, t=time)
+                    out["sample"] = out["mean"]
+                noisy_measurement = self.q_sample(measurement, t=time)
+                if pretrain_model == "osmosis" and not rgb_guidance:
+                    freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
+                    if guided:
+                        img, loss, variable_dict, _grads, _aux = cond_fn(
+                            x_t=out["sample"], measurement=measurement, noisy_measurement=noisy_measurement,
+                            x_prev=img, x_0_hat=out["pred_xstart"], freeze_phi=freeze,
+                            time_index=float(idx) / T)
+                    else:
+                        img = out["sample"]
+                    noise = torch.randn_like(img)
+                    img = img.detach()
+                    if idx != 0:
+                        img = img + torch.exp(0.5 * out["log_variance"].detach()) * noise
+                else:
+                    img, loss = cond_fn(x_t=out["sample"], measurement=measurement,
+                                        noisy_measurement=noisy_measurement, x_prev=img,
+                                        x_0_hat=out["pred_xstart"])
+                    img = img.detach()
+        if pretrain_model == "osmosis" and not rgb_guidance:
+            return img, variable_dict, loss, out["pred_xstart"].detach().cpu()
+        return img
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    def __init__(self, use_timesteps, **kwargs):
+        self.use_timesteps = set(use_timesteps)
+        self.timestep_map = []
+        self.original_num_steps = len(kwargs["betas"])
+        base_ac = np.cumprod(1.0 - np.array(kwargs["betas"], dtype=np.float64), axis=0)
+        last, new_betas = 1.0, []
+        for i, ac in enumerate(base_ac):
+            if i in self.use_timesteps:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        kwargs["betas"] = np.array(new_betas)
+        super().__init__(**kwargs)
+
+    def _model_timesteps(self, idx: int) -> float:
+        t = float(self.timestep_map[idx])
+        return t * (1000.0 / self.original_num_steps) if self.rescale_timesteps else t
+
+    def p_mean_variance(self, model, *args, **kwargs):
+        return super().p_mean_variance(self._wrap_model(model), *args, **kwargs)
+
+    def _wrap_model(self, model):
+        if isinstance(model, _WrappedModel):
+            return model
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+
+    def _scale_timesteps(self, t):
+        return t   # done by the wrapped model
+
+
+class _WrappedModel:
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+        self.model = model
+        self.timestep_map = timestep_map
+        self.rescale_timesteps = rescale_timesteps
+        self.original_num_steps = original_num_steps
+
+    def __call__(self, x, ts, **kwargs):
+        map_tensor = torch.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        new_ts = map_tensor[ts]
+        if self.rescale_timesteps:
+            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        return self.model(x, new_ts, **kwargs)
+
+
+@register_sampler(name="ddpm")
+class DDPM(SpacedDiffusion):
+    def p_sample(self, model, x, t):
+        out = self.p_mean_variance(model, x, t)
+        sample = out["mean"]
+        noise = torch.randn_like(x)
+        if t[0] != 0:
+            sample = sample + torch.exp(0.5 * out["log_variance"]) * noise
+        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+
+
+@register_sampler(name="ddim")
+class DDIM(SpacedDiffusion):
+    def p_sample(self, model, x, t, eta=0.0):
+        out = self.p_mean_variance(model, x, t)
+        eps = self.predict_eps_from_x_start(x, t, out["pred_xstart"])
+        ab = extract_and_expand(self.alphas_cumprod, t, x)
+        ab_prev = extract_and_expand(self.alphas_cumprod_prev, t, x)
+        sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
+        noise = torch.randn_like(x)
+        sample = out["pred_xstart"] * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+        if t[0] != 0:
+            sample = sample + sigma * noise
+        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+
+    def predict_eps_from_x_start(self, x_t, t, pred_xstart):
+        c1 = extract_and_expand(self.sqrt_recip_alphas_cumprod, t, x_t)
+        c2 = extract_and_expand(self.sqrt_recipm1_alphas_cumprod, t, x_t)
+        return (c1 * x_t - pred_xstart) / c2

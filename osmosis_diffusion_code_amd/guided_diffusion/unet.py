@@ -1,0 +1,260 @@
+"""UNet of the Osmosis RGBD prior -- `create_model` / `UNetModel` surface of the reference's
+guided_diffusion/unet.py (create_model :27-98, UNetModel :475-742), executed by hand-written gfx950
+kernels (see ../engine.py) instead of ATen modules.
+
+What is kept from the reference
+  * `create_model(**unet_model)` argument list and digestion (channel_mult table, attention
+    resolutions string, `pretrain_model == "osmosis"` -> 4 input / 8 output channels, the
+    swallow-and-warn checkpoint load :94-97);
+  * an `nn.Module` whose `state_dict()` keys and OIHW fp32 shapes are exactly the reference's
+    (`input_blocks.N.M.in_layers.2.weight`, `...emb_layers.1.weight`, `...out_layers.3.weight`,
+    `...skip_connection.weight`, `N.1.norm/qkv/proj_out`, `out.0/out.2`), so the released checkpoint
+    loads unchanged;
+  * `model(x[B,4,H,W], t[B]) -> [B,8,H,W]`, differentiable w.r.t. `x` under torch.autograd (the
+    guidance step back-propagates through the network; no weight gradients exist on this path).
+
+What is different: the module holds parameters only.  The computation is a recorded plan of C-ABI
+kernel calls over NHWC buffers (UNetEngine); there is no CPU / eager fallback.
+"""
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..engine import UNetEngine
+
+NUM_CLASSES = 1000
+
+
+class _Slot(nn.Module):
+    """A parameter holder named like the reference sub-module it replaces (weight [+ bias])."""
+
+    def __init__(self, w_shape, b_shape=None, kind="conv"):
+        super().__init__()
+        self.kind = kind
+        self.weight = nn.Parameter(torch.empty(*w_shape), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(*b_shape), requires_grad=False) if b_shape is not None else None
+
+
+class _Seq(nn.Module):
+    """Children registered under integer names, possibly with gaps (e.g. in_layers.0 and .2)."""
+
+    def __init__(self, items: Dict[int, nn.Module]):
+        super().__init__()
+        for i, m in items.items():
+            self.add_module(str(i), m)
+
+    def at(self, i: int) -> nn.Module:
+        return getattr(self, str(i))
+
+
+class ResBlockParams(nn.Module):
+    def __init__(self, cin, cout, emb_ch, scale_shift, up=False, down=False):
+        super().__init__()
+        self.cin, self.cout, self.up, self.down, self.scale_shift = cin, cout, up, down, scale_shift
+        self.in_layers = _Seq({0: _Slot((cin,), (cin,), "norm"), 2: _Slot((cout, cin, 3, 3), (cout,))})
+        self.emb_layers = _Seq({1: _Slot(((2 if scale_shift else 1) * cout, emb_ch), ((2 if scale_shift else 1) * cout,), "linear")})
+        self.out_layers = _Seq({0: _Slot((cout,), (cout,), "norm"), 3: _Slot((cout, cout, 3, 3), (cout,))})
+        if cin != cout:
+            self.skip_connection = _Slot((cout, cin, 1, 1), (cout,))
+        else:
+            self.skip_connection = None
+
+
+class AttentionParams(nn.Module):
+    def __init__(self, ch, heads, new_order):
+        super().__init__()
+        self.ch, self.heads, self.new_order = ch, heads, new_order
+        self.norm = _Slot((ch,), (ch,), "norm")
+        self.qkv = _Slot((3 * ch, ch, 1), (3 * ch,))
+        self.proj_out = _Slot((ch, ch, 1), (ch,))
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False):
+        super().__init__()
+        if dims != 2:
+            raise NotImplementedError("HIP UNet covers dims=2")
+        if num_classes is not None:
+            raise NotImplementedError("class-conditional UNet is outside the Osmosis hot path")
+        if not resblock_updown:
+            raise NotImplementedError("HIP UNet covers resblock_updown=True (all shipped configs)")
+        if not use_scale_shift_norm:
+            raise NotImplementedError("HIP UNet covers use_scale_shift_norm=True (all shipped configs)")
+        if use_fp16:
+            raise NotImplementedError("use_fp16 has no working reference (SURVEY.md F3); the HIP path is fp32")
+        if dropout:
+            raise NotImplementedError("dropout is inference-irrelevant and not implemented")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        self.channel_mult = tuple(channel_mult)
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.use_new_attention_order = use_new_attention_order
+        self.dtype = torch.float32
+
+        mc = model_channels
+        ted = mc * 4
+        self.time_embed = _Seq({0: _Slot((ted, mc), (ted,), "linear"), 2: _Slot((ted, ted), (ted,), "linear")})
+
+        def heads_for(ch, nh):
+            if num_head_channels == -1:
+                return nh
+            assert ch % num_head_channels == 0, \
+                f"q,k,v channels {ch} is not divisible by num_head_channels {num_head_channels}"
+            return ch // num_head_channels
+
+        def res(cin, cout, **kw):
+            return ResBlockParams(cin, cout, ted, use_scale_shift_norm, **kw)
+
+        ch = int(channel_mult[0] * mc)
+        self.input_blocks = nn.ModuleList([_Seq({0: _Slot((ch, in_channels, 3, 3), (ch,))})])
+        chans = [ch]
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, int(mult * mc))]
+                ch = int(mult * mc)
+                if ds in self.attention_resolutions:
+                    layers.append(AttentionParams(ch, heads_for(ch, num_heads), use_new_attention_order))
+                self.input_blocks.append(_Seq(dict(enumerate(layers))))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(_Seq({0: res(ch, ch, down=True)}))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = _Seq({0: res(ch, ch), 1: AttentionParams(ch, heads_for(ch, num_heads), use_new_attention_order),
+                                  2: res(ch, ch)})
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [res(ch + ich, int(mc * mult))]
+                ch = int(mc * mult)
+                if ds in self.attention_resolutions:
+                    layers.append(AttentionParams(ch, heads_for(ch, num_heads_upsample), use_new_attention_order))
+                if level and i == num_res_blocks:
+                    layers.append(res(ch, ch, up=True))
+                    ds //= 2
+                self.output_blocks.append(_Seq(dict(enumerate(layers))))
+        self.out = _Seq({0: _Slot((ch,), (ch,), "norm"), 2: _Slot((out_channels, ch, 3, 3), (out_channels,))})
+        self.reset_parameters()
+        self._engines: Dict[Tuple, UNetEngine] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def reset_parameters(self, seed: int = 0):
+        """Random initialisation used when no checkpoint is available (the reference silently
+        continues with its own random init, unet.py:94-97).  Unlike the reference's zero_module
+        init, every conv gets non-zero weights so a random model is not degenerate."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if p.ndim == 1:
+                    v = torch.randn(p.shape, generator=g)
+                    is_norm_w = name.endswith("weight")
+                    p.copy_(1.0 + 0.1 * v if is_norm_w else 0.05 * v)
+                else:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.5 / fan_in ** 0.5))
+
+    def convert_to_fp16(self):
+        raise NotImplementedError("the HIP path is fp32 (reference use_fp16 is broken as shipped, SURVEY.md F3)")
+
+    def convert_to_fp32(self):
+        return None
+
+    def _params_version(self):
+        return tuple(p._version for p in self.parameters())
+
+    def engine(self, B: int, H: int, W: int) -> UNetEngine:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("UNetModel runs only on a HIP device (model.to('cuda')); "
+                               "there is no CPU fallback on the product path")
+        key = (B, H, W, str(dev))
+        eng = self._engines.get(key)
+        ver = self._params_version()
+        if eng is None or eng.params_version != ver:
+            eng = UNetEngine(self, B, H, W, dev)
+            eng.params_version = ver
+            self._engines = {key: eng}      # one live engine: activations are large
+        return eng
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, timesteps, y=None):
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected x [B,{self.in_channels},H,W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        eng = self.engine(B, H, W)
+        return _UNetFunction.apply(x, timesteps, eng)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """x -> UNet(x, t); backward = data gradient only (kernels: engine.backward)."""
+
+    @staticmethod
+    def forward(ctx, x, timesteps, eng):
+        out = eng.forward(x, timesteps, need_grad=x.requires_grad)
+        ctx.eng = eng
+        ctx.ticket = eng.ticket
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.eng
+        if eng.ticket != ctx.ticket:
+            raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
+        return eng.backward(grad_out.contiguous()).clone(), None, None
+
+
+def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,
+                 use_checkpoint=False, attention_resolutions="16", num_heads=1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, dropout=0, resblock_updown=False,
+                 use_fp16=False, use_new_attention_order=False, model_path="", pretrain_model=""):
+    if channel_mult == "":
+        table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+        if image_size not in table:
+            raise ValueError(f"unsupported image size: {image_size}")
+        channel_mult = table[image_size]
+    else:
+        channel_mult = tuple(int(c) for c in channel_mult.split(","))
+
+    attention_ds = []
+    if isinstance(attention_resolutions, int):
+        attention_ds.append(image_size // attention_resolutions)
+    elif isinstance(attention_resolutions, str):
+        for r in attention_resolutions.split(","):
+            attention_ds.append(image_size // int(r))
+    else:
+        raise NotImplementedError
+
+    osm = pretrain_model == "osmosis"   # change_input_output_unet(in=4, out=8): utils.py:265-288
+    model = UNetModel(image_size=image_size,
+                      in_channels=4 if osm else 3,
+                      model_channels=num_channels,
+                      out_channels=8 if osm else (3 if not learn_sigma else 6),
+                      num_res_blocks=num_res_blocks,
+                      attention_resolutions=tuple(attention_ds),
+                      dropout=dropout, channel_mult=channel_mult,
+                      num_classes=(NUM_CLASSES if class_cond else None),
+                      use_checkpoint=use_checkpoint, use_fp16=use_fp16, num_heads=num_heads,
+                      num_head_channels=num_head_channels, num_heads_upsample=num_heads_upsample,
+                      use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
+                      use_new_attention_order=use_new_attention_order)
+    try:
+        model.load_state_dict(torch.load(model_path, map_location="cpu"))
+    except Exception as e:  # same behaviour as the reference: warn and continue with random init
+        print(f"Got exception: {e} / Randomly initialize")
+    return model

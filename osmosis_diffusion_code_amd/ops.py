@@ -1,0 +1,192 @@
+"""Thin tensor-level wrappers over the C ABI (see include/osmosis_hip.h).
+
+`Mat` is an NHWC "matrix view": rows = pixels (b*H*W), cols = channels, ld = row stride.  Any 2-D
+torch view with unit column stride qualifies, so channel slices of a wider buffer (zero-copy
+concatenation / split) are first-class.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, GemmDesc, PhysDesc, call, current_stream_ptr, ptr, query
+
+
+@dataclass
+class Mat:
+    t: torch.Tensor      # backing 2-D view (kept alive)
+    rows: int
+    cols: int
+    ld: int
+
+    @staticmethod
+    def of(t: torch.Tensor) -> "Mat":
+        if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+            raise _lib.OsmosisHipError("Mat.of needs a 2-D view with unit column stride")
+        return Mat(t, t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+    @property
+    def p(self) -> int:
+        return ptr(self.t)
+
+    def cols_slice(self, c0: int, c1: int) -> "Mat":
+        return Mat(self.t[:, c0:c1], self.rows, c1 - c0, self.ld)
+
+
+def _s():
+    return current_stream_ptr()
+
+
+def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat, B: int, H: int, W: int,
+           ksize: int, res: Optional[Mat] = None, accumulate: bool = False,
+           splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None):
+    d = ConvDesc()
+    d.x, d.w, d.bias = x.p, ptr(w_packed), ptr(bias)
+    d.res = res.p if res is not None else None
+    d.y = y.p
+    d.splitk_ws = ptr(splitk_ws)
+    d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, x.cols, y.cols
+    d.ksize, d.splitk, d.accumulate = ksize, splitk, int(accumulate)
+    d.ldx, d.ldy, d.ldr = x.ld, y.ld, (res.ld if res is not None else 0)
+    call("osm_conv2d_nhwc", C.byref(d), _s(), keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws))
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True):
+    """OIHW (or [O][I][1] conv1d / [O][I] linear) -> (fwd [k*k][O][I], dgrad [k*k][I][O])."""
+    w = w_oihw.contiguous()
+    O, I = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() >= 3 else 1
+    wf = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_fwd else None
+    wd = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_dgrad else None
+    call("osm_pack_conv_weight", ptr(w), ptr(wf), ptr(wd), O, I, k, _s(), keep=(w, wf, wd))
+    return wf, wd
+
+
+def gemm(A: torch.Tensor, lda: int, Bm: torch.Tensor, ldb: int, Cm: torch.Tensor, ldc: int, M: int, N: int,
+         K: int, b_kn: bool = False, alpha: float = 1.0, nb1: int = 1, nb2: int = 1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, res: Optional[torch.Tensor] = None, ldr: int = 0,
+         accumulate: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0):
+    """Raw-pointer GEMM: element offsets (in floats) select sub-matrices of the backing tensors."""
+    d = GemmDesc()
+    d.A, d.Bm, d.C = ptr(A) + 4 * a_off, ptr(Bm) + 4 * b_off, ptr(Cm) + 4 * c_off
+    d.bias = ptr(bias)
+    d.res = (ptr(res) + 4 * c_off) if res is not None else None
+    d.M, d.N, d.K, d.b_kn = M, N, K, int(b_kn)
+    d.nb1, d.nb2, d.accumulate, d.alpha = nb1, nb2, int(accumulate), alpha
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    call("osm_gemm", C.byref(d), _s(), keep=(A, Bm, Cm, bias, res))
+
+
+def splitk_hint(M, N, K, taps, nbatch=1) -> int:
+    return query("osm_splitk_hint", M, N, K, taps, nbatch)
+
+
+def gn_nchunk(HW: int) -> int:
+    return query("osm_gn_nchunk", HW)
+
+
+def gn_stats(x: Mat, B: int, HW: int, G: int, part: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
+    call("osm_gn_stats", x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), _s(), keep=(x.t, part, stats))
+
+
+def _film(film):
+    """film: None or a 2-D [B][>=2C] view (row stride = ldfilm)."""
+    if film is None:
+        return None, 0
+    return ptr(film), (film.stride(0) if film.shape[0] > 1 else film.shape[1])
+
+
+def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=None, silu=True):
+    fp, ldf = _film(film)
+    call("osm_gn_apply", x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
+         int(silu), _s(), keep=(x.t, y.t, stats, gamma, beta, film))
+
+
+def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
+           film=None, silu=True, addend: Optional[Mat] = None):
+    fp, ldf = _film(film)
+    call("osm_gn_bwd", x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld,
+         addend.p if addend is not None else None, addend.ld if addend is not None else 0,
+         B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(part), ptr(gstats), _s(),
+         keep=(x.t, dy.t, dx.t, addend.t if addend else None, stats, gamma, beta, film, part, gstats))
+
+
+def pool2x2(x: Mat, y: Mat, B, H, W, scale=0.25):
+    call("osm_pool2x2", x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
+
+
+def upsample2x(x: Mat, y: Mat, B, H, W, scale=1.0):
+    call("osm_upsample2x", x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
+
+
+def softmax_rows(S, P, PT, nmat, T):
+    call("osm_softmax_rows", ptr(S), ptr(P), ptr(PT), nmat, T, _s(), keep=(S, P, PT))
+
+
+def softmax_rows_bwd(P, dP, dS, dST, nmat, T):
+    call("osm_softmax_rows_bwd", ptr(P), ptr(dP), ptr(dS), ptr(dST), nmat, T, _s(), keep=(P, dP, dS, dST))
+
+
+def timestep_embedding(t, out, B, dim, max_period=10000.0):
+    call("osm_timestep_embedding", ptr(t), ptr(out), B, dim, max_period, _s(), keep=(t, out))
+
+
+def linear(x, W, b, y, B, K, N, silu_in=False, silu_out=False):
+    call("osm_linear", ptr(x), ptr(W), ptr(b), ptr(y), B, K, N, int(silu_in), int(silu_out), _s(),
+         keep=(x, W, b, y))
+
+
+def nchw_to_nhwc(x, y: Mat, B, Cc, HW):
+    call("osm_nchw_to_nhwc", ptr(x), y.p, y.ld, B, Cc, HW, _s(), keep=(x, y.t))
+
+
+def nhwc_to_nchw(x: Mat, y, B, Cc, HW):
+    call("osm_nhwc_to_nchw", x.p, x.ld, ptr(y), B, Cc, HW, _s(), keep=(x.t, y))
+
+
+def copy2d(x: Mat, y: Mat, accumulate=False):
+    call("osm_copy2d", x.p, x.ld, y.p, y.ld, x.rows, x.cols, int(accumulate), _s(), keep=(x.t, y.t))
+
+
+# ----------------------------------------------------------------------------- sampler step
+def posterior(model_out, x, coef, x0, mean, logvar, B, HW):
+    call("osm_posterior", ptr(model_out), ptr(x), ptr(coef), ptr(x0), ptr(mean), ptr(logvar), B, HW, _s(),
+         keep=(model_out, x, coef, x0, mean, logvar))
+
+
+def phys_nblk(HW):
+    return query("osm_phys_nblk", HW)
+
+
+def phys_reduce(desc: PhysDesc, x0, y, phi, part):
+    call("osm_phys_reduce", C.byref(desc), ptr(x0), ptr(y), ptr(phi), ptr(part), _s(), keep=(desc, x0, y, phi, part))
+
+
+def phys_finalize(desc: PhysDesc, part, red, phi, do_update, loss_out):
+    call("osm_phys_finalize", C.byref(desc), ptr(part), ptr(red), ptr(phi), int(do_update), ptr(loss_out), _s(),
+         keep=(desc, part, red, phi, loss_out))
+
+
+def phys_grad(desc: PhysDesc, x0, y, phi, red, g):
+    call("osm_phys_grad", C.byref(desc), ptr(x0), ptr(y), ptr(phi), ptr(red), ptr(g), _s(),
+         keep=(desc, x0, y, phi, red, g))
+
+
+def posterior_bwd(g, coef, d_out, B, HW):
+    call("osm_posterior_bwd", ptr(g), ptr(coef), ptr(d_out), B, HW, _s(), keep=(g, coef, d_out))
+
+
+def guide_update(mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, grad_out, B, HW):
+    call("osm_guide_update", ptr(mean), ptr(logvar), ptr(g), ptr(dx_unet), ptr(noise), ptr(coef), ptr(scale4),
+         float(clip), ptr(x_next), ptr(grad_out), B, HW, _s(),
+         keep=(mean, logvar, g, dx_unet, noise, coef, scale4, x_next, grad_out))
+
+
+def fetch_coefs(table, step, delta, coef_out, t_out, B):
+    call("osm_fetch_coefs", ptr(table), ptr(step), delta, ptr(coef_out), ptr(t_out), B, _s(),
+         keep=(table, step, coef_out, t_out))

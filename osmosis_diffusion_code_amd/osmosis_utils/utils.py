@@ -1,0 +1,112 @@
+"""Host-side helpers of the hot path (mirror of the reference's osmosis_utils/utils.py subset:
+str2bool :384-395, get_depth_value :529-541, convert_depth :544-566, is_freeze_phi :571-590,
+set_alternate_length :595-630, set_loss_weight :674-700).  Same names, arguments and error behaviour."""
+import argparse
+
+import numpy as np
+import torch
+
+DEPTH_TYPE_CODE = {None: 0, "original": 0, "gamma": 1, "move": 2}
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    s = v.lower()
+    if s in ("yes", "true", "t", "y", "1"):
+        return True
+    if s in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("boolean value expected")
+
+
+def get_depth_value(value_raw, **kwargs):
+    if isinstance(value_raw, float):
+        return value_raw
+    if isinstance(value_raw, int):
+        return float(value_raw)
+    if isinstance(value_raw, str):
+        return np.array([float(p) for p in value_raw.split(",")], dtype=float)
+    if isinstance(value_raw, (np.ndarray, np.generic)):
+        return value_raw
+    raise NotImplementedError
+
+
+def depth_code_and_values(depth_type, value):
+    """(code, (v0,v1,v2)) as the kernels want them; raises like convert_depth for unknown types."""
+    if depth_type not in DEPTH_TYPE_CODE:
+        raise NotImplementedError
+    code = DEPTH_TYPE_CODE[depth_type]
+    v = get_depth_value(value) if value is not None else 0.0
+    vals = [0.0, 1.0, 1.0]
+    if code == 1:
+        vals = [float(v[0]), float(v[1]), float(v[2])]
+    elif code == 2:
+        vals = [float(v if np.isscalar(v) else np.asarray(v).ravel()[0]), 1.0, 1.0]
+    return code, vals
+
+
+def convert_depth(depth, depth_type, **kwargs):
+    """Tensor version (host/visualisation use; the sampler's hot path evaluates this inside the
+    physics kernels)."""
+    value = get_depth_value(kwargs.get("value", None)) if kwargs.get("value", None) is not None else None
+    if depth_type == "move":
+        return depth + value
+    if depth_type == "gamma":
+        return torch.pow((depth + value[0]) * value[1], value[2])
+    if depth_type is None or depth_type == "original":
+        return 0.5 * (depth + 1.0)
+    raise NotImplementedError
+
+
+def parse_weight_function(weight_function):
+    """'gamma,1.4,1.4,1' -> ('gamma', array([1.4,1.4,1.]))"""
+    if not isinstance(weight_function, str):
+        return "none", None
+    parts = weight_function.split(",")
+    value = None
+    if len(parts) > 1:
+        value = np.asarray(parts[1:]).astype(float)
+        value = value.item() if value.shape[0] == 1 else value
+    return parts[0], value
+
+
+def set_loss_weight(loss_weight_type, weight_function=None, degraded_image=None, x_0_hat=None):
+    fn, value = parse_weight_function(weight_function)
+    if loss_weight_type == "none" or loss_weight_type is None:
+        return 1
+    if loss_weight_type == "depth":
+        return convert_depth(depth=x_0_hat.detach()[:, 3:4], depth_type=fn, value=value)
+    raise NotImplementedError
+
+
+def _outside_guidance(p, idx, T):
+    return idx > p["start_guidance"] * T or idx < p["stop_guidance"] * T
+
+
+def _outside_update(p, idx, T):
+    return idx > p["update_start"] * T or idx < p["update_end"] * T
+
+
+def is_freeze_phi(sample_pattern, time_index, num_timesteps):
+    if sample_pattern is None or sample_pattern["pattern"] == "original":
+        return False
+    return bool(_outside_guidance(sample_pattern, time_index, num_timesteps)
+                or _outside_update(sample_pattern, time_index, num_timesteps))
+
+
+def set_alternate_length(sample_pattern, time_index, num_timesteps):
+    if sample_pattern["pattern"] != "original" and sample_pattern is not None:
+        assert sample_pattern["update_start"] > sample_pattern["update_end"]
+        assert sample_pattern["s_start"] > sample_pattern["s_end"]
+        if sample_pattern["local_M"] > 1:
+            assert sample_pattern["update_start"] >= sample_pattern["s_start"]
+            assert sample_pattern["s_end"] >= sample_pattern["update_end"]
+    if sample_pattern is None or sample_pattern["pattern"] == "original":
+        return 1
+    T = num_timesteps
+    if _outside_guidance(sample_pattern, time_index, T) or _outside_update(sample_pattern, time_index, T):
+        return 1
+    if time_index > sample_pattern["s_start"] * T or time_index < sample_pattern["s_end"] * T:
+        return 1
+    return sample_pattern["local_M"]

@@ -1,0 +1,114 @@
+"""Sampler-step kernels (posterior, physical model + loss + analytic gradients, phi SGD, guidance
+update) against the CPU oracle's autograd on the same seeded inputs.  fp32, tolerances stated."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_ref as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+OPS = {
+    "underwater_physical_revised": (
+        dict(depth_type="gamma", value="1.4,1.4,1", phi_a="1.1,0.95,0.95", phi_b="0.95, 0.8, 0.8",
+             phi_inf="0.14, 0.29, 0.49"),
+        dict(scale="7,7,7,0.9", gradient_clip="True,0.005", aux={"avrg_loss": 0.5, "val_loss": 20})),
+    "underwater_physical": (
+        dict(depth_type="original", value="1.4,1.4,1", phi_ab="1.1,0.95,0.95", phi_inf="0.2,0.4,0.7"),
+        dict(scale="4,4,4,1", gradient_clip="True,0.001", aux={"val_loss": 40})),
+    "haze_physical": (
+        dict(depth_type="gamma", value="1.4,1.4,1", phi_ab="1.0", phi_inf="0.14, 0.29, 0.49"),
+        dict(scale="7,7,7,0.9", gradient_clip="True,0.005", aux={"avrg_loss": 0.5, "val_loss": 20})),
+}
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from osmosis_diffusion_code_amd import ops
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    return ops, M, CM
+
+
+def test_posterior_kernel(mods):
+    ops, _, _ = mods
+    tb = D.make_tables(1000, "linear", "250")
+    g = torch.Generator().manual_seed(0)
+    B, HW, t = 2, 48, 137
+    mo = torch.randn(B, 8, HW, generator=g)
+    x = torch.randn(B, 4, HW, generator=g)
+    ref = D.p_mean_variance(tb, mo.reshape(B, 8, 6, 8), x.reshape(B, 4, 6, 8), t)
+    coef = torch.tensor([np.float32(tb.sqrt_recip_alphas_cumprod[t]), np.float32(tb.sqrt_recipm1_alphas_cumprod[t]),
+                         np.float32(tb.posterior_mean_coef1[t]), np.float32(tb.posterior_mean_coef2[t]),
+                         np.float32(tb.posterior_log_variance_clipped[t]), np.float32(tb.log_betas[t]), 1.0, t],
+                        dtype=torch.float32, device=DEV)
+    x0, mean, lv = (torch.empty(B, 4, HW, device=DEV) for _ in range(3))
+    ops.posterior(mo.to(DEV), x.to(DEV), coef, x0, mean, lv, B, HW)
+    assert torch.allclose(x0.cpu().reshape(B, 4, 6, 8), ref["pred_xstart"], atol=1e-5, rtol=1e-6)
+    assert torch.allclose(mean.cpu().reshape(B, 4, 6, 8), ref["mean"], atol=1e-5, rtol=1e-6)
+    assert torch.allclose(lv.cpu().reshape(B, 4, 6, 8), ref["log_variance"], atol=1e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("opname", list(OPS))
+@pytest.mark.parametrize("loss_function", ["norm", "mse"])
+def test_physics_loss_grad_and_phi_sgd(mods, opname, loss_function):
+    """20 inner iterations of (loss, d/dphi, SGD) + the final d/dx0 -- versus autograd on the oracle."""
+    ops, M, CM = mods
+    okw, ckw = OPS[opname]
+    H = W = 24
+    g = torch.Generator().manual_seed(11)
+    x0 = (0.6 * torch.randn(1, 4, H, W, generator=g)).requires_grad_(True)
+    y = torch.rand(1, 3, H, W, generator=g) * 1.6 - 0.8
+
+    # oracle: x0 is the leaf here (chain through the UNet is tested elsewhere)
+    op = D.PhysOperator(opname, batch_size=1, **{**okw, **{k + "_eta": 1e-3 for k in ("phi_a", "phi_b", "phi_ab", "phi_inf")}})
+    guide = D.OsmosisGuidance(op, n_iter=20, loss_function=loss_function, **ckw)
+    op.set_requires_grad(True)
+    for it in range(20):
+        sep, loss = guide.loss(x0, y)
+        total = loss + D.aux_loss(x0, guide.aux)
+        if it == 19:
+            total.backward(inputs=[x0] + list(op.phi.values()))
+        else:
+            total.backward(inputs=list(op.phi.values()))
+        op.sgd_step()
+    ref_g = x0.grad.clone()
+
+    # HIP path through the drop-in operator / conditioning classes
+    oper = M.get_operator(opname, device=DEV, batch_size=1,
+                          **{**okw, **{k + "_eta": 1e-3 for k in ("phi_a", "phi_b", "phi_ab", "phi_inf")
+                                       if k in ("phi_inf",) or k in okw}}, optimizer="sgd")
+    cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), loss_function=loss_function,
+                                      loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                                      scale=ckw["scale"], gradient_x_prev=True, gradient_clip=ckw["gradient_clip"],
+                                      n_iter=20, aux_loss=ckw["aux"], pattern="pcgs")
+    gx0, sep_loss = cond.loss_grad_x0(x0.detach().to(DEV), y.to(DEV), freeze_phi=False)
+    assert np.allclose(sep_loss.cpu().numpy(), sep, rtol=2e-5), (sep_loss, sep)
+    for n, v in oper.variables().items():
+        assert torch.allclose(v.cpu(), op.phi[n].detach(), atol=2e-6), n
+    scale = float(ref_g.abs().max())
+    assert float((gx0.cpu() - ref_g).abs().max()) < 2e-5 * scale + 1e-9
+
+
+def test_guide_update_kernel(mods):
+    ops, _, _ = mods
+    g = torch.Generator().manual_seed(4)
+    B, HW = 2, 40
+    mean, lv, gg, dxu, nz = (torch.randn(B, 4, HW, generator=g) * s for s in (1, 0.3, 0.01, 0.01, 1))
+    coef = torch.tensor([1.7, 0.3, 0, 0, 0, 0, 1.0, 5.0], device=DEV)
+    scale4 = torch.tensor([7.0, 7.0, 7.0, 0.9])
+    out = torch.empty(B, 4, HW, device=DEV)
+    gout = torch.empty(B, 4, HW, device=DEV)
+    ops.guide_update(mean.to(DEV), lv.to(DEV), gg.to(DEV), dxu.to(DEV), nz.to(DEV), coef, scale4.to(DEV), 0.005,
+                     out, gout, B, HW)
+    grad = 1.7 * gg + dxu
+    ref = mean - scale4[None, :, None] * grad.clamp(-0.005, 0.005) + torch.exp(0.5 * lv) * nz
+    assert torch.allclose(gout.cpu(), grad, atol=1e-7)
+    assert torch.allclose(out.cpu(), ref, atol=1e-6)
+    coef[6] = 0.0   # t == 0: no noise
+    ops.guide_update(mean.to(DEV), lv.to(DEV), gg.to(DEV), dxu.to(DEV), nz.to(DEV), coef, scale4.to(DEV), 0.005,
+                     out, None, B, HW)
+    assert torch.allclose(out.cpu(), mean - scale4[None, :, None] * grad.clamp(-0.005, 0.005), atol=1e-6)

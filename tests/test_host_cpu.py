@@ -1,0 +1,207 @@
+"""CPU-only checks of the product's host logic: registries and their error behaviour, schedule
+tables (bit-exact vs the reference-captured golden), string-valued config parsing, state_dict
+layout, the C-ABI library's exported symbols, and the loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd  # noqa: E402
+from osmosis_diffusion_code_amd.guided_diffusion import measurements as M  # noqa: E402
+from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM  # noqa: E402
+from osmosis_diffusion_code_amd.guided_diffusion import posterior_mean_variance as pmv  # noqa: E402
+from osmosis_diffusion_code_amd.guided_diffusion import unet  # noqa: E402
+from osmosis_diffusion_code_amd.osmosis_utils import utils as utilso  # noqa: E402
+from osmosis_diffusion_code_amd.osmosis_utils import losses as losseso  # noqa: E402
+from osmosis_diffusion_code_amd import _lib  # noqa: E402
+
+DIFF = dict(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+            model_var_type="learned_range", dynamic_threshold=False, clip_denoised=False,
+            rescale_timesteps=False)
+
+
+@pytest.mark.parametrize("tag,resp", [("T1000", 1000), ("T250", "250"), ("T10", [10])])
+def test_sampler_tables_bit_exact_vs_reference(tag, resp):
+    g = dict(np.load(os.path.join(GOLD, "schedules.npz")))
+    s = gd.create_sampler(timestep_respacing=resp, **DIFF)
+    assert np.array_equal(s.betas, g[f"{tag}.betas"])
+    assert s.timestep_map == list(g[f"{tag}.timestep_map"])
+    assert np.array_equal(s.mean_processor.sqrt_recip_alphas_cumprod, g[f"{tag}.sqrt_recip_alphas_cumprod"])
+    assert np.array_equal(s.mean_processor.sqrt_recipm1_alphas_cumprod, g[f"{tag}.sqrt_recipm1_alphas_cumprod"])
+    assert np.array_equal(s.mean_processor.posterior_mean_coef1, g[f"{tag}.posterior_mean_coef1"])
+    assert np.array_equal(s.mean_processor.posterior_mean_coef2, g[f"{tag}.posterior_mean_coef2"])
+    assert np.array_equal(s.var_processor.posterior_log_variance_clipped, g[f"{tag}.posterior_log_variance_clipped"])
+    tab = s.coef_table()
+    T = s.num_timesteps
+    assert tab.shape == (T, 8) and tab.dtype == np.float32
+    assert np.array_equal(tab[:, 0], g[f"{tag}.sqrt_recip_alphas_cumprod"].astype(np.float32))
+    assert np.array_equal(tab[:, 5], g[f"{tag}.log_betas"].astype(np.float32))
+    assert tab[0, 6] == 0.0 and (tab[1:, 6] == 1.0).all()
+    assert np.array_equal(tab[:, 7], np.array(s.timestep_map, dtype=np.float32))
+
+
+def test_schedule_helpers_and_errors():
+    g = dict(np.load(os.path.join(GOLD, "schedules.npz")))
+    assert np.array_equal(gd.get_named_beta_schedule("cosine", 50), g["cosine50.betas"])
+    assert sorted(gd.space_timesteps(300, [10, 15, 20])) == list(g["space_1000_10_15_20"])
+    assert sorted(gd.space_timesteps(1000, "ddim25")) == list(g["space_ddim25"])
+    with pytest.raises(NotImplementedError):
+        gd.get_named_beta_schedule("quadratic", 10)
+    with pytest.raises(ValueError):
+        gd.space_timesteps(10, [20])
+    with pytest.raises(ValueError):
+        gd.space_timesteps(1000, "ddim999")
+
+
+def test_registries_raise_like_the_reference():
+    with pytest.raises(NameError):
+        gd.get_sampler("nope")
+    with pytest.raises(NameError):
+        gd.register_sampler("ddpm")(object)
+    with pytest.raises(NameError):
+        M.get_operator("nope", device="cpu")
+    with pytest.raises(NameError):
+        M.register_operator("haze_physical")(object)
+    with pytest.raises(NameError):
+        M.get_noise("nope")
+    with pytest.raises(NameError):
+        CM.get_conditioning_method("nope", None, None)
+    with pytest.raises(NameError):
+        CM.register_conditioning_method("osmosis")(object)
+    with pytest.raises(NameError):
+        pmv.get_mean_processor("nope", betas=None, dynamic_threshold=False, clip_denoised=False)
+    with pytest.raises(NameError):
+        pmv.get_var_processor("nope", betas=None)
+    with pytest.raises(NameError):
+        losseso.get_loss("nope")
+    # third-party additions stay possible
+    @M.register_noise("unit_test_noise")
+    class _N(M.Noise):
+        def forward(self, data):
+            return data
+    assert M.get_noise("unit_test_noise").__name__ == "unit_test_noise"
+
+
+def test_operator_config_parsing():
+    op = M.get_operator("underwater_physical_revised", device="cpu", batch_size=2, optimizer="sgd",
+                        depth_type="gamma", value="1.4,1.4,1", phi_a="1.1,0.95,0.95", phi_a_eta="1e-5",
+                        phi_b="0.95, 0.8, 0.8", phi_b_learn_flag=False, phi_inf="0.14, 0.29, 0.49")
+    assert op.__name__ == "underwater_physical_revised"
+    assert op.phi.shape == (2, 9)
+    assert np.allclose(op.phi[1].numpy(), [1.1, 0.95, 0.95, 0.95, 0.8, 0.8, 0.14, 0.29, 0.49])
+    assert op.eta3() == (1e-5, 0.0, 1e-5)
+    v = op.variables()
+    assert set(v) == {"phi_a", "phi_b", "phi_inf"} and v["phi_a"].shape == (2, 3, 1, 1)
+    hz = M.get_operator("haze_physical", device="cpu", phi_ab="1.0", phi_inf="0.1,0.2,0.3", depth_type="gamma",
+                        value="1.4,1.4,1", optimizer="GD")
+    assert hz.variables()["phi_ab"].shape == (1, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        M.get_operator("haze_physical", device="cpu", phi_ab="1.0", phi_inf="0.1,0.2,0.3", optimizer="adam")
+    with pytest.raises(ValueError):
+        M.get_operator("haze_physical", device="cpu", phi_ab="1.0", phi_inf="0.1,0.2,0.3", optimizer="bogus")
+    with pytest.raises(NotImplementedError):
+        M.get_operator("haze_physical", device="cpu", phi_ab="1.0", phi_inf="0.1,0.2,0.3", depth_type="cubic")
+    # forward model on CPU tensors == oracle formula
+    from oracle.diffusion_ref import PhysOperator
+    ref = PhysOperator("haze_physical", depth_type="gamma", value="1.4,1.4,1", phi_ab="1.0", phi_inf="0.1,0.2,0.3")
+    x = torch.randn(1, 4, 5, 5, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(hz.forward(x), ref.forward(x), atol=1e-7)
+
+
+def test_conditioning_config_parsing():
+    op = M.get_operator("underwater_physical", device="cpu", phi_ab="1,1,1", phi_inf="0.2,0.4,0.7", optimizer="sgd")
+    c = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), scale="7,7,7,0.9",
+                                   gradient_clip="True,0.005", gradient_x_prev=True, n_iter=20,
+                                   aux_loss={"avrg_loss": 0.5, "val_loss": "20"}, weight_function="gamma,1.4,1.4,1",
+                                   loss_weight="depth")
+    assert c.scale.tolist() == pytest.approx([7, 7, 7, 0.9])
+    assert c.gradient_clip and c.gradient_clip_value == 0.005 and c.n_iter == 20
+    assert c.aux_loss.kernel_coefficients() == {"gamma_avrg": 0.5, "gamma_val": 20.0}
+    c2 = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), scale=3.0, gradient_clip="False")
+    assert c2.scale.tolist() == [3.0] and not c2.gradient_clip and c2.clip_value == 0.0
+    assert utilso.parse_weight_function("gamma,1.4,1.4,1")[0] == "gamma"
+    assert utilso.str2bool("Yes") and not utilso.str2bool("0")
+    with pytest.raises(Exception):
+        utilso.str2bool("maybe")
+
+
+def test_freeze_and_alternate_schedule():
+    p = dict(pattern="pcgs", update_start=0.7, update_end=0, s_start=1, s_end=0, local_M=1,
+             start_guidance=1, stop_guidance=0)
+    assert utilso.is_freeze_phi(p, 999, 1000) and utilso.is_freeze_phi(p, 701, 1000)
+    assert not utilso.is_freeze_phi(p, 700, 1000) and not utilso.is_freeze_phi(p, 0, 1000)
+    assert not utilso.is_freeze_phi({"pattern": "original"}, 5, 10) and not utilso.is_freeze_phi(None, 5, 10)
+    assert utilso.set_alternate_length(p, 500, 1000) == 1
+    from oracle.diffusion_ref import is_freeze_phi as ref_freeze
+    for idx in range(0, 1000, 37):
+        assert utilso.is_freeze_phi(p, idx, 1000) == ref_freeze(p, idx, 1000)
+
+
+def test_state_dict_layout_matches_reference_keys():
+    kw = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2",
+              attention_resolutions="128,64", num_head_channels=16, num_heads=4, learn_sigma=True,
+              use_scale_shift_norm=True, resblock_updown=True, pretrain_model="osmosis")
+    m = unet.create_model(**kw)
+    shapes = U.param_shapes(U.UNetConfig.from_create_model_kwargs(**kw))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], k
+    # same key set as the golden blocks captured from the reference modules
+    g = np.load(os.path.join(GOLD, "blocks.npz"))
+    ref_keys = {k.split(".sd.")[1] for k in g.files if k.startswith("res_skip.sd.")}
+    ours = {k[len("input_blocks.3.0."):] for k in sd if k.startswith("input_blocks.3.0.")}
+    assert ours == ref_keys
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 32, 32), torch.zeros(1))
+
+
+def test_full_size_model_has_the_reference_parameter_count():
+    cfg = U.UNetConfig.from_create_model_kwargs(image_size=256, num_channels=256, num_res_blocks=2,
+                                                attention_resolutions="32, 16, 8", num_heads=4,
+                                                num_head_channels=64, use_scale_shift_norm=True,
+                                                resblock_updown=True, learn_sigma=True, pretrain_model="osmosis")
+    n = sum(int(np.prod(s)) for s in U.param_shapes(cfg).values())
+    assert n == 552_821_000   # SURVEY.md section 6 [probe]
+
+
+def test_create_model_argument_errors():
+    with pytest.raises(ValueError):
+        unet.create_model(image_size=100, num_channels=32, num_res_blocks=1)
+    with pytest.raises(NotImplementedError):
+        unet.create_model(image_size=64, num_channels=32, num_res_blocks=1, attention_resolutions=1.5)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "osmosis_hip.h")).read()
+    declared = set(re.findall(r"\b(osm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"osm_status"}
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/osmosis_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.load().osm_version() > 0
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    from osmosis_diffusion_code_amd import ops
+    with pytest.raises(_lib.OsmosisHipError, match="no CPU fallback"):
+        ops.timestep_embedding(torch.zeros(2), torch.zeros(2, 8), 2, 8)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "osmosis_diffusion_code_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
