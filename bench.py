@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the Osmosis guided-diffusion hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): osmosis_sample_config.yaml -- the 552.8 M-parameter RGBD UNet
+(256 ch, mult 1,1,2,2,4,4, attention at 32/16/8), 1x4x256x256 per GPU, 1000-step DDPM (linear
+schedule, epsilon mean, learned-range variance), `underwater_physical_revised` operator, 'osmosis'
+guidance with n_iter=20 inner phi iterations, scale 7,7,7,0.9, clip 0.005, aux losses 0.5/20.
+One "step" = one iteration of the reference loop (gaussian_diffusion.py:213): UNet forward, posterior,
+20x (physics loss + phi SGD), UNet input-gradient, guidance update, noise.  Timed steps are taken
+from the phi-update regime (t <= 0.7 T), i.e. the expensive 70 % of the chain.  Weights are seeded
+synthetic (no checkpoint is available offline), inputs synthetic; timing is value independent.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (3x3 implicit-GEMM conv,
+fp32 MFMA): algorithmic FLOPs of every 3x3-conv launch of one guided step divided by the
+HIP-event-measured duration of those launches (events on the launch stream).  `cpu_baseline` times
+the CPU oracle (oracle/, torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+UNET_KW = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
+               class_cond=False, use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4,
+               num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+               resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path="",
+               pretrain_model="osmosis")
+DIFFUSION = dict(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                 model_var_type="learned_range", dynamic_threshold=False, clip_denoised=False,
+                 rescale_timesteps=False, timestep_respacing=1000)
+OPERATOR = dict(optimizer="sgd", depth_type="gamma", value="1.4,1.4,1", phi_a="1.1,0.95,0.95", phi_a_eta="1e-5",
+                phi_a_learn_flag=True, phi_b="0.95, 0.8, 0.8", phi_b_eta="1e-5", phi_b_learn_flag=True,
+                phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5", phi_inf_learn_flag=True)
+COND = dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1", scale="7,7,7,0.9",
+            gradient_x_prev=True, gradient_clip="True,0.005")
+PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0, n_iter=20,
+               start_guidance=1, stop_guidance=0)
+AUX = {"avrg_loss": 0.5, "val_loss": 20}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+
+
+def shard(n_items: int, rank: int, world: int):
+    """images[rank::world] -- every image is an independent chain."""
+    return list(range(n_items))[rank::world]
+
+
+def synthetic_inputs(image_index: int, B: int, size: int):
+    g = torch.Generator().manual_seed(1000 + image_index)
+    x_T = torch.randn(B, 4, size, size, generator=g)
+    y = torch.rand(B, 3, size, size, generator=g) * 1.6 - 0.8
+    return x_T, y
+
+
+def seeded_weights(model, seed=1234):
+    """Deterministic non-degenerate weights for the product model (no oracle import on this path)."""
+    model.reset_parameters(seed)
+
+
+def run_gpu(args, rank, world, dev):
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+
+    kw = dict(UNET_KW)
+    if args.tiny:
+        kw.update(num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+                  num_head_channels=16)
+    model = unet.create_model(**kw)
+    seeded_weights(model)
+    model = model.to(dev).eval()
+    B, S = args.batch, args.image_size
+    sampler = gd.create_sampler(**DIFFUSION)
+    op = M.get_operator("underwater_physical_revised", device=dev, batch_size=B, **OPERATOR)
+    cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **COND, **PATTERN, aux_loss=AUX)
+    x_T, y = synthetic_inputs(shard(world, rank, world)[0], B, S)
+    x_T, y = x_T.to(dev), y.to(dev)
+    T = sampler.num_timesteps
+    first = min(int(0.7 * T) - 1, T - 1)
+
+    def run(n_steps, start):
+        return sampler.p_sample_loop(model=model, x_start=x_T, measurement=y, measurement_cond_fn=cond.conditioning,
+                                     record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+                                     sample_pattern=PATTERN, index_range=(start, start - n_steps + 1),
+                                     reference_rng_order=False)
+
+    if args.warmup > 0:
+        run(args.warmup, first)
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(args.steps, first - args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(out[0]).all())
+    return model, dt, finite
+
+
+def roofline(model, args):
+    """HIP-event timing of every launch of one guided step's UNet plans; 3x3 conv = dominant kernel."""
+    B, S = args.batch, args.image_size
+    eng = model.engine(B, S, S)
+
+    def select(name, a):
+        if name == "osm_conv2d_nhwc":
+            d = a[0]._obj
+            fl = 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * d.ksize * d.ksize
+            return ("conv3x3" if d.ksize == 3 else "conv1x1", fl)
+        if name == "osm_gemm":
+            d = a[0]._obj
+            return ("attn_gemm", 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2)
+        if name.startswith("osm_gn"):
+            return ("groupnorm", 0.0)
+        return ("other", 0.0)
+
+    agg = {}
+    reps = 3
+    for _ in range(reps):
+        for plan in (eng._fwd_plan, eng._bwd_plan):
+            for (tag, fl), ms in plan.replay_timed(select):
+                a = agg.setdefault(tag, [0.0, 0.0, 0])
+                a[0] += ms
+                a[1] += fl
+                a[2] += 1
+    out = {k: {"ms_per_step": v[0] / reps, "gflop_per_step": v[1] / reps / 1e9, "launches_per_step": v[2] // reps}
+           for k, v in agg.items()}
+    c = out["conv3x3"]
+    achieved = c["gflop_per_step"] / c["ms_per_step"]  # GFLOP/ms == TFLOP/s
+    return {"bound": "mfma", "kernel": "igemm_f32_kernel<9,false> (3x3 conv fwd + dgrad)",
+            "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
+            "avg_launch_ms": c["ms_per_step"] / c["launches_per_step"],
+            "launches_per_step": c["launches_per_step"]}, out
+
+
+def cpu_baseline(args):
+    """Time the CPU oracle (torch-CPU fp32 restatement of the reference path) on the host cores."""
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    kw = dict(UNET_KW)
+    if args.tiny:
+        kw.update(num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+                  num_head_channels=16)
+    cfg = U.UNetConfig.from_create_model_kwargs(**kw)
+    sd = U.seeded_state_dict(cfg, 1234)
+    cores = torch.get_num_threads()
+    tb = D.make_tables(1000, "linear", 1000)
+    rop = D.PhysOperator("underwater_physical_revised", batch_size=1, depth_type="gamma", value="1.4,1.4,1",
+                         phi_a="1.1,0.95,0.95", phi_b="0.95, 0.8, 0.8", phi_inf="0.14, 0.29, 0.49")
+    rg = D.OsmosisGuidance(rop, n_iter=20, scale=COND["scale"], gradient_clip=COND["gradient_clip"], aux=AUX)
+    x_T, y = synthetic_inputs(0, 1, args.image_size)
+    n_timed = args.cpu_steps
+    sub = D.Tables(D.named_beta_schedule("linear", 1000), range(0, 1 + n_timed))   # t = n_timed .. 0 : phi-update regime
+    noises = [torch.randn(1, 4, args.image_size, args.image_size) for _ in range(1 + n_timed)]
+    model = lambda x, t: U.unet_forward(sd, cfg, x, t)  # noqa: E731
+    times = []
+
+    class Timed(list):
+        def append(self, rec):
+            times.append(time.perf_counter())
+            super().append(rec)
+
+    t0 = time.perf_counter()
+    D.p_sample_loop(model, sub, 0.5 * x_T, y, rg, PATTERN, noises, Timed())
+    steps = [b - a for a, b in zip([t0] + times[:-1], times)]
+    timed = steps[1:]                                   # first step = warm-up
+    sps = len(timed) / sum(timed)
+    return {"value": round(sps, 5), "unit": "denoise-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(timed)} guided steps (B=1, 256x256, n_iter=20) after 1 warm-up step, "
+                      f"torch-CPU fp32 oracle, {cores} threads; {sum(timed) / len(timed):.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU (reference config: 1)")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model, dt, finite = run_gpu(args, rank, world, dev)
+    units = world * args.batch * args.steps
+    line = {
+        "metric": "denoise-steps/sec (256x256 RGBD, 1000-step DDPM+guidance)",
+        "value": round(units / dt, 4), "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
+                               "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime t<=0.7T",
+                   "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
+                   "weights": "seeded synthetic", "parallelism": f"images[rank::{world}] (no collective on the path)",
+                   "finite_outputs": finite},
+        "images_per_sec_at_1000_steps": round(units / dt / 1000.0, 6),
+    }
+    if rank == 0:
+        rl, breakdown = roofline(model, args)
+        line["roofline"] = rl
+        line["kernel_breakdown_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in breakdown.items()}
+        line["achieved_tflops_whole_step"] = round(
+            sum(v["gflop_per_step"] for v in breakdown.values()) / (1e3 * dt / args.steps), 2)
+        if world == 1 and args.cpu_steps > 0:
+            del model
+            line["cpu_baseline"] = cpu_baseline(args)
+            line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,24 @@ class Recorder:
             if rc != 0:
                 raise OsmosisHipError(f"{fn.__name__} failed ({rc}): {load().osm_last_error().decode()}")
 
+    def replay_timed(self, select):
+        """Replay with HIP events around the selected launches (events are recorded on the stream
+        the kernels run on).  `select(fn_name, args)` returns a tag or None.  Returns [(tag, ms)]."""
+        marks = []
+        for fn, args in self.calls:
+            tag = select(fn.__name__, args)
+            if tag is None:
+                fn(*args)
+                continue
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args)
+            e1.record()
+            marks.append((tag, e0, e1))
+        torch.cuda.synchronize()
+        return [(tag, e0.elapsed_time(e1)) for tag, e0, e1 in marks]
+
     def __len__(self):
         return len(self.calls)
 

@@ -229,7 +229,10 @@ class GaussianDiffusion:
         trace = kwargs.get("trace", None)                 # list collecting per-step tensors (tests)
         draw_measurement_noise = kwargs.get("reference_rng_order", noise_fn is None)
         loss = None
-        for k, idx in enumerate(range(T - 1, -1, -1)):
+        # optional sub-range of the chain (benchmarks / resumed chains): idx = first .. last, descending
+        first, last = kwargs.get("index_range", (T - 1, 0))
+        step.fill_(first)
+        for k, idx in enumerate(range(first, last - 1, -1)):
             guided = self._guidance_flag(sample_pattern, idx)
             freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
             if draw_measurement_noise:

@@ -62,7 +62,7 @@ def test_conv_fwd_and_dgrad(ops, B, Cin, Cout, H, W, k, splitk):
     ops.conv2d(xm, wf, bias.to(DEV), ops.Mat.of(y), B, H, W, k, res=ops.Mat.of(to_nhwc(res)),
                splitk=splitk, splitk_ws=ws)
     out = from_nhwc(y, B, H, W)
-    assert relerr(out, ref) < 2e-6, relerr(out, ref)
+    assert relerr(out, ref) < 5e-6, relerr(out, ref)
 
     # data gradient == conv with the dgrad packing
     dy = torch.randn(B, Cout, H, W, generator=g)
@@ -71,7 +71,7 @@ def test_conv_fwd_and_dgrad(ops, B, Cin, Cout, H, W, k, splitk):
     dx = torch.full((B * H * W, Cin), float("nan"), device=DEV)
     ws2 = torch.empty(splitk * B * H * W * Cin, device=DEV) if splitk > 1 else None
     ops.conv2d(ops.Mat.of(to_nhwc(dy)), wd, None, ops.Mat.of(dx), B, H, W, k, splitk=splitk, splitk_ws=ws2)
-    assert relerr(from_nhwc(dx, B, H, W), dref) < 2e-6
+    assert relerr(from_nhwc(dx, B, H, W), dref) < 5e-6
 
 
 def test_conv_strided_views_and_accumulate(ops):
