@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
           sh[e] = a.film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
         }
       }
+#pragma unroll 4
       for (int p = p0 + tr; p < p1; p += rowT) {
         const long long row = (long long)b * a.HW + p;
         float xv[VEC], dv[VEC];
@@ -132,18 +133,27 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
   }
 }
 
+// one wave per (b, g): lanes stride over the chunk partials, fp64 combine, shuffle reduce.
 template <int MODE>
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int G,
-                                   int nchunk, double n, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ out, int B, int G, int nchunk,
+                                                           double n, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B * G) return;
   const int b = i / G, g = i % G;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    const float* pp = part + (((long long)b * nchunk + k) * G + g) * 2;
-    s1 += (double)pp[0];
-    s2 += (double)pp[1];
+  for (int k = lane; k < nchunk; k += 64) {
+    const float2 pp = *reinterpret_cast<const float2*>(part + (((long long)b * nchunk + k) * G + g) * 2);
+    s1 += (double)pp.x;
+    s2 += (double)pp.y;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (lane != 0) return;
   if (MODE == 0) {
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
@@ -157,16 +167,27 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, float* __rest
 }
 
 // MODE 0: y = act(GN(x)).   MODE 1: dx = dGN(dy) (+ addend)
+// Same (chunk, image) grid and (column-vector, row) thread mapping as the reduce pass: a thread owns
+// fixed channel vector(s), so gamma/beta/FiLM/statistics are loaded once and the row loop is pure
+// streaming (no integer division in the hot loop).
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
   const int vpr = a.C / VEC;
-  const long long total = (long long)a.B * a.HW * vpr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long row = i / vpr;
-    const int v = (int)(i - row * vpr);
+  const int colT = vpr < 256 ? vpr : 256;
+  const int rowT = 256 / colT;
+  const int nj = (vpr + 255) / 256;
+  const int tc = tid % colT, tr = tid / colT;
+  if (tr >= rowT) return;
+  const int p0 = chunk * PPC;
+  const int p1 = min(a.HW, p0 + PPC);
+  const bool film = a.film != nullptr;
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) {
+    const int v = tc + colT * j;
+    if (j >= nj || v >= vpr) break;
     const int c = v * VEC;
-    const int b = (int)(row / a.HW);
     const int g = c / a.gs;
     const float mean = a.stats[(b * a.G + g) * 2];
     const float rstd = a.stats[(b * a.G + g) * 2 + 1];
@@ -175,47 +196,67 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
       m1 = a.gstats[(b * a.G + g) * 2];
       m2 = a.gstats[(b * a.G + g) * 2 + 1];
     }
-    float xv[VEC], dv[VEC], ov[VEC], av[VEC];
-    if (VEC == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
-      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-      if (MODE == 1) {
-        const float4 u = *reinterpret_cast<const float4*>(a.dy + row * a.lddy + c);
-        dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
-        if (a.addend) {
-          const float4 w = *reinterpret_cast<const float4*>(a.addend + row * a.ldadd + c);
-          av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
-        }
-      }
-    } else {
-      xv[0] = a.x[row * a.ldx + c];
-      if (MODE == 1) {
-        dv[0] = a.dy[row * a.lddy + c];
-        if (a.addend) av[0] = a.addend[row * a.ldadd + c];
-      }
-    }
+    float ga[VEC], be[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float ga = a.gamma[c + e], be = a.beta[c + e];
-      const float sc = a.film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
-      const float sh = a.film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
-      float xh, z;
-      gn_fwd_elem(xv[e], mean, rstd, ga, be, a.film != nullptr, sc, sh, xh, z);
-      if (MODE == 0) {
-        ov[e] = a.silu ? osm::silu_f(z) : z;
-      } else {
-        float dz = dv[e] * (a.silu ? osm::dsilu_f(z) : 1.0f);
-        if (a.film) dz *= (1.0f + sc);
-        const float dxh = dz * ga;
-        float r = rstd * (dxh - m1 - xh * m2);
-        if (a.addend) r += av[e];
-        ov[e] = r;
-      }
+      ga[e] = a.gamma[c + e];
+      be[e] = a.beta[c + e];
+      sc[e] = film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
+      sh[e] = film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
     }
-    if (VEC == 4) {
-      *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    } else {
-      a.out[row * a.ldo + c] = ov[0];
+    const float* xp = a.x + ((long long)b * a.HW + p0 + tr) * a.ldx + c;
+    const float* dp = MODE == 1 ? a.dy + ((long long)b * a.HW + p0 + tr) * a.lddy + c : nullptr;
+    const float* ap = (MODE == 1 && a.addend) ? a.addend + ((long long)b * a.HW + p0 + tr) * a.ldadd + c : nullptr;
+    float* op = a.out + ((long long)b * a.HW + p0 + tr) * a.ldo + c;
+    const long long sx = (long long)rowT * a.ldx, sd = (long long)rowT * a.lddy, sa = (long long)rowT * a.ldadd,
+                    so = (long long)rowT * a.ldo;
+#pragma unroll 4
+    for (int p = p0 + tr; p < p1; p += rowT) {
+      float xv[VEC], dv[VEC], ov[VEC], av[VEC];
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(xp);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        if (MODE == 1) {
+          const float4 u = *reinterpret_cast<const float4*>(dp);
+          dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
+          if (ap) {
+            const float4 w = *reinterpret_cast<const float4*>(ap);
+            av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
+          }
+        }
+      } else {
+        xv[0] = *xp;
+        if (MODE == 1) {
+          dv[0] = *dp;
+          if (ap) av[0] = *ap;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float xh, z;
+        gn_fwd_elem(xv[e], mean, rstd, ga[e], be[e], film, sc[e], sh[e], xh, z);
+        if (MODE == 0) {
+          ov[e] = a.silu ? osm::silu_f(z) : z;
+        } else {
+          float dz = dv[e] * (a.silu ? osm::dsilu_f(z) : 1.0f);
+          if (film) dz *= (1.0f + sc[e]);
+          const float dxh = dz * ga[e];
+          float r = rstd * (dxh - m1 - xh * m2);
+          if (ap) r += av[e];
+          ov[e] = r;
+        }
+      }
+      if (VEC == 4) {
+        *reinterpret_cast<float4*>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      } else {
+        *op = ov[0];
+      }
+      xp += sx;
+      op += so;
+      if (MODE == 1) {
+        dp += sd;
+        if (ap) ap += sa;
+      }
     }
   }
 }
@@ -249,7 +290,7 @@ int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
   int rc = osm::check_launch("gn_reduce_kernel");
   if (rc) return rc;
   const int n = a.B * a.G;
-  hipLaunchKernelGGL((gn_finalize_kernel<MODE>), dim3((n + 63) / 64), dim3(64), 0, st, a.part, finalized, a.B,
+  hipLaunchKernelGGL((gn_finalize_kernel<MODE>), dim3((n + 3) / 4), dim3(256), 0, st, a.part, finalized, a.B,
                      a.G, a.nchunk, (double)a.HW * a.gs, a.eps);
   return osm::check_launch("gn_finalize_kernel");
 }
@@ -257,14 +298,14 @@ int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
 template <int MODE>
 int run_apply(GNArgs& a, hipStream_t st) {
   a.gs = a.C / a.G;
+  a.nchunk = (a.HW + PPC - 1) / PPC;
   const bool v4 = use_vec4(a);
-  const long long total = (long long)a.B * a.HW * (a.C / (v4 ? 4 : 1));
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (!v4) OSM_REQUIRE(a.C <= 256 * NJMAX, "GroupNorm scalar path: C too large");
+  dim3 grid(a.nchunk, a.B);
   if (v4)
-    hipLaunchKernelGGL((gn_apply_kernel<4, MODE>), dim3((int)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gn_apply_kernel<4, MODE>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<1, MODE>), dim3((int)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gn_apply_kernel<1, MODE>), grid, dim3(256), 0, st, a);
   return osm::check_launch("gn_apply_kernel");
 }
 

@@ -28,10 +28,13 @@ inline int check_launch(const char* what) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+// sigmoid via the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); the accurate expf /
+// IEEE divide cost ~10x the VALU work and turn the HBM-bound GroupNorm passes VALU-bound.
+__device__ __forceinline__ float sigmoid_f(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 // d silu(z) / dz = s (1 + z (1 - s)),  s = sigmoid(z)
 __device__ __forceinline__ float dsilu_f(float z) {
-  float s = 1.0f / (1.0f + expf(-z));
+  const float s = sigmoid_f(z);
   return s * (1.0f + z * (1.0f - s));
 }
 
