@@ -155,9 +155,23 @@ def roofline(model, args):
             json.dump(rows, f, indent=0)
     c = out["conv3x3"]
     achieved = c["gflop_per_step"] / c["ms_per_step"]  # GFLOP/ms == TFLOP/s
+    # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py); null when none is committed.
+    traffic, traffic_src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
+        try:
+            for k in json.load(open(path))["kernels"]:
+                if k["kernel"].replace(" ", "") == "igemm_f32_kernel<9,false>":
+                    traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1] for k, v in per_shape.items()
+                    if k[5] == 3) / max(1, sum(v[1] for k, v in per_shape.items() if k[5] == 3))
     return {"bound": "mfma", "kernel": "igemm_f32_kernel<9,false> (3x3 conv fwd + dgrad)",
             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch_avg": round(alg_bytes),
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
             "avg_launch_ms": c["ms_per_step"] / c["launches_per_step"],
             "launches_per_step": c["launches_per_step"]}, out
