@@ -47,6 +47,7 @@ PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local
                start_guidance=1, stop_guidance=0)
 AUX = {"avrg_loss": 0.5, "val_loss": 20}
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 
 
 def shard(n_items: int, rank: int, world: int):
@@ -80,6 +81,7 @@ def run_gpu(args, rank, world, dev):
     model = unet.create_model(**kw)
     seeded_weights(model)
     model = model.to(dev).eval()
+    model.conv_mode = args.conv_mode
     B, S = args.batch, args.image_size
     sampler = gd.create_sampler(**DIFFUSION)
     op = M.get_operator("underwater_physical_revised", device=dev, batch_size=B, **OPERATOR)
@@ -162,15 +164,25 @@ def roofline(model, args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
             for k in json.load(open(path))["kernels"]:
-                if k["kernel"].replace(" ", "") == "igemm_f32_kernel<9,false>":
+                if k["kernel"].replace(" ", "") == {"f32": "igemm_f32_kernel<9,false>", "bf16x6": "igemm_bf16s_kernel<9,3>",
+                                                    "bf16x3": "igemm_bf16s_kernel<9,2>"}[args.conv_mode]:
                     traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except Exception:
             pass
     alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1] for k, v in per_shape.items()
                     if k[5] == 3) / max(1, sum(v[1] for k, v in per_shape.items() if k[5] == 3))
-    return {"bound": "mfma", "kernel": "igemm_f32_kernel<9,false> (3x3 conv fwd + dgrad)",
-            "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+    kname, peak, note = {
+        "f32": ("igemm_f32_kernel<9,false>", FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
+        "bf16x6": ("igemm_bf16s_kernel<9,3>", BF16_MFMA_PEAK_TFLOPS / 6.0,
+                   "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per fp32 product (fp32-class accuracy): "
+                   "peak = dense bf16 MFMA peak 2500 TFLOP/s / 6; achieved counts ALGORITHMIC flops"),
+        "bf16x3": ("igemm_bf16s_kernel<9,2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
+                   "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative): "
+                   "peak = 2500 / 3; achieved counts ALGORITHMIC flops"),
+    }[args.conv_mode]
+    return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": round(alg_bytes),
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
             "avg_launch_ms": c["ms_per_step"] / c["launches_per_step"],
@@ -222,6 +234,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU (reference config: 1)")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "bf16x3"],
+                    help="conv arithmetic: exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
     args = ap.parse_args()
@@ -248,7 +262,7 @@ def main():
         "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
                                "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime t<=0.7T",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
-                   "weights": "seeded synthetic", "parallelism": f"images[rank::{world}] (no collective on the path)",
+                   "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode, "parallelism": f"images[rank::{world}] (no collective on the path)",
                    "finite_outputs": finite},
         "images_per_sec_at_1000_steps": round(units / dt / 1000.0, 6),
     }

@@ -52,6 +52,9 @@ typedef struct osm_conv_desc {
   int splitk;          /* >=1: number of K slices                                      */
   int accumulate;      /* !=0: y += result                                             */
   long long ldx, ldy, ldr;
+  int wfmt;            /* weight image: 0 = fp32 [tap][Cout][Cin] (exact-f32 MFMA);
+                          3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
+                          (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16) */
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
 
@@ -74,6 +77,13 @@ typedef struct osm_gemm_desc {
   long long lda, ldb, ldc, ldr;
   long long sA1, sB1, sC1, sA2, sB2, sC2;   /* batch strides in floats (res uses sC*)  */
 } osm_gemm_desc;
+/* Split-bf16 weight images: `wfmt` planes of bf16 [plane][tap][rows][Kp], Kp = K rounded up to 8, zero
+ * padded; forward rows=Cout,K=Cin; data-gradient rows=Cin,K=Cout (taps flipped).  Sizes in uint16
+ * elements from osm_packed_weight_elems (wfmt 0 -> float elements of osm_pack_conv_weight). */
+long long osm_packed_weight_elems(int Cout, int Cin, int ksize, int wfmt, int dgrad);
+int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize,
+                               int wfmt, void* stream);
+
 int osm_gemm(const osm_gemm_desc* d, void* stream);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("y", C.c_void_p), ("splitk_ws", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("ksize", C.c_int), ("splitk", C.c_int), ("accumulate", C.c_int),
-                ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong)]
+                ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong), ("wfmt", C.c_int)]
 
 
 class GemmDesc(C.Structure):
@@ -59,6 +59,7 @@ _SIGS = {
     "osm_conv2d_nhwc": [C.POINTER(ConvDesc), _P],
     "osm_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _P],
     "osm_gemm": [C.POINTER(GemmDesc), _P],
+    "osm_pack_conv_weight_bf16s": [_P, _P, _P, _I, _I, _I, _I, _P],
     "osm_splitk_hint": [_I, _I, _I, _I, _I],
     "osm_gn_nchunk": [_I],
     "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
@@ -83,7 +84,7 @@ _SIGS = {
     "osm_fetch_coefs": [_P, _P, _I, _P, _P, _I, _P],
     "osm_version": [],
 }
-EXPORTS = sorted(list(_SIGS) + ["osm_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems"])
 
 _lib = None
 _lock = threading.Lock()
@@ -106,6 +107,8 @@ def load():
                 fn = getattr(lib, name)
                 fn.argtypes = argtypes
                 fn.restype = C.c_int
+            lib.osm_packed_weight_elems.argtypes = [_I, _I, _I, _I, _I]
+            lib.osm_packed_weight_elems.restype = C.c_longlong
             lib.osm_last_error.argtypes = []
             lib.osm_last_error.restype = C.c_char_p
             _lib = lib
@@ -196,6 +199,6 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if not t.is_cuda:
         raise OsmosisHipError("osmosis_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
                               "(there is no CPU fallback on the product path)")
-    if t.dtype not in (torch.float32, torch.int32):
+    if t.dtype not in (torch.float32, torch.int32, torch.int16):   # int16 = packed bf16 weight planes
         raise OsmosisHipError(f"osmosis_hip kernels are fp32; got {t.dtype}")
     return t.data_ptr()

@@ -47,6 +47,7 @@ struct IGemmParams {
   float alpha;
   long long lda, ldb, ldc, ldr;
   long long tapstrideB;
+  long long planestrideB;
   int nb1;
   long long sA1, sB1, sC1, sA2, sB2, sC2;
   int mtiles, ntiles;
@@ -312,14 +313,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st) {
+#include "igemm_bf16s.inc.h"
+
+int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
   p.nchunks = taps * ((p.K + BK - 1) / BK);
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > p.nchunks) p.splitk = p.nchunks;
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
-  if (taps == 9) {
+  if (wfmt != 0) {
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
+    if (wfmt == 3 && taps == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), grid, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 3)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), grid, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 2 && taps == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 2>), grid, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 2)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), grid, dim3(256), 0, st, p.A, Bp, p);
+    else
+      return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+  } else if (taps == 9) {
     if (b_kn) return osm::fail(OSM_ERR_UNSUPPORTED, "3x3 conv needs [n][k] weights");
     hipLaunchKernelGGL((igemm_f32_kernel<9, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   } else if (b_kn) {
@@ -344,7 +359,7 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st) {
 extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
   const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (nbatch > 0 ? nbatch : 1);
   const int nchunks = taps * ((K + BK - 1) / BK);
-  if (tiles >= 256) return 1;
+  if (tiles >= 512) return 1;   // >= 2 workgroups per CU already
   long long s = (512 + tiles - 1) / tiles;  // aim at ~2 workgroups per CU
   const int max_by_chunks = nchunks / 4 > 0 ? nchunks / 4 : 1;  // >= 4 chunks per slice
   if (s > max_by_chunks) s = max_by_chunks;
@@ -368,7 +383,14 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   p.lda = d->ldx; p.ldb = d->Cin; p.ldc = d->ldy; p.ldr = d->ldr;
   p.tapstrideB = (long long)d->Cout * d->Cin;
   p.nb1 = 1; p.nbatch = 1;
-  return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream);
+  if (d->wfmt != 0) {   // split-bf16 weight planes [plane][tap][Cout][Kp], Kp = Cin rounded up to 8
+    OSM_REQUIRE(d->wfmt == 2 || d->wfmt == 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
+    const long long Kp = (d->Cin + 7) & ~7;
+    p.ldb = Kp;
+    p.tapstrideB = (long long)d->Cout * Kp;
+    p.planestrideB = (long long)d->ksize * d->ksize * d->Cout * Kp;
+  }
+  return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream, d->wfmt);
 }
 
 extern "C" int osm_gemm(const osm_gemm_desc* d, void* stream) {
@@ -399,4 +421,29 @@ extern "C" int osm_pack_conv_weight(const float* w, float* wf, float* wd, int Co
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wf, wd, Cout, Cin, k);
   return osm::check_launch("pack_weight_kernel");
+}
+
+extern "C" long long osm_packed_weight_elems(int Cout, int Cin, int k, int wfmt, int dgrad) {
+  if (wfmt == 0) return (long long)k * k * Cout * Cin;                         // floats
+  const int rows = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  return (long long)wfmt * k * k * rows * ((K + 7) & ~7);                      // bf16 (uint16) elements
+}
+
+extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int k,
+                                          int wfmt, void* stream) {
+  OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_bf16s: null pointer");
+  OSM_REQUIRE(k == 1 || k == 3, "osm_pack_conv_weight_bf16s: ksize must be 1 or 3");
+  OSM_REQUIRE(wfmt == 2 || wfmt == 3, "osm_pack_conv_weight_bf16s: wfmt must be 2 or 3");
+  for (int dg = 0; dg < 2; ++dg) {
+    unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
+    if (!out) continue;
+    const long long per_plane = osm_packed_weight_elems(Cout, Cin, k, wfmt, dg) / wfmt;
+    int blocks = (int)((per_plane + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_bf16s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
+                       k, wfmt, dg);
+    int rc = osm::check_launch("pack_weight_bf16s_kernel");
+    if (rc) return rc;
+  }
+  return OSM_OK;
 }

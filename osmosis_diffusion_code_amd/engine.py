@@ -32,11 +32,12 @@ G = 32  # GroupNorm32 groups (nn.py:93-100)
 
 
 class _Conv:
-    def __init__(self, slot, dev):
+    def __init__(self, slot, dev, wfmt=0):
         w = slot.weight.detach().to(dev, torch.float32)
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.k = w.shape[2] if w.dim() == 4 else 1
-        self.wf, self.wd = ops.pack_conv_weight(w)
+        self.wfmt = wfmt
+        self.wf, self.wd = ops.pack_conv_weight(w, wfmt=wfmt)
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
 
 
@@ -47,31 +48,35 @@ class _Norm:
 
 
 class _Res:
-    def __init__(self, p, dev):
+    def __init__(self, p, dev, wfmt=0):
         self.cin, self.cout, self.up, self.down = p.cin, p.cout, p.up, p.down
         self.n1 = _Norm(p.in_layers.at(0), dev)
-        self.c1 = _Conv(p.in_layers.at(2), dev)
+        self.c1 = _Conv(p.in_layers.at(2), dev, wfmt)
         e = p.emb_layers.at(1)
         self.ew = e.weight.detach().to(dev, torch.float32).contiguous()
         self.eb = e.bias.detach().to(dev, torch.float32).contiguous()
         self.n2 = _Norm(p.out_layers.at(0), dev)
-        self.c2 = _Conv(p.out_layers.at(3), dev)
-        self.skip = _Conv(p.skip_connection, dev) if p.skip_connection is not None else None
+        self.c2 = _Conv(p.out_layers.at(3), dev, wfmt)
+        self.skip = _Conv(p.skip_connection, dev, wfmt) if p.skip_connection is not None else None
         self.saved = None
 
 
 class _Attn:
-    def __init__(self, p, dev):
+    def __init__(self, p, dev, wfmt=0):
         self.ch, self.heads, self.new_order = p.ch, p.heads, p.new_order
         self.norm = _Norm(p.norm, dev)
-        self.qkv = _Conv(p.qkv, dev)
-        self.proj = _Conv(p.proj_out, dev)
+        self.qkv = _Conv(p.qkv, dev, wfmt)
+        self.proj = _Conv(p.proj_out, dev, wfmt)
         self.saved = None
 
 
 class UNetEngine:
-    def __init__(self, model, B: int, H: int, W: int, dev):
+    def __init__(self, model, B: int, H: int, W: int, dev, conv_mode: str = "f32"):
         self.B, self.H, self.W, self.dev = B, H, W, dev
+        if conv_mode not in ops.WFMT:
+            raise ValueError(f"conv_mode must be one of {sorted(ops.WFMT)}, got {conv_mode!r}")
+        self.conv_mode = conv_mode
+        wfmt = ops.WFMT[conv_mode]
         self.mc = model.model_channels
         self.ted = 4 * self.mc
         self.cin, self.cout = model.in_channels, model.out_channels
@@ -89,10 +94,10 @@ class UNetEngine:
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
             if isinstance(m, ResBlockParams):
-                return _Res(m, dev)
+                return _Res(m, dev, wfmt)
             if isinstance(m, AttentionParams):
-                return _Attn(m, dev)
-            return _Conv(m, dev)
+                return _Attn(m, dev, wfmt)
+            return _Conv(m, dev, wfmt)
 
         def seq(s):
             return [wrap(m) for _, m in sorted(((int(k), v) for k, v in s._modules.items()), key=lambda kv: kv[0])]
@@ -104,7 +109,7 @@ class UNetEngine:
         self.mid = seq(model.middle_block)
         self.outb = [seq(s) for s in model.output_blocks]
         self.out_norm = _Norm(model.out.at(0), dev)
-        self.out_conv = _Conv(model.out.at(2), dev)
+        self.out_conv = _Conv(model.out.at(2), dev, wfmt)
 
         f32 = dict(device=dev, dtype=torch.float32)
         self.x_in = torch.zeros(B, self.cin, H, W, **f32)
@@ -149,7 +154,7 @@ class UNetEngine:
         if sk > 1:
             ws = self._scr_flat("splitk", sk * M * cout)
         ops.conv2d(x, cv.wd if dgrad else cv.wf, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
-                   accumulate=accumulate, splitk=sk, splitk_ws=ws)
+                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):

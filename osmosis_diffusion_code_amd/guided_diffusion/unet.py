@@ -16,6 +16,7 @@ What is kept from the reference
 What is different: the module holds parameters only.  The computation is a recorded plan of C-ABI
 kernel calls over NHWC buffers (UNetEngine); there is no CPU / eager fallback.
 """
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -151,6 +152,9 @@ class UNetModel(nn.Module):
         self.out = _Seq({0: _Slot((ch,), (ch,), "norm"), 2: _Slot((out_channels, ch, 3, 3), (out_channels,))})
         self.reset_parameters()
         self._engines: Dict[Tuple, UNetEngine] = {}
+        # arithmetic of the conv / 1x1 contractions: "f32" exact-fp32 MFMA (parity mode), "bf16x6"
+        # (fp32 split into 3 bf16 terms, 6 MFMAs: fp32-class accuracy), "bf16x3" (2 terms, ~2^-16)
+        self.conv_mode = os.environ.get("OSM_CONV_MODE", "bf16x6")
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self, seed: int = 0):
@@ -182,11 +186,11 @@ class UNetModel(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs only on a HIP device (model.to('cuda')); "
                                "there is no CPU fallback on the product path")
-        key = (B, H, W, str(dev))
+        key = (B, H, W, str(dev), self.conv_mode)
         eng = self._engines.get(key)
         ver = self._params_version()
         if eng is None or eng.params_version != ver:
-            eng = UNetEngine(self, B, H, W, dev)
+            eng = UNetEngine(self, B, H, W, dev, conv_mode=self.conv_mode)
             eng.params_version = ver
             self._engines = {key: eng}      # one live engine: activations are large
         return eng

@@ -41,7 +41,7 @@ def _s():
 
 def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat, B: int, H: int, W: int,
            ksize: int, res: Optional[Mat] = None, accumulate: bool = False,
-           splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None):
+           splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0):
     d = ConvDesc()
     d.x, d.w, d.bias = x.p, ptr(w_packed), ptr(bias)
     d.res = res.p if res is not None else None
@@ -50,17 +50,31 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, x.cols, y.cols
     d.ksize, d.splitk, d.accumulate = ksize, splitk, int(accumulate)
     d.ldx, d.ldy, d.ldr = x.ld, y.ld, (res.ld if res is not None else 0)
+    d.wfmt = wfmt
     call("osm_conv2d_nhwc", C.byref(d), _s(), keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws))
 
 
-def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True):
-    """OIHW (or [O][I][1] conv1d / [O][I] linear) -> (fwd [k*k][O][I], dgrad [k*k][I][O])."""
+# conv arithmetic modes: weight-image format code of the C ABI
+WFMT = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True, wfmt: int = 0):
+    """OIHW (or [O][I][1] conv1d / [O][I] linear) -> (fwd image, dgrad image).
+    wfmt 0: fp32 [k*k][O][I] / [k*k][I][O];  2 / 3: split-bf16 planes (int16 tensors)."""
     w = w_oihw.contiguous()
     O, I = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() >= 3 else 1
-    wf = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_fwd else None
-    wd = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_dgrad else None
-    call("osm_pack_conv_weight", ptr(w), ptr(wf), ptr(wd), O, I, k, _s(), keep=(w, wf, wd))
+    if wfmt == 0:
+        wf = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_fwd else None
+        wd = torch.empty(k * k * O * I, device=w.device, dtype=torch.float32) if want_dgrad else None
+        call("osm_pack_conv_weight", ptr(w), ptr(wf), ptr(wd), O, I, k, _s(), keep=(w, wf, wd))
+        return wf, wd
+    lib = _lib.load()
+    nf = lib.osm_packed_weight_elems(O, I, k, wfmt, 0)
+    nd = lib.osm_packed_weight_elems(O, I, k, wfmt, 1)
+    wf = torch.empty(nf, device=w.device, dtype=torch.int16) if want_fwd else None
+    wd = torch.empty(nd, device=w.device, dtype=torch.int16) if want_dgrad else None
+    call("osm_pack_conv_weight_bf16s", ptr(w), ptr(wf), ptr(wd), O, I, k, wfmt, _s(), keep=(w, wf, wd))
     return wf, wd
 
 

@@ -250,3 +250,49 @@ def test_bad_arguments_return_errors(ops):
     with pytest.raises(OsmosisHipError, match="multiples of 4"):
         ops.conv2d(ops.Mat.of(x), torch.zeros(9 * 8 * 6, device=DEV), None,
                    ops.Mat.of(torch.zeros(16, 8, device=DEV)), 1, 4, 4, 3)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 4e-6), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,splitk", [
+    (1, 32, 64, 16, 16, 3, 1), (2, 4, 32, 8, 8, 3, 1), (1, 64, 8, 16, 16, 3, 1), (1, 96, 160, 12, 20, 3, 1),
+    (1, 256, 128, 8, 8, 3, 4), (2, 64, 64, 8, 8, 1, 1), (1, 128, 256, 32, 32, 3, 1), (1, 36, 44, 8, 8, 3, 2)])
+def test_conv_split_bf16_modes(ops, mode, tol, B, Cin, Cout, H, W, k, splitk):
+    """Split-bf16 MFMA path (fp32 = 3 bf16 terms): bf16x6 must be fp32-class, bf16x3 ~2^-16."""
+    wfmt = ops.WFMT[mode]
+    g = torch.Generator().manual_seed(B * 977 + Cin + 3 * Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    ref = (F.conv2d(x.double(), w.double(), bias.double(), padding=k // 2) + res.double()).float()
+    wf, wd = ops.pack_conv_weight(w.to(DEV), wfmt=wfmt)
+    y = torch.full((B * H * W, Cout), float("nan"), device=DEV)
+    ws = torch.empty(splitk * B * H * W * Cout, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(to_nhwc(x)), wf, bias.to(DEV), ops.Mat.of(y), B, H, W, k, res=ops.Mat.of(to_nhwc(res)),
+               splitk=splitk, splitk_ws=ws, wfmt=wfmt)
+    e = relerr(from_nhwc(y, B, H, W), ref)
+    assert e < tol, (mode, e)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    (dref,) = torch.autograd.grad(F.conv2d(xr, w.double(), None, padding=k // 2), xr, dy.double())
+    dx = torch.full((B * H * W, Cin), float("nan"), device=DEV)
+    ws2 = torch.empty(splitk * B * H * W * Cin, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(to_nhwc(dy)), wd, None, ops.Mat.of(dx), B, H, W, k, splitk=splitk, splitk_ws=ws2, wfmt=wfmt)
+    e = relerr(from_nhwc(dx, B, H, W), dref.float())
+    assert e < tol, (mode, "dgrad", e)
+
+
+def test_split_bf16_weight_planes_reconstruct_exactly(ops):
+    """3 planes reproduce the fp32 weight bit-exactly; padding to K%8 is zero."""
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(5, 12, 3, 3, generator=g)
+    wf, wd = ops.pack_conv_weight(w.to(DEV), wfmt=3)
+    Kp = 16
+    pl = wf.cpu().view(3, 9, 5, Kp).to(torch.int32)
+    f = (pl << 16).view(torch.float32) if False else torch.stack([(p.to(torch.int32) << 16).view(torch.float32) for p in pl])
+    rec = f.sum(0)            # [9][5][16]
+    assert torch.equal(rec[:, :, :12], w.permute(2, 3, 0, 1).reshape(9, 5, 12))
+    assert float(rec[:, :, 12:].abs().max()) == 0.0
+    pld = wd.cpu().view(3, 9, 12, 8)
+    recd = torch.stack([(p.to(torch.int32) << 16).view(torch.float32) for p in pld]).sum(0)
+    assert torch.equal(recd[:, :, :5], w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 12, 5))

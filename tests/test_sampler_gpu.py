@@ -67,12 +67,14 @@ def make_sampler(gd):
                                   dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
 
 
+@pytest.mark.parametrize("conv_mode", ["f32", "bf16x6"])
 @pytest.mark.parametrize("opname", list(OPERATORS))
-def test_fused_loop_matches_reference_trace(pkg, opname):
+def test_fused_loop_matches_reference_trace(pkg, opname, conv_mode):
     unet, gd, M, CM = pkg
     g = dict(np.load(os.path.join(GOLD, f"loop_{opname}.npz")))
     spec = OPERATORS[opname]
     model = make_model(unet)
+    model.conv_mode = conv_mode
     operator = M.get_operator(opname, device=DEV, batch_size=1, **spec["operator"])
     cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN,
                                       **spec["aux"])
@@ -91,7 +93,7 @@ def test_fused_loop_matches_reference_trace(pkg, opname):
             e = float((rec[key].cpu() - torch.from_numpy(g[gk][k])).abs().max())
             worst[key] = max(worst.get(key, 0.0), e)
         assert np.allclose(rec["loss"].cpu().numpy(), g["trace.loss"][k], rtol=1e-4), (k, rec["loss"], g["trace.loss"][k])
-    print(opname, "worst max-abs errors over 10 free-running steps:", worst)
+    print(opname, conv_mode, "worst max-abs errors over 10 free-running steps:", worst)
     assert worst["x_in"] < 1e-3 and worst["x0"] < 1e-3 and worst["mean"] < 1e-3
     assert worst["grad"] < 1e-3 * max(1.0, float(np.abs(g["trace.grad"]).max()))
     assert float((img.cpu() - torch.from_numpy(g["final_img"])).abs().max()) < 1e-3

@@ -37,6 +37,7 @@ def build(create_model, kw, seed=1234):
 def test_tiny_unet_vs_reference_golden(create_model):
     g = dict(np.load(os.path.join(GOLD, "tiny_unet.npz")))
     m, cfg, sd = build(create_model, TINY_KW)
+    m.conv_mode = "f32"      # exact-fp32 MFMA mode
     x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
     t = torch.from_numpy(g["t"]).to(DEV)
     y = m(x, t)
@@ -89,17 +90,37 @@ def test_full_size_unet_256_vs_oracle(create_model):
     xr = x.clone().requires_grad_(True)
     yr = U.unet_forward(sd, cfg, xr, t)
     (dxr,) = torch.autograd.grad((yr * w).sum(), xr)
-    xd = x.to(DEV).requires_grad_(True)
-    yd = m(xd, t.to(DEV))
-    (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
-    ey = float((yd.detach().cpu() - yr.detach()).abs().max())
-    ed = float((dxd.cpu() - dxr).abs().max())
-    print("full-size max-abs err: y", ey, "scale", float(yr.abs().max()), "dx", ed, "scale", float(dxr.abs().max()))
-    assert ey < 1e-4 * max(1.0, float(yr.abs().max()))
-    assert ed < 1e-4 * max(1.0, float(dxr.abs().max()))
+    for mode in ("f32", "bf16x6"):
+        m.conv_mode = mode
+        xd = x.to(DEV).requires_grad_(True)
+        yd = m(xd, t.to(DEV))
+        (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+        ey = float((yd.detach().cpu() - yr.detach()).abs().max())
+        ed = float((dxd.cpu() - dxr).abs().max())
+        print(mode, "full-size max-abs err: y", ey, "scale", float(yr.abs().max()), "dx", ed, "scale",
+              float(dxr.abs().max()))
+        assert ey < 1e-4 * max(1.0, float(yr.abs().max()))
+        assert ed < 1e-4 * max(1.0, float(dxr.abs().max()))
 
 
 def test_cpu_model_refuses_to_run(create_model):
     m = create_model(**TINY_KW)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 4, 32, 32), torch.zeros(1))
+
+
+@pytest.mark.parametrize("mode,tol_y,tol_dx", [("bf16x6", 2e-5, 2e-5), ("bf16x3", 2e-3, 2e-3)])
+def test_tiny_unet_split_bf16_modes(create_model, mode, tol_y, tol_dx):
+    """Split-bf16 conv arithmetic vs the reference golden (same vectors as the exact-f32 test)."""
+    g = dict(np.load(os.path.join(GOLD, "tiny_unet.npz")))
+    m, cfg, sd = build(create_model, TINY_KW)
+    m.conv_mode = mode
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    y = m(x, t)
+    (dx,) = torch.autograd.grad((y[:, :4] ** 2).sum(), x)
+    ey = float((y.detach().cpu() - torch.from_numpy(g["y"])).abs().max())
+    ref = torch.from_numpy(g["dx"])
+    ed = float((dx.cpu() - ref).abs().max()) / float(ref.abs().max())
+    print(mode, "tiny UNet max-abs err y", ey, "rel err dx", ed)
+    assert ey < tol_y and ed < tol_dx
