@@ -77,14 +77,17 @@ typedef struct osm_gemm_desc {
   long long lda, ldb, ldc, ldr;
   long long sA1, sB1, sC1, sA2, sB2, sC2;   /* batch strides in floats (res uses sC*)  */
 } osm_gemm_desc;
-/* Split-bf16 weight images: `wfmt` planes of bf16 [plane][tap][rows][Kp], Kp = K rounded up to 8, zero
- * padded; forward rows=Cout,K=Cin; data-gradient rows=Cin,K=Cout (taps flipped).  Sizes in uint16
+/* Split-bf16 weight images: `wfmt` planes of bf16 in MFMA-fragment order
+ * [plane][tap][k16-step s][n/32 j][lane l][8]: n = 32j + (l&31), k = 16s + 8(l>>5) + e, zero padded, an even
+ * number of k16 steps; forward n=Cout,k=Cin; data-gradient n=Cin,k=Cout (taps flipped).  Sizes in uint16
  * elements from osm_packed_weight_elems (wfmt 0 -> float elements of osm_pack_conv_weight). */
 long long osm_packed_weight_elems(int Cout, int Cin, int ksize, int wfmt, int dgrad);
 int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize,
                                int wfmt, void* stream);
 
 int osm_gemm(const osm_gemm_desc* d, void* stream);
+/* profiling aid: host copy of the s_memtime phase stamps written by an OSM_DBG=9 conv launch */
+int osm_debug_read_stamps(unsigned long long* host_out);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
 

@@ -24,6 +24,7 @@
 //   * Small-M layers (8x8..32x32) are weight-bandwidth bound: split-K over grid.y with fp32
 //     partials and a deterministic reduce.
 #include "osm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,6 +49,7 @@ struct IGemmParams {
   long long lda, ldb, ldc, ldr;
   long long tapstrideB;
   long long planestrideB;
+  int nt32, ksteps;     // split-bf16 fragment image: 32-column tiles, k16 steps per tap
   int nb1;
   long long sA1, sB1, sC1, sA2, sB2, sC2;
   int mtiles, ntiles;
@@ -324,14 +326,22 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
   if (wfmt != 0) {
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
-    if (wfmt == 3 && taps == 9)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), grid, dim3(256), 0, st, p.A, Bp, p);
+    const dim3 g2((p.mtiles * p.ntiles + 1) / 2, p.splitk, 1);   // ping-pong workgroups own two tiles
+    static const int dbg = getenv("OSM_DBG") ? atoi(getenv("OSM_DBG")) : 0;   // profiling builds only
+    if (wfmt == 3 && taps == 9 && dbg == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 9>), g2, dim3(512), 0, st, p.A, Bp, p);
+    else if (wfmt == 3 && taps == 9 && dbg == 10)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 10>), g2, dim3(512), 0, st, p.A, Bp, p);
+    else if (wfmt == 3 && taps == 9 && dbg == 11)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 11>), g2, dim3(512), 0, st, p.A, Bp, p);
+    else if (wfmt == 3 && taps == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), g2, dim3(512), 0, st, p.A, Bp, p);
     else if (wfmt == 3)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), grid, dim3(256), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), g2, dim3(512), 0, st, p.A, Bp, p);
     else if (wfmt == 2 && taps == 9)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 2>), grid, dim3(256), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 2>), g2, dim3(512), 0, st, p.A, Bp, p);
     else if (wfmt == 2)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), grid, dim3(256), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), g2, dim3(512), 0, st, p.A, Bp, p);
     else
       return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
   } else if (taps == 9) {
@@ -383,12 +393,10 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   p.lda = d->ldx; p.ldb = d->Cin; p.ldc = d->ldy; p.ldr = d->ldr;
   p.tapstrideB = (long long)d->Cout * d->Cin;
   p.nb1 = 1; p.nbatch = 1;
-  if (d->wfmt != 0) {   // split-bf16 weight planes [plane][tap][Cout][Kp], Kp = Cin rounded up to 8
+  if (d->wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
     OSM_REQUIRE(d->wfmt == 2 || d->wfmt == 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
-    const long long Kp = (d->Cin + 7) & ~7;
-    p.ldb = Kp;
-    p.tapstrideB = (long long)d->Cout * Kp;
-    p.planestrideB = (long long)d->ksize * d->ksize * d->Cout * Kp;
+    p.nt32 = (d->Cout + 31) / 32;
+    p.ksteps = 2 * ((d->Cin + 31) / 32);
   }
   return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream, d->wfmt);
 }
@@ -425,8 +433,8 @@ extern "C" int osm_pack_conv_weight(const float* w, float* wf, float* wd, int Co
 
 extern "C" long long osm_packed_weight_elems(int Cout, int Cin, int k, int wfmt, int dgrad) {
   if (wfmt == 0) return (long long)k * k * Cout * Cin;                         // floats
-  const int rows = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-  return (long long)wfmt * k * k * rows * ((K + 7) & ~7);                      // bf16 (uint16) elements
+  const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  return (long long)wfmt * k * k * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // bf16 (uint16) elements
 }
 
 extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int k,
@@ -446,4 +454,11 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
     if (rc) return rc;
   }
   return OSM_OK;
+}
+
+// profiling aid: copy the phase timeline recorded by an OSM_DBG=9 launch (8 waves x 32 chunks x 4 stamps)
+extern "C" int osm_debug_read_stamps(unsigned long long* host_out) {
+  hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 8 * 32 * 4);
+  return e == hipSuccess ? OSM_OK : osm::fail(OSM_ERR_LAUNCH, "osm_debug_read_stamps: %s", hipGetErrorString(e));
 }

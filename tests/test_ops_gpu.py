@@ -283,16 +283,25 @@ def test_conv_split_bf16_modes(ops, mode, tol, B, Cin, Cout, H, W, k, splitk):
 
 
 def test_split_bf16_weight_planes_reconstruct_exactly(ops):
-    """3 planes reproduce the fp32 weight bit-exactly; padding to K%8 is zero."""
+    """3 planes reproduce the fp32 weight bit-exactly in MFMA-fragment order
+    [plane][tap][k16-step][n/32][lane][8]; padding is zero."""
     g = torch.Generator().manual_seed(1)
-    w = torch.randn(5, 12, 3, 3, generator=g)
+    Cout, Cin = 5, 12
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
     wf, wd = ops.pack_conv_weight(w.to(DEV), wfmt=3)
-    Kp = 16
-    pl = wf.cpu().view(3, 9, 5, Kp).to(torch.int32)
-    f = (pl << 16).view(torch.float32) if False else torch.stack([(p.to(torch.int32) << 16).view(torch.float32) for p in pl])
-    rec = f.sum(0)            # [9][5][16]
-    assert torch.equal(rec[:, :, :12], w.permute(2, 3, 0, 1).reshape(9, 5, 12))
-    assert float(rec[:, :, 12:].abs().max()) == 0.0
-    pld = wd.cpu().view(3, 9, 12, 8)
-    recd = torch.stack([(p.to(torch.int32) << 16).view(torch.float32) for p in pld]).sum(0)
-    assert torch.equal(recd[:, :, :5], w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 12, 5))
+
+    def unpack(img, N, K):
+        nt32, ks = (N + 31) // 32, 2 * ((K + 31) // 32)
+        pl = img.cpu().view(3, 9, ks, nt32, 64, 8).to(torch.int32)
+        f = ((pl << 16).view(torch.float32)).sum(0)                  # [9][ks][nt32][64][8]
+        full = torch.zeros(9, nt32 * 32, ks * 16)
+        for l in range(64):
+            for e in range(8):
+                full[:, (l & 31)::32, (8 * (l >> 5) + e)::16] = f[:, :, :, l, e].permute(0, 2, 1)
+        return full
+
+    rec = unpack(wf, Cout, Cin)
+    assert torch.equal(rec[:, :Cout, :Cin], w.permute(2, 3, 0, 1).reshape(9, Cout, Cin))
+    assert float(rec[:, Cout:].abs().max()) == 0.0 and float(rec[:, :, Cin:].abs().max()) == 0.0
+    recd = unpack(wd, Cin, Cout)
+    assert torch.equal(recd[:, :Cin, :Cout], w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Cin, Cout))
