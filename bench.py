@@ -131,7 +131,11 @@ def roofline(model, args):
             d = a[0]._obj
             return ("attn_gemm", 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2, None)
         if name.startswith("osm_gn"):
-            return ("groupnorm", 0.0, None)
+            i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 8}[name]
+            shape = (name, int(a[i0]), int(a[i0 + 1]), int(a[i0 + 2]))
+            passes = {"osm_gn_stats": 1, "osm_gn_apply": 2, "osm_gn_bwd": 5 if a[6] else 4}[name]
+            per_shape.setdefault(shape, [0.0, 0, 4.0 * shape[1] * shape[2] * shape[3] * passes])
+            return ("groupnorm", 0.0, shape)
         return ("other", 0.0, None)
 
     agg = {}
@@ -151,7 +155,7 @@ def roofline(model, args):
            for k, v in agg.items()}
     if args.dump_layers:
         rows = [{"B,H,W,Cin,Cout,k,splitk": list(k), "launches_per_step": v[1] // reps, "ms_per_launch": v[0] / v[1],
-                 "tflops": v[2] / (v[0] / v[1]) / 1e9} for k, v in per_shape.items()]
+                 "tflops": v[2] / (v[0] / v[1]) / 1e9} for k, v in per_shape.items()]   # GN rows: "tflops" = TB/s
         rows.sort(key=lambda r: -r["ms_per_launch"] * r["launches_per_step"])
         with open(args.dump_layers, "w") as f:
             json.dump(rows, f, indent=0)

@@ -459,6 +459,6 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
 // profiling aid: copy the phase timeline recorded by an OSM_DBG=9 launch (8 waves x 32 chunks x 4 stamps)
 extern "C" int osm_debug_read_stamps(unsigned long long* host_out) {
   hipDeviceSynchronize();
-  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 8 * 32 * 4);
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 8 * 32 * 8);
   return e == hipSuccess ? OSM_OK : osm::fail(OSM_ERR_LAUNCH, "osm_debug_read_stamps: %s", hipGetErrorString(e));
 }

@@ -59,10 +59,10 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 // timeline probe (profiling builds only, OSM_DBG=9): s_memtime at the phase boundaries of workgroup 0
-__device__ unsigned long long g_dbg_stamps[8 * 32 * 4];
+__device__ unsigned long long g_dbg_stamps[8 * 32 * 8];
 #define OSM_STAMP(slot_)                                                                             \
   if (DBG >= 9 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (it_s) < 32)     \
-    g_dbg_stamps[((threadIdx.x >> 6) * 32 + (it_s)) * 4 + (slot_)] = __builtin_amdgcn_s_memtime();
+    g_dbg_stamps[((threadIdx.x >> 6) * 32 + (it_s)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime();
 
 template <int TAPS, int NP, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __restrict__ Aglob,
@@ -214,15 +214,19 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __rest
     bf16x8_t fx[2][NP], fy[2][NP];                                                                   \
     OSM_S_READ(fx, 0, 0)                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                               \
+    OSM_STAMP(4)                                                                                     \
     OSM_S_READ(fy, 0, 1)                                                                             \
     OSM_S_MMA(fx, bc_, 0, 0)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
+    OSM_STAMP(5)                                                                                     \
     OSM_S_READ(fx, 1, 0)                                                                             \
     OSM_S_MMA(fy, bc_, 0, 1)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
+    OSM_STAMP(6)                                                                                     \
     OSM_S_READ(fy, 1, 1)                                                                             \
     OSM_S_MMA(fx, bc_, 1, 0)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
+    OSM_STAMP(7)                                                                                     \
     OSM_S_MMA(fy, bc_, 1, 1)                                                                         \
     OSM_STAMP(3)                                                                                     \
     __syncthreads();                                                                                 \

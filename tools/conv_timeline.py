@@ -20,13 +20,14 @@ y = torch.empty(B * H * W, Cout, device=dev)
 wf, _ = ops.pack_conv_weight(w, wfmt=3)
 for _ in range(3):
     ops.conv2d(ops.Mat.of(x), wf, None, ops.Mat.of(y), B, H, W, k, wfmt=3)
-buf = (C.c_ulonglong * (8 * 32 * 4))()
+buf = (C.c_ulonglong * (8 * 32 * 8))()
 assert _lib.load().osm_debug_read_stamps(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(8, 32, 4).astype(np.int64)
+t = np.frombuffer(buf, dtype=np.uint64).reshape(8, 32, 8).astype(np.int64)
 t0 = t[:, 0, 0].min()
 for wv in (0, 4):
     print(f"wave {wv} (group {wv // 4}):  chunk: start  store  bar1  mfma  bar2   [cycles]")
     for c in range(4, 14):
         s = t[wv, c]
         nxt = t[wv, c + 1, 0]
-        print(f"   {c:2d}: {s[0]-t0:8d}  {s[1]-s[0]:6d} {s[2]-s[1]:6d} {s[3]-s[2]:6d} {nxt-s[3]:6d}   total {nxt-s[0]}")
+        print(f"   {c:2d}: {s[0]-t0:8d}  {s[1]-s[0]:6d} {s[2]-s[1]:6d} {s[3]-s[2]:6d} {nxt-s[3]:6d}   total {nxt-s[0]}"
+              f"   | mfma quarters: first-reads {s[4]-s[2]:5d}  q0 {s[5]-s[4]:5d}  q1 {s[6]-s[5]:5d}  q2 {s[7]-s[6]:5d}  q3 {s[3]-s[7]:5d}")
