@@ -78,7 +78,10 @@ def run_gpu(args, rank, world, dev):
     if args.tiny:
         kw.update(num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
                   num_head_channels=16)
-    model = unet.create_model(**kw)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):     # create_model prints its "no checkpoint" notice
+        model = unet.create_model(**kw)
     seeded_weights(model)
     model = model.to(dev).eval()
     model.conv_mode = args.conv_mode
@@ -173,8 +176,9 @@ def roofline(model, args):
                     traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except Exception:
             pass
-    alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1] for k, v in per_shape.items()
-                    if k[5] == 3) / max(1, sum(v[1] for k, v in per_shape.items() if k[5] == 3))
+    convs3 = {k: v for k, v in per_shape.items() if len(k) == 7 and k[5] == 3}
+    alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
+                    for k, v in convs3.items()) / max(1, sum(v[1] for v in convs3.values()))
     kname, peak, note = {
         "f32": ("igemm_f32_kernel<9,false>", FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
         "bf16x6": ("igemm_bf16s_kernel<9,3>", BF16_MFMA_PEAK_TFLOPS / 6.0,

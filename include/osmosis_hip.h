@@ -86,8 +86,6 @@ int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, 
                                int wfmt, void* stream);
 
 int osm_gemm(const osm_gemm_desc* d, void* stream);
-/* profiling aid: host copy of the s_memtime phase stamps written by an OSM_DBG=9 conv launch */
-int osm_debug_read_stamps(unsigned long long* host_out);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
 

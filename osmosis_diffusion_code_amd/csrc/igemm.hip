@@ -326,22 +326,15 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
   if (wfmt != 0) {
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
-    const dim3 g2((p.mtiles * p.ntiles + 1) / 2, p.splitk, 1);   // ping-pong workgroups own two tiles
-    static const int dbg = getenv("OSM_DBG") ? atoi(getenv("OSM_DBG")) : 0;   // profiling builds only
-    if (wfmt == 3 && taps == 9 && dbg == 9)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 9>), g2, dim3(512), 0, st, p.A, Bp, p);
-    else if (wfmt == 3 && taps == 9 && dbg == 10)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 10>), g2, dim3(512), 0, st, p.A, Bp, p);
-    else if (wfmt == 3 && taps == 9 && dbg == 11)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3, 11>), g2, dim3(512), 0, st, p.A, Bp, p);
-    else if (wfmt == 3 && taps == 9)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), g2, dim3(512), 0, st, p.A, Bp, p);
+    const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
+    if (wfmt == 3 && taps == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 3)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), g2, dim3(512), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 2 && taps == 9)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 2>), g2, dim3(512), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 2>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 2)
-      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), g2, dim3(512), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), g2, dim3(256), 0, st, p.A, Bp, p);
     else
       return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
   } else if (taps == 9) {
@@ -456,9 +449,3 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
   return OSM_OK;
 }
 
-// profiling aid: copy the phase timeline recorded by an OSM_DBG=9 launch (8 waves x 32 chunks x 4 stamps)
-extern "C" int osm_debug_read_stamps(unsigned long long* host_out) {
-  hipDeviceSynchronize();
-  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 8 * 32 * 8);
-  return e == hipSuccess ? OSM_OK : osm::fail(OSM_ERR_LAUNCH, "osm_debug_read_stamps: %s", hipGetErrorString(e));
-}

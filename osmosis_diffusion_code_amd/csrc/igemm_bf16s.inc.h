@@ -20,9 +20,12 @@
 //       rows 80 B apart so ds_read_b128 fragment reads are conflict-free.
 //   Waves are 1(M) x 4(N): each wave owns 128 rows x 32 columns (4 MFMA tiles), so every staged A byte is
 //       reused by all four waves and no B byte is fetched twice inside a workgroup.
-//   PING-PONG workgroup: 8 waves = two 4-wave groups, each owning one 128x128 output tile and its own A
-//       stage.  Both run the same two-phase loop (split+store | MFMA) shifted by ONE barrier, so in every
-//       barrier interval one group feeds the matrix pipe while the other stages.
+//   SOFTWARE-PIPELINED single loop: every wave interleaves the MFMAs of chunk k (fragments from LDS buffer
+//       k&1) with the split + LDS store of chunk k+1 (into buffer (k+1)&1) and the global prefetches of
+//       chunks k+2 / k+3, one barrier per chunk.  (Measured with s_memtime stamps: separate store / MFMA
+//       phases -- whether in lockstep or ping-ponged between two wave groups -- serialise on the in-order
+//       waves: 48 % MFMA busy.  An MFMA leaves ~5 issue slots per 32-cycle gap; the ~140 VALU + 40 memory
+//       instructions of the staging work fit in the 48 gaps of a chunk.)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -58,33 +61,23 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
 
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-// timeline probe (profiling builds only, OSM_DBG=9): s_memtime at the phase boundaries of workgroup 0
-__device__ unsigned long long g_dbg_stamps[8 * 32 * 8];
-#define OSM_STAMP(slot_)                                                                             \
-  if (DBG >= 9 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (it_s) < 32)     \
-    g_dbg_stamps[((threadIdx.x >> 6) * 32 + (it_s)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime();
-
 template <int TAPS, int NP, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __restrict__ Aglob,
+__global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Bglob,
                                                               IGemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * S_PLANE];
-  const int grp = threadIdx.x >> 8;
-  unsigned char* As = smem + grp * (NP * S_PLANE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * S_PLANE];   // two A stages
+  unsigned char* As = smem;
 
-  const int tid = threadIdx.x & 255;
+  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
   const int nt = p.mtiles * p.ntiles;
-  const int npair = (nt + 1) >> 1;
   const int bid = blockIdx.x;
-  const int q = npair >> 3, r = npair & 7, xcd = bid & 7, idx = bid >> 3;
-  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int id = 2 * pid + grp;
-  const bool tile_ok = id < nt;          // odd tile count: the last group only keeps the barriers company
+  const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
-  const int m0 = tile_ok ? tile_m * BM : p.M, n0 = tile_ok ? tile_n * BN : p.N;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const float* __restrict__ A = Aglob;
   const unsigned short* __restrict__ Bm = Bglob;
 
@@ -93,14 +86,19 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __rest
   const int kc0 = ks * per;
   const int kc1 = min(p.nchunks, kc0 + per);
 
-  // ---- A staging coordinates: float4 column group cg of rows r0 + 32 i
+  // ---- A staging coordinates: float4 column group cg of rows r0 + 32 i.
+  // Addressing is "uniform 64-bit base (SGPR) + per-lane 32-bit byte offset": the base points (W+1) pixels
+  // before the tile so that every tap offset is non-negative; per chunk only ONE scalar delta changes.
+  // Masked lanes (halo / ragged edge / channel tail) read their own centre pixel (always valid memory)
+  // and are zeroed after the load -- ~9 VALU per load instead of ~30 of 64-bit pointer arithmetic.
   const int cg = tid & 7, r0 = tid >> 3;
-  long long arow[4];
-  unsigned amask[4];
+  const long long rowB = (long long)p.lda * 4;                         // bytes per pixel row
+  const long long biasB = (TAPS == 9) ? (long long)(p.W + 1) * rowB : 0;
+  const char* __restrict__ sbaseA = reinterpret_cast<const char*>(A) + (long long)m0 * rowB - biasB;
+  unsigned vcen[4], vsafe[4], amask[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + r0 + 32 * i;
-    arow[i] = (long long)m * p.lda;
     unsigned mk = 0;
     if (m < p.M) {
       if (TAPS == 9) {
@@ -116,63 +114,66 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __rest
       }
     }
     amask[i] = mk;
+    vsafe[i] = (unsigned)(biasB + (m < p.M ? (long long)(r0 + 32 * i) * rowB : 0));
+    vcen[i] = vsafe[i] + 16u * cg;
   }
-  // byte offsets from the operand bases to the zero page (global memory is one flat 64-bit space)
-  const long long zoffA = reinterpret_cast<const char*>(g_zero_page) - reinterpret_cast<const char*>(A);
-  const long long zoffB = reinterpret_cast<const char*>(g_zero_page) - reinterpret_cast<const char*>(Bm);
 
-  // ---- B fragment addressing: image [plane][tap][k16-step][n/32][lane][8]
-  const int jn = (n0 >> 5) + wave;                 // this wave's 32-column tile
+  // ---- B fragment addressing: image [plane][tap][k16-step][n/32][lane][8]; wave-uniform base + lane offset
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int jn = (n0 >> 5) + wave_u;               // this wave's 32-column tile
   const bool b_ok = jn < p.nt32;
-  const long long b_lane = ((long long)jn * 64 + lane) * 16;          // bytes inside one (plane, tap, step) slab
+  const unsigned b_lane = b_ok ? (unsigned)((jn * 64 + lane) * 16) : (unsigned)(lane & 1) * 16u;
   const long long b_step = (long long)p.nt32 * 64 * 16;               // bytes per k16-step
   const long long b_tap = b_step * p.ksteps;                          // bytes per tap
   const long long b_plane = b_tap * TAPS;                             // bytes per plane
+  const char* __restrict__ sbaseB0 = b_ok ? reinterpret_cast<const char*>(Bm) : reinterpret_cast<const char*>(g_zero_page);
 
-  // Two register sets for each operand: global loads are issued >= one full chunk (~3000 cycles)
-  // before they are consumed.  (Measured: with a half-chunk distance the ~1500-cycle loaded latency
-  // sat on the critical path twice per chunk -- the no-MFMA ablation still ran at 52 % of the time.)
+  // Two register sets per operand: every global load is issued >= one full chunk before it is consumed,
+  // and every prefetch is UNCONDITIONAL (tail chunks re-load the last chunk) so that the compiler's
+  // vmcnt bookkeeping is static -- with conditional loads it has to assume the shortest path and ends
+  // up waiting for the newest loads inside the MFMA stream.
   float4 raE[4], raO[4];
+  unsigned okE = 0, okO = 0;                  // validity bits of the staged A registers
   uint4 bE00, bE01, bE02, bE10, bE11, bE12;   // [k16-step][plane] B fragments, even chunks
   uint4 bO00, bO01, bO02, bO10, bO11, bO12;   // odd chunks
   bE02 = bE12 = bO02 = bO12 = make_uint4(0u, 0u, 0u, 0u);
 
-#define OSM_S_LOAD_A(ra_, kc_)                                                                       \
+#define OSM_S_LOAD_A(ra_, ok_, kc_)                                                                  \
   {                                                                                                  \
     const int cc_ = (kc_) / TAPS;                                                                    \
     const int tap_ = (kc_) - cc_ * TAPS;                                                             \
-    long long toff_ = 0;                                                                             \
-    if (TAPS == 9) toff_ = ((long long)(tap_ / 3 - 1) * p.W + (tap_ % 3 - 1)) * p.lda;               \
-    const int c_ = cc_ * BK + 4 * cg;                                                                \
-    const bool cok_ = c_ < p.K;                                                                      \
+    int sdelta_ = cc_ * (BK * 4);                                                                    \
+    if (TAPS == 9) sdelta_ += (int)(((tap_ / 3 - 1) * p.W + (tap_ % 3 - 1)) * rowB);                 \
+    const bool cok_ = cc_ * BK + 4 * cg < p.K;                                                       \
+    ok_ = 0;                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      const bool ok_ = cok_ && ((amask[i] >> tap_) & 1u);                                            \
-      const long long o_ = ok_ ? (arow[i] + toff_ + c_) * 4 : zoffA;                                 \
-      ra_[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A) + o_);              \
+      const bool o_ = cok_ && ((amask[i] >> tap_) & 1u);                                             \
+      ok_ |= (o_ ? 1u : 0u) << i;                                                                    \
+      const unsigned vo_ = o_ ? vcen[i] + (unsigned)sdelta_ : vsafe[i];                              \
+      ra_[i] = *reinterpret_cast<const float4*>(sbaseA + vo_);                                       \
     }                                                                                                \
   }
 #define OSM_S_LOAD_B(b_, kc_)                                                                        \
   {                                                                                                  \
     const int cc_ = (kc_) / TAPS;                                                                    \
     const int tap_ = (kc_) - cc_ * TAPS;                                                             \
-    const long long o_ = b_ok ? tap_ * b_tap + (2 * cc_) * b_step + b_lane : zoffB;                  \
+    const char* sb_ = sbaseB0 + (b_ok ? tap_ * b_tap + (2 * cc_) * b_step : 0);                      \
     const long long st_ = b_ok ? b_step : 0;                                                         \
     const long long pl_ = b_ok ? b_plane : 0;                                                        \
-    const char* bp_ = reinterpret_cast<const char*>(Bm) + o_;                                        \
-    b_##00 = *reinterpret_cast<const uint4*>(bp_);                                                   \
-    b_##10 = *reinterpret_cast<const uint4*>(bp_ + st_);                                             \
-    b_##01 = *reinterpret_cast<const uint4*>(bp_ + pl_);                                             \
-    b_##11 = *reinterpret_cast<const uint4*>(bp_ + pl_ + st_);                                       \
+    b_##00 = *reinterpret_cast<const uint4*>(sb_ + b_lane);                                          \
+    b_##10 = *reinterpret_cast<const uint4*>(sb_ + st_ + b_lane);                                    \
+    b_##01 = *reinterpret_cast<const uint4*>(sb_ + pl_ + b_lane);                                    \
+    b_##11 = *reinterpret_cast<const uint4*>(sb_ + pl_ + st_ + b_lane);                              \
     if (NP == 3) {                                                                                   \
-      b_##02 = *reinterpret_cast<const uint4*>(bp_ + 2 * pl_);                                       \
-      b_##12 = *reinterpret_cast<const uint4*>(bp_ + 2 * pl_ + st_);                                 \
+      b_##02 = *reinterpret_cast<const uint4*>(sb_ + 2 * pl_ + b_lane);                              \
+      b_##12 = *reinterpret_cast<const uint4*>(sb_ + 2 * pl_ + st_ + b_lane);                        \
     }                                                                                                \
   }
-#define OSM_S_READ(f_, st_, half_)                                                                   \
+// fragment reads of one quarter (2 tiles x NP planes) from A stage `buf_`
+#define OSM_S_READ(f_, buf_, st_, half_)                                                             \
   _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                      \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                                \
-      if (DBG == 10) f_[t][q2] = as_frag(make_uint4(t, q2, st_, half_));                             \
-      else f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + q2 * S_PLANE +                      \
+      f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + (buf_) * (NP * S_PLANE) + q2 * S_PLANE + \
                                                      (64 * (half_) + 32 * t) * S_ROWB + 32 * (st_));
 #define OSM_S_MMA(f_, b_, st_, half_)                                                                \
   {                                                                                                  \
@@ -188,47 +189,39 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __rest
             __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[1][pa], bf[pb], acc[2 * (half_) + 1], 0, 0, 0); \
       }                                                                                              \
   }
-// one chunk: phase 1 = prefetch next B set, split + store this chunk's A registers;
-//            phase 2 = refill this A register set two chunks ahead, 2 k16-steps x 4 tiles x (6|3) MFMAs
-#define OSM_S_CHUNK(ra_, bc_, bn_, it_)                                                              \
+// split one staged float4 (rows r0 + 32 i) into NP planes of A stage `buf_`
+#define OSM_S_SPLIT(ra_, ok_, i_, buf_)                                                              \
   {                                                                                                  \
-    const int it_s = (it_);                                                                          \
-    OSM_STAMP(0)                                                                                     \
-    /* prefetches are UNCONDITIONAL (tail chunks re-load the last chunk): with conditional loads the   \
-       compiler's vmcnt bookkeeping must assume the shortest path and waits for the newest loads */   \
-    OSM_S_LOAD_B(bn_, min(kc0 + (it_) + 1, kc1 - 1));                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      uint2 pl[NP];                                                                                  \
-      if (DBG == 11) { asm volatile("" ::"v"(ra_[i].x), "v"(ra_[i].y), "v"(ra_[i].z), "v"(ra_[i].w)); continue; } \
-      split_planes<NP>(ra_[i], pl);                                                                  \
-      _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                              \
-        *reinterpret_cast<uint2*>(As + q2 * S_PLANE + (r0 + 32 * i) * S_ROWB + 8 * cg) = pl[q2];     \
-    }                                                                                                \
-    OSM_STAMP(1)                                                                                     \
-    __syncthreads();                                                                                 \
-    OSM_STAMP(2)                                                                                     \
-    OSM_S_LOAD_A(ra_, min(kc0 + (it_) + 2, kc1 - 1));                                          \
-    /* software-pipelined fragment reads: the 6 ds_read_b128 of quarter q+1 are issued BEFORE the 12   \
-       MFMAs of quarter q (the compiler otherwise sinks every read next to its first use and exposes   \
-       the LDS latency ~12 times per chunk: measured 2450 cycles for 1536 cycles of MFMA) */           \
+    uint2 pl[NP];                                                                                    \
+    split_planes<NP>(sel4(((ok_) >> (i_)) & 1u, ra_[i_]), pl);                                                                   \
+    _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                                \
+      *reinterpret_cast<uint2*>(As + (buf_) * (NP * S_PLANE) + q2 * S_PLANE + (r0 + 32 * (i_)) * S_ROWB + \
+                                8 * cg) = pl[q2];                                                    \
+  }
+// one chunk `it_`: MFMAs on stage it&1 with B set bc_, interleaved with the split of A(it+1) (register set
+// ra_) into stage (it+1)&1; prefetch B(it+1) -> bn_ and, once ra_ is consumed, A(it+3) -> ra_.
+#define OSM_S_CHUNK(ra_, ok_, bc_, bn_, it_)                                                              \
+  {                                                                                                  \
+    const int rb_ = (it_) & 1, wb_ = rb_ ^ 1;                                                        \
     bf16x8_t fx[2][NP], fy[2][NP];                                                                   \
-    OSM_S_READ(fx, 0, 0)                                                                             \
+    OSM_S_LOAD_B(bn_, min(kc0 + (it_) + 1, kc1 - 1));                                                \
+    OSM_S_READ(fx, rb_, 0, 0)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    OSM_STAMP(4)                                                                                     \
-    OSM_S_READ(fy, 0, 1)                                                                             \
+    OSM_S_READ(fy, rb_, 0, 1)                                                                        \
     OSM_S_MMA(fx, bc_, 0, 0)                                                                         \
+    OSM_S_SPLIT(ra_, ok_, 0, wb_)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    OSM_STAMP(5)                                                                                     \
-    OSM_S_READ(fx, 1, 0)                                                                             \
+    OSM_S_READ(fx, rb_, 1, 0)                                                                        \
     OSM_S_MMA(fy, bc_, 0, 1)                                                                         \
+    OSM_S_SPLIT(ra_, ok_, 1, wb_)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    OSM_STAMP(6)                                                                                     \
-    OSM_S_READ(fy, 1, 1)                                                                             \
+    OSM_S_READ(fy, rb_, 1, 1)                                                                        \
     OSM_S_MMA(fx, bc_, 1, 0)                                                                         \
+    OSM_S_SPLIT(ra_, ok_, 2, wb_)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    OSM_STAMP(7)                                                                                     \
     OSM_S_MMA(fy, bc_, 1, 1)                                                                         \
-    OSM_STAMP(3)                                                                                     \
+    OSM_S_SPLIT(ra_, ok_, 3, wb_)                                                                         \
+    OSM_S_LOAD_A(ra_, ok_, min(kc0 + (it_) + 3, kc1 - 1));                                                \
     __syncthreads();                                                                                 \
   }
 
@@ -243,22 +236,25 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16s_kernel(const float* __rest
 
   const int nk = kc1 - kc0;
   if (nk > 0) {
-    OSM_S_LOAD_A(raE, kc0);
+    OSM_S_LOAD_A(raE, okE, kc0);
     OSM_S_LOAD_B(bE, kc0);
-    OSM_S_LOAD_A(raO, min(kc0 + 1, kc1 - 1));
+    OSM_S_LOAD_A(raO, okO, min(kc0 + 1, kc1 - 1));
+    // stage chunk 0 (not overlapped), then refill its register set two chunks ahead
+#pragma unroll
+    for (int i = 0; i < 4; ++i) OSM_S_SPLIT(raE, okE, i, 0)
+    OSM_S_LOAD_A(raE, okE, min(kc0 + 2, kc1 - 1));
+    __syncthreads();
+    for (int it = 0; it < nk; it += 2) {
+      OSM_S_CHUNK(raO, okO, bE, bO, it);
+      if (it + 1 < nk) OSM_S_CHUNK(raE, okE, bO, bE, it + 1);
+    }
   }
-  if (grp == 1) __syncthreads();   // phase shift of group 1 (group 0 pays the matching barrier after the loop)
-  for (int it = 0; it < nk; it += 2) {
-    OSM_S_CHUNK(raE, bE, bO, it);
-    if (it + 1 < nk) OSM_S_CHUNK(raO, bO, bE, it + 1);
-  }
-  if (grp == 0) __syncthreads();
 #undef OSM_S_LOAD_A
 #undef OSM_S_LOAD_B
 #undef OSM_S_CHUNK
 #undef OSM_S_READ
 #undef OSM_S_MMA
-  if (!tile_ok) return;
+#undef OSM_S_SPLIT
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool partial = p.splitk > 1;
