@@ -171,8 +171,8 @@ def roofline(model, args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
             for k in json.load(open(path))["kernels"]:
-                if k["kernel"].replace(" ", "") == {"f32": "igemm_f32_kernel<9,false>", "bf16x6": "igemm_bf16s_kernel<9,3>",
-                                                    "bf16x3": "igemm_bf16s_kernel<9,2>"}[args.conv_mode]:
+                if k["kernel"].replace(" ", "").startswith({"f32": "igemm_f32_kernel<9,false", "bf16x6": "igemm_bf16s_kernel<9,3",
+                                                            "bf16x3": "igemm_bf16s_kernel<9,2"}[args.conv_mode]):
                     traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except Exception:
             pass
