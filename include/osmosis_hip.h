@@ -177,6 +177,11 @@ int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, in
 int osm_guide_update(const float* mean, const float* logvar, const float* g, const float* dx_unet,
                      const float* noise, const float* coef, const float* scale4, float clip,
                      float* x_next, float* grad_out, int B, int HW, void* stream);
+/* unconditional ancestral step of the RGBD prior sampler (osmosis_utils/diffusion.py:94-122), NCHW:
+ *   eps = model_out[:, :C]; x_next = c_a (x - c_b eps) + c_s z; x0 = c_r x - c_m eps (x0, z optional)
+ * coef: device float[8] = {c_a, c_b, c_s, c_r, c_m, -, -, t} */
+int osm_ancestral_step(const float* model_out, const float* x, const float* z, const float* coef,
+                       float* x_next, float* x0, int B, int C, int Cout, int HW, void* stream);
 /* coef_out[8] = table[*step][8]; t_out[b] = coef_out[7]; then *step += delta (graph-replayable) */
 int osm_fetch_coefs(const float* table, int* step, int delta, float* coef_out, float* t_out, int B,
                     void* stream);

@@ -257,11 +257,54 @@ def gen_loops():
         print(opname, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
 
 
+def gen_prior():
+    """Unconditional RGBD-prior sampler (osmosis_utils/diffusion.py:59-130): last 6 steps of the
+    1000-step chain (t = 6..1) on the tiny seeded UNet.  The reference only defines its return values
+    when it records, so recording is on with the two visualisation sinks replaced by no-ops."""
+    import tempfile
+    from osmosis_utils import diffusion as R_diff
+    m, cfg, sd = tiny_model()
+    R_diff.make_grid = lambda *a, **k: torch.zeros(3, 4, 4)
+
+    class _Img:
+        def save(self, *a, **k):
+            pass
+    R_diff.tvtf.to_pil_image = lambda *a, **k: _Img()
+    diff = R_diff.GaussianDiffusion(T=1000, schedule="linear")
+    x_T = 0.3 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(3))
+    draws, xs = [], []
+    orig = torch.randn_like
+
+    def logged(t, **kw):
+        r = orig(t, **kw)
+        draws.append(r.clone())
+        return r
+
+    def net(x, t):
+        xs.append(x.detach().clone())
+        return m(x, t)
+
+    torch.manual_seed(0)
+    torch.randn_like = logged
+    try:
+        x, (rgb, depth_color) = diff.inverse(net=net, shape=(4, 32, 32), image_channels=4, steps=6, x=x_T.clone(),
+                                             start_t=6, device="cpu", record_process=True, record_every=1000,
+                                             save_path=tempfile.mkdtemp(), image_idx=0)
+    finally:
+        torch.randn_like = orig
+    assert len(draws) == 5 and len(xs) == 6
+    np.savez_compressed(os.path.join(OUT, "prior_inverse.npz"), x_T=npy(x_T), noise=np.stack([npy(d) for d in draws]),
+                        x_steps=np.stack([npy(v) for v in xs]), x_final=npy(x), x_start_rgb=npy(rgb),
+                        beta=diff.beta, alphabar=diff.alphabar,
+                        cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_schedules()
     gen_blocks()
     gen_tiny_unet()
     gen_loops()
+    gen_prior()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

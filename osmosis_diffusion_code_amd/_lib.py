@@ -82,6 +82,7 @@ _SIGS = {
     "osm_posterior_bwd": [_P, _P, _P, _I, _I, _P],
     "osm_guide_update": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     "osm_fetch_coefs": [_P, _P, _I, _P, _P, _I, _P],
+    "osm_ancestral_step": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "osm_version": [],
 }
 EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems"])

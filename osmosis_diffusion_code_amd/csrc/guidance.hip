@@ -245,6 +245,30 @@ __global__ __launch_bounds__(256) void guide_update_kernel(const float* __restri
   }
 }
 
+// unconditional ancestral step of the RGBD prior sampler (reference osmosis_utils/diffusion.py:94-122):
+//   eps = model_out[:, :C] ; x_next = c_a (x - c_b eps) + c_s z ; x0 = c_r x - c_m eps
+// coef = {c_a, c_b, c_s, c_r, c_m, -, -, t}
+__global__ __launch_bounds__(256) void ancestral_step_kernel(const float* __restrict__ mo,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ coef,
+                                                              float* __restrict__ x_next, float* __restrict__ x0,
+                                                              int B, int C, int Cout, int HW) {
+  const long long total = (long long)B * C * HW;
+  const float ca = coef[0], cb = coef[1], cs = coef[2], cr = coef[3], cm = coef[4];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / ((long long)C * HW);
+    const long long rem = i - b * (long long)C * HW;
+    const float eps = mo[b * (long long)Cout * HW + rem];
+    const float xv = x[i];
+    if (x0) x0[i] = cr * xv - cm * eps;
+    float v = ca * (xv - cb * eps);
+    if (z) v += cs * z[i];
+    x_next[i] = v;
+  }
+}
+
 __global__ void fetch_coefs_kernel(const float* __restrict__ table, int* __restrict__ step, int delta,
                                    float* __restrict__ coef_out, float* __restrict__ t_out, int B) {
   const int s = *step;
@@ -336,4 +360,12 @@ extern "C" int osm_fetch_coefs(const float* table, int* step, int delta, float* 
   hipLaunchKernelGGL(fetch_coefs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, step, delta, coef_out,
                      t_out, B);
   return osm::check_launch("fetch_coefs_kernel");
+}
+
+extern "C" int osm_ancestral_step(const float* model_out, const float* x, const float* z, const float* coef,
+                                  float* x_next, float* x0, int B, int C, int Cout, int HW, void* stream) {
+  OSM_REQUIRE(model_out && x && coef && x_next && B > 0 && C > 0 && Cout >= C && HW > 0, "osm_ancestral_step: bad argument");
+  hipLaunchKernelGGL(ancestral_step_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0, (hipStream_t)stream,
+                     model_out, x, z, coef, x_next, x0, B, C, Cout, HW);
+  return osm::check_launch("ancestral_step_kernel");
 }

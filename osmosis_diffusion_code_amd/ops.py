@@ -204,3 +204,8 @@ def guide_update(mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, gr
 def fetch_coefs(table, step, delta, coef_out, t_out, B):
     call("osm_fetch_coefs", ptr(table), ptr(step), delta, ptr(coef_out), ptr(t_out), B, _s(),
          keep=(table, step, coef_out, t_out))
+
+
+def ancestral_step(model_out, x, z, coef, x_next, x0, B, Cc, Cout, HW):
+    call("osm_ancestral_step", ptr(model_out), ptr(x), ptr(z), ptr(coef), ptr(x_next), ptr(x0), B, Cc, Cout, HW, _s(),
+         keep=(model_out, x, z, coef, x_next, x0))
