@@ -129,7 +129,12 @@ def roofline(model, args):
             fl = 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * d.ksize * d.ksize
             shape = (d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.splitk)
             per_shape.setdefault(shape, [0.0, 0, fl])
-            return ("conv3x3" if d.ksize == 3 else "conv1x1", fl, shape)
+            if d.ksize != 3:
+                return ("conv1x1", fl, shape)
+            # split-bf16 modes: layers with W >= 16 run the halo-tile kernel (the dominant one), the 8x8
+            # layers the tap-chunked kernel
+            halo = args.conv_mode != "f32" and d.W >= 16 and d.H >= 8
+            return ("conv3x3" if halo or args.conv_mode == "f32" else "conv3x3_8x8", fl, shape)
         if name == "osm_gemm":
             d = a[0]._obj
             return ("attn_gemm", 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2, None)
@@ -171,20 +176,21 @@ def roofline(model, args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
             for k in json.load(open(path))["kernels"]:
-                if k["kernel"].replace(" ", "").startswith({"f32": "igemm_f32_kernel<9,false", "bf16x6": "igemm_bf16s_kernel<9,3",
-                                                            "bf16x3": "igemm_bf16s_kernel<9,2"}[args.conv_mode]):
+                if k["kernel"].replace(" ", "").startswith({"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
+                                                            "bf16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]):
                     traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except Exception:
             pass
-    convs3 = {k: v for k, v in per_shape.items() if len(k) == 7 and k[5] == 3}
+    convs3 = {k: v for k, v in per_shape.items()
+              if len(k) == 7 and k[5] == 3 and (args.conv_mode == "f32" or (k[2] >= 16 and k[1] >= 8))}
     alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
                     for k, v in convs3.items()) / max(1, sum(v[1] for v in convs3.values()))
     kname, peak, note = {
         "f32": ("igemm_f32_kernel<9,false>", FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
-        "bf16x6": ("igemm_bf16s_kernel<9,3>", BF16_MFMA_PEAK_TFLOPS / 6.0,
+        "bf16x6": ("conv3_halo_bf16s_kernel<3>", BF16_MFMA_PEAK_TFLOPS / 6.0,
                    "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per fp32 product (fp32-class accuracy): "
                    "peak = dense bf16 MFMA peak 2500 TFLOP/s / 6; achieved counts ALGORITHMIC flops"),
-        "bf16x3": ("igemm_bf16s_kernel<9,2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
+        "bf16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
                    "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative): "
                    "peak = 2500 / 3; achieved counts ALGORITHMIC flops"),
     }[args.conv_mode]

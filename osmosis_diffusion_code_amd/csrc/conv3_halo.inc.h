@@ -1,0 +1,200 @@
+// 3x3 split-bf16 convolution on HALO tiles (included inside igemm.hip's anonymous namespace, after
+// igemm_bf16s.inc.h whose split helpers / fragment-order weight image it shares).
+//
+// igemm_bf16s_kernel treats the 9 taps as 9 independent K-chunks: every activation is fetched from
+// L2/HBM, split into bf16 planes on the VALU and stored to LDS nine times per N-tile, with one barrier
+// per 48 MFMAs.  Measured (round 1): MFMA pipe ~50 % busy, 3x HBM over-fetch.  Here a workgroup owns a
+// SPATIAL patch of 8 x 16 output pixels (= the 128 rows of the GEMM tile) and, per 32-channel slab,
+// stages the (8+2) x (16+2) halo ONCE: 180 pixels x 32 channels -> NP bf16 planes in LDS.  The nine taps
+// are then nine shifted windows of the same LDS image:
+//     A-fragment address = lane base + compile-time constant (tap shift, k16 half, plane, row block),
+// so the MFMA stream of a slab is 9 taps x 2 k16-steps x 24 MFMAs = 432 MFMAs per wave between two
+// barriers, fed by ds_read_b128 (immediate offsets, no address VALU) and by the pre-swizzled weight
+// fragments streamed straight from L2 into VGPRs.  Per slab and thread the staging work is 6 float4
+// loads + 6 splits (was 9 x 4), i.e. ~7x less VALU / LDS-store work and 9x fewer A reads.
+//
+// Row r of MFMA row-block i (0..3) is patch pixel (py, px) = (i + 4 (r >> 4), r & 15).  LDS pixel rows are
+// 80 B apart (32 bf16 + pad) and the halo row pitch is 20 pixels: with lanes 16-31 four halo rows (= 80
+// LDS rows = 5 x 16) below lanes 0-15, every ds_read_b128 lane group of gfx950 ({0-3,12-15,20-27}, ...) sees
+// 16 distinct bank quads for every tap shift -> 4 LDS cycles per fragment read (pitch 18 / adjacent rows: 8).
+
+constexpr int HALO_W = 18;                       // 16 + 2 staged pixels per halo row
+constexpr int HALO_P = 20;                       // LDS pitch of a halo row, in pixels
+constexpr int HALO_PIX = 180;                    // 10 x 18 staged pixels
+constexpr int HALO_ROWS = 10 * HALO_P + 8;       // LDS pixel rows (+ a dump row for the unused staging slots)
+constexpr int H_PLANE = HALO_ROWS * S_ROWB;      // bytes per plane
+constexpr int B_RING = 3;                        // weight-fragment register sets (divides the 18 steps of a slab)
+constexpr int B_DIST = 2;                        // steps between a weight fragment's load and its use
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* __restrict__ Aglob,
+                                                                   const unsigned short* __restrict__ Bglob,
+                                                                   IGemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[NP * H_PLANE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- XCD-aware tile mapping; M-tiles enumerate (image, patch row, patch col), N-tiles fastest
+  const int nt = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
+  const int tpx = (p.W + 15) >> 4, tpy = (p.H + 7) >> 3;
+  const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
+  const int x0 = tx * 16, y0 = ty * 8, n0 = tile_n * BN;
+
+  const int ks = blockIdx.y;
+  const int nslab = (p.K + BK - 1) / BK;
+  const int per = (nslab + p.splitk - 1) / p.splitk;
+  const int kc0 = ks * per;
+  const int kc1 = min(nslab, kc0 + per);
+
+  // ---- halo staging coordinates: slot s = tid + 256 j -> halo pixel (tid >> 3) + 32 j, float4 group tid & 7
+  const int cg = tid & 7;
+  const long long rowB = (long long)p.lda * 4;
+  const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
+  unsigned voff[6], woff[6], vmask = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int hp = (tid >> 3) + 32 * j;
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    woff[j] = (unsigned)((hp < HALO_PIX ? hy * HALO_P + hx : 10 * HALO_P) * S_ROWB + 8 * cg);
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = hp < HALO_PIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
+    voff[j] = (unsigned)((long long)(yc * p.W + xc) * rowB);
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+
+  // ---- B fragment addressing (image [plane][tap][k16-step][n/32][lane][8])
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int jn = (n0 >> 5) + wave_u;
+  const bool b_ok = jn < p.nt32;
+  const unsigned b_lane = b_ok ? (unsigned)((jn * 64 + lane) * 16) : (unsigned)(lane & 1) * 16u;
+  // uniform 32-bit byte offsets (the largest image, 2048 -> 1024 channels, is 113 MB)
+  const unsigned b_step = b_ok ? (unsigned)p.nt32 * 1024u : 0u;
+  const unsigned b_tap = b_step * (unsigned)p.ksteps;
+  const unsigned b_plane = b_tap * 9u;
+  const char* __restrict__ sbaseB0 =
+      b_ok ? reinterpret_cast<const char*>(Bglob) : reinterpret_cast<const char*>(g_zero_page);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int lr = lane & 31, lk = lane >> 5;
+  const unsigned char* a_rd = As + ((lr >> 4) * (4 * HALO_P) + (lr & 15)) * S_ROWB + 16 * lk;
+
+  float4 ra[6];
+  unsigned okm = 0;
+  uint4 bq[B_RING][NP];   // rolling weight-fragment sets: step g lives in bq[g % B_RING]
+
+#define OSM_H_LOAD_A(cc_)                                                                  \
+  {                                                                                        \
+    const bool cok_ = (cc_) * BK + 4 * cg < p.K;                                           \
+    const unsigned d_ = (unsigned)((cc_) * (BK * 4) + 16 * cg);                            \
+    okm = cok_ ? vmask : 0u;                                                               \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                          \
+      ra[j] = *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)));     \
+  }
+// weight fragments of step s_ (tap s_/2, k16 half s_&1) of slab cc_
+#define OSM_H_LOAD_B(slot_, cc_, s_)                                                       \
+  {                                                                                        \
+    const unsigned so_ = (unsigned)((s_) >> 1) * b_tap + (unsigned)(2 * (cc_) + ((s_) & 1)) * b_step; \
+    _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
+      bq[slot_][q2] = *reinterpret_cast<const uint4*>(sbaseB0 + (so_ + q2 * b_plane) + b_lane); \
+  }
+// A fragments of half-step hs_ (step hs_/2, row blocks 2 (hs_&1) and 2 (hs_&1) + 1)
+#define OSM_H_READ(f_, hs_)                                                                \
+  {                                                                                        \
+    constexpr int t_ = (hs_) >> 2, kk_ = ((hs_) >> 1) & 1, h_ = (hs_) & 1;                 \
+    constexpr int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
+      _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                    \
+        f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + q2 * H_PLANE +               \
+                                                       (2 * h_ + t) * (HALO_P * S_ROWB) + off_);     \
+  }
+#define OSM_H_MMA(f_, slot_, h_)                                                           \
+  _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
+    _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb) {                          \
+      acc[2 * (h_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[0][pa], as_frag(bq[slot_][pb]), \
+                                                              acc[2 * (h_)], 0, 0, 0);     \
+      acc[2 * (h_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[1][pa], as_frag(bq[slot_][pb]), \
+                                                                  acc[2 * (h_) + 1], 0, 0, 0); \
+    }
+
+  if (kc1 > kc0) {
+    OSM_H_LOAD_A(kc0);
+#pragma unroll
+    for (int s0 = 0; s0 < B_DIST; ++s0) OSM_H_LOAD_B(s0, kc0, s0);
+    for (int c = kc0; c < kc1; ++c) {
+      // split the staged halo of slab c into LDS (masked lanes / slots store zeros)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        uint2 pl[NP];
+        split_planes<NP>(sel4((okm >> j) & 1u, ra[j]), pl);
+#pragma unroll
+        for (int q2 = 0; q2 < NP; ++q2)
+          *reinterpret_cast<uint2*>(As + q2 * H_PLANE + woff[j]) = pl[q2];
+      }
+      const int cn = min(c + 1, kc1 - 1);
+      OSM_H_LOAD_A(cn);                      // next slab's halo: in flight during the MFMA stream
+      __syncthreads();
+      bf16x8_t fx[2][NP], fy[2][NP];
+      OSM_H_READ(fx, 0)
+#define OSM_H_STEP(s_)                                                                     \
+      OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
+      OSM_H_READ(fy, 2 * (s_) + 1)                                                         \
+      OSM_H_MMA(fx, (s_) % B_RING, 0)                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      if ((s_) + 1 < 18) OSM_H_READ(fx, (2 * (s_) + 2) % 36)                               \
+      OSM_H_MMA(fy, (s_) % B_RING, 1)                                                           \
+      __builtin_amdgcn_sched_barrier(0);
+      OSM_H_STEP(0) OSM_H_STEP(1) OSM_H_STEP(2) OSM_H_STEP(3) OSM_H_STEP(4) OSM_H_STEP(5)
+      OSM_H_STEP(6) OSM_H_STEP(7) OSM_H_STEP(8) OSM_H_STEP(9) OSM_H_STEP(10) OSM_H_STEP(11)
+      OSM_H_STEP(12) OSM_H_STEP(13) OSM_H_STEP(14) OSM_H_STEP(15) OSM_H_STEP(16) OSM_H_STEP(17)
+#undef OSM_H_STEP
+      __syncthreads();                       // every wave is done reading this slab's LDS image
+    }
+  }
+#undef OSM_H_LOAD_A
+#undef OSM_H_LOAD_B
+#undef OSM_H_READ
+#undef OSM_H_MMA
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const bool partial = p.splitk > 1;
+  float* Cb = partial ? p.ws + ((long long)ks * p.M) * p.N : p.C;
+  const float* Rb = (p.res && !partial) ? p.res : nullptr;
+  const long long ldc = partial ? (long long)p.N : p.ldc;
+  const int n = n0 + 32 * wave + lr;
+  if (n >= p.N) return;
+  const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
+  // element e of row block tm is patch pixel (tm + 4 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
+  const int xl = x0 + 4 * lk;
+  const long long pix0 = (long long)img * p.H * p.W + (long long)y0 * p.W + xl;
+  float* __restrict__ cp = Cb + pix0 * ldc + n;
+  const float* __restrict__ rp = Rb ? Rb + pix0 * p.ldr + n : nullptr;
+  const long long crow = (long long)p.W * ldc, rrow = (long long)p.W * p.ldr;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int dy = tm + 4 * (e >> 3), dx = (e & 3) + 8 * ((e >> 2) & 1);
+      if (y0 + dy >= p.H || xl + dx >= p.W) continue;
+      float* c = cp + dy * crow + dx * ldc;
+      float v = acc[tm][e];
+      if (!partial) {
+        v = v * p.alpha + bv;
+        if (rp) v += rp[dy * rrow + dx * p.ldr];
+        if (p.accumulate) v += *c;
+      }
+      *c = v;
+    }
+  }
+}

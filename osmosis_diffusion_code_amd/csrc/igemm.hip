@@ -316,6 +316,16 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 #include "igemm_bf16s.inc.h"
+#include "conv3_halo.inc.h"
+
+// OSM_CONV_HALO=0 selects the tap-chunked kernel for 3x3 layers too (A/B measurements only)
+bool halo_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("OSM_CONV_HALO");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   p.mtiles = (p.M + BM - 1) / BM;
@@ -324,7 +334,21 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > p.nchunks) p.splitk = p.nchunks;
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
-  if (wfmt != 0) {
+  if (wfmt != 0 && taps == 9 && p.W >= 16 && p.H >= 8 && halo_enabled()) {
+    // halo-tile kernel: M-tiles are 8 x 16 pixel patches, K is consumed in 32-channel slabs of all 9 taps
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
+    const int nimg = p.M / (p.H * p.W);
+    p.mtiles = nimg * ((p.H + 7) / 8) * ((p.W + 15) / 16);
+    p.nchunks = (p.K + BK - 1) / BK;
+    if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+    const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
+    if (wfmt == 3)
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3>), g2, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 2)
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2>), g2, dim3(256), 0, st, p.A, Bp, p);
+    else
+      return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+  } else if (wfmt != 0) {
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
     if (wfmt == 3 && taps == 9)
