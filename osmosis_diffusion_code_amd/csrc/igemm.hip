@@ -386,8 +386,13 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
   const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (nbatch > 0 ? nbatch : 1);
   const int nchunks = taps * ((K + BK - 1) / BK);
-  if (tiles >= 512) return 1;   // >= 2 workgroups per CU already
-  long long s = (512 + tiles - 1) / tiles;  // aim at ~2 workgroups per CU
+  static const int target = [] {   // OSM_SPLITK_TARGET: workgroups to aim for (tuning knob)
+    const char* e = std::getenv("OSM_SPLITK_TARGET");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256;
+  }();
+  if (tiles >= target) return 1;   // one workgroup per CU already (measured: 256 beats 384 / 512 / 768)
+  long long s = (target + tiles - 1) / tiles;  // aim at ~1 workgroup per CU: fewer fp32 partials to write and re-read
   const int max_by_chunks = nchunks / 4 > 0 ? nchunks / 4 : 1;  // >= 4 chunks per slice
   if (s > max_by_chunks) s = max_by_chunks;
   if (s > 64) s = 64;
