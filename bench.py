@@ -137,7 +137,15 @@ def roofline(model, args):
             return ("conv3x3" if halo or args.conv_mode == "f32" else "conv3x3_8x8", fl, shape)
         if name == "osm_gemm":
             d = a[0]._obj
-            return ("attn_gemm", 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2, None)
+            fl = 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2
+            shape = ("osm_gemm", d.M, d.N, d.K, d.nb1 * d.nb2, int(d.b_kn))
+            per_shape.setdefault(shape, [0.0, 0, fl])
+            return ("attn_gemm", fl, shape)
+        if name in ("osm_softmax_rows", "osm_softmax_rows_bwd"):
+            i0 = 3 if name == "osm_softmax_rows" else 4
+            shape = (name, int(a[i0]), int(a[i0 + 1]))
+            per_shape.setdefault(shape, [0.0, 0, 4.0 * shape[1] * shape[2] * shape[2] * (3 if i0 == 3 else 4)])
+            return ("softmax", 0.0, shape)
         if name.startswith("osm_gn"):
             i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 8}[name]
             shape = (name, int(a[i0]), int(a[i0 + 1]), int(a[i0 + 2]))

@@ -76,6 +76,8 @@ typedef struct osm_gemm_desc {
   float alpha;         /* C = alpha*A*B (+bias +res)                                   */
   long long lda, ldb, ldc, ldr;
   long long sA1, sB1, sC1, sA2, sB2, sC2;   /* batch strides in floats (res uses sC*)  */
+  int splitk;          /* <=1: none; else K is cut into `splitk` slices ...            */
+  float* splitk_ws;    /* ... with fp32 partials in splitk*nb1*nb2*M*N floats, reduced deterministically */
 } osm_gemm_desc;
 /* Split-bf16 weight images: `wfmt` planes of bf16 in MFMA-fragment order
  * [plane][tap][k16-step s][n/32 j][lane l][8]: n = 32j + (l&31), k = 16s + 8(l>>5) + e, zero padded, an even

@@ -40,7 +40,8 @@ class GemmDesc(C.Structure):
                 ("nb1", C.c_int), ("nb2", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_float),
                 ("lda", C.c_longlong), ("ldb", C.c_longlong), ("ldc", C.c_longlong), ("ldr", C.c_longlong),
                 ("sA1", C.c_longlong), ("sB1", C.c_longlong), ("sC1", C.c_longlong),
-                ("sA2", C.c_longlong), ("sB2", C.c_longlong), ("sC2", C.c_longlong)]
+                ("sA2", C.c_longlong), ("sB2", C.c_longlong), ("sC2", C.c_longlong),
+                ("splitk", C.c_int), ("splitk_ws", C.c_void_p)]
 
 
 class PhysDesc(C.Structure):

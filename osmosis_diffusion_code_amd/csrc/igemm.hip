@@ -61,7 +61,9 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-template <int TAPS, bool B_KN>
+// NARROW (N <= 64, e.g. attention P V with 64-wide heads): the four waves split the 128 rows (32 each) and
+// every wave covers the 64 live columns, instead of 2 x 2 waves of 64 x 64 where half would multiply zeros.
+template <int TAPS, bool B_KN, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restrict__ Aglob,
                                                             const float* __restrict__ Bglob,
                                                             IGemmParams p) {
@@ -199,16 +201,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
+  constexpr int WROWS = NARROW ? 32 : 64;   // rows per wave
   const int lr = lane & 31, lk = lane >> 5;
 
   auto compute = [&](int buf) {
-    const float* a = As + buf * BM * LDS_STRIDE + (64 * wm + lr) * LDS_STRIDE + 4 * lk;
+    const float* a = As + buf * BM * LDS_STRIDE + (WROWS * wm + lr) * LDS_STRIDE + 4 * lk;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       float4 af[2], bf[2];
       af[0] = *reinterpret_cast<const float4*>(a + 8 * kk);
-      af[1] = *reinterpret_cast<const float4*>(a + 32 * LDS_STRIDE + 8 * kk);
+      af[1] = NARROW ? af[0] : *reinterpret_cast<const float4*>(a + 32 * LDS_STRIDE + 8 * kk);
       if (!B_KN) {
         const float* b = Bs + buf * BN * LDS_STRIDE + (64 * wn + lr) * LDS_STRIDE + 4 * lk;
         bf[0] = *reinterpret_cast<const float4*>(b + 8 * kk);
@@ -227,8 +230,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
       for (int j = 0; j < 4; ++j) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1v[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[j], acc[1][1], 0, 0, 0);
+        if (!NARROW) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[j], acc[1][1], 0, 0, 0);
+        }
       }
     }
   };
@@ -261,10 +266,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
     if (n >= p.N) continue;
     const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tm = 0; tm < (NARROW ? 1 : 2); ++tm) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + 64 * wm + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int m = m0 + WROWS * wm + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (m >= p.M) continue;
         float v = acc[tm][tn][e];
         if (!partial) {
@@ -364,8 +369,12 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   } else if (taps == 9) {
     if (b_kn) return osm::fail(OSM_ERR_UNSUPPORTED, "3x3 conv needs [n][k] weights");
     hipLaunchKernelGGL((igemm_f32_kernel<9, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
+  } else if (b_kn && p.N <= 64) {
+    hipLaunchKernelGGL((igemm_f32_kernel<1, true, true>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   } else if (b_kn) {
     hipLaunchKernelGGL((igemm_f32_kernel<1, true>), grid, dim3(256), 0, st, p.A, p.Bm, p);
+  } else if (p.N <= 64) {
+    hipLaunchKernelGGL((igemm_f32_kernel<1, false, true>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   } else {
     hipLaunchKernelGGL((igemm_f32_kernel<1, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   }
@@ -432,9 +441,10 @@ extern "C" int osm_gemm(const osm_gemm_desc* d, void* stream) {
   OSM_REQUIRE(d->sA1 % 4 == 0 && d->sB1 % 4 == 0 && d->sA2 % 4 == 0 && d->sB2 % 4 == 0,
               "osm_gemm: batch strides of A/B must be multiples of 4");
   IGemmParams p{};
-  p.A = d->A; p.Bm = d->Bm; p.bias = d->bias; p.res = d->res; p.C = d->C; p.ws = nullptr;
+  OSM_REQUIRE(d->splitk <= 1 || d->splitk_ws, "osm_gemm: splitk>1 needs a workspace");
+  p.A = d->A; p.Bm = d->Bm; p.bias = d->bias; p.res = d->res; p.C = d->C; p.ws = d->splitk_ws;
   p.M = d->M; p.N = d->N; p.K = d->K; p.H = 1; p.W = d->M;
-  p.splitk = 1; p.accumulate = d->accumulate; p.alpha = d->alpha;
+  p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate; p.alpha = d->alpha;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.tapstrideB = 0;
   p.nb1 = d->nb1; p.nbatch = d->nb1 * d->nb2;

@@ -248,6 +248,16 @@ class UNetEngine:
                    silu=True, addend=add)
 
     # ------------------------------------------------------------------ Attention
+    def _gemm(self, *a, **kw):
+        """ops.gemm with split-K when the batch of (M, N) tiles alone would leave most CUs idle
+        (P V / dq / dk / dv: 64-wide heads, K = T)."""
+        M, N, K = a[6], a[7], a[8]
+        nbatch = kw.get("nb1", 1) * kw.get("nb2", 1)
+        sk = ops.splitk_hint(M, N, K, 1, nbatch)
+        if sk > 1:
+            kw.update(splitk=sk, splitk_ws=self._scr_flat("splitk", sk * nbatch * M * N))
+        ops.gemm(*a, **kw)
+
     def _attn_offsets(self, blk: _Attn):
         C, nh = blk.ch, blk.heads
         ch = C // nh
@@ -270,13 +280,13 @@ class UNetEngine:
         nmat = B * nh
         S = self._scr_flat("s0", nmat * T * T)
         alpha = 1.0 / math.sqrt(ch)     # (q*ch^-1/4)·(k*ch^-1/4)
-        ops.gemm(qkv.t, 3 * C, qkv.t, 3 * C, S, T, T, T, ch, b_kn=False, alpha=alpha, nb1=nh, nb2=B,
+        self._gemm(qkv.t, 3 * C, qkv.t, 3 * C, S, T, T, T, ch, b_kn=False, alpha=alpha, nb1=nh, nb2=B,
                  sA=(hs, T * 3 * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), a_off=qo, b_off=ko)
         P = self._small(nmat * T * T)
         PT = self._small(nmat * T * T)
         ops.softmax_rows(S, P, PT, nmat, T)
         a = self._scr("b", M, C)
-        ops.gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+        self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                  sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
         self._conv(a, blk.proj, dst, hw, res=x)
         blk.saved = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw)
@@ -296,7 +306,7 @@ class UNetEngine:
         da = self._scr("a", M, C)
         self._conv(dy, blk.proj, da, hw, dgrad=True)
         dP = self._scr_flat("s0", nmat * T * T)
-        ops.gemm(da.t, C, qkv.t, 3 * C, dP, T, T, T, ch, b_kn=False, nb1=nh, nb2=B,
+        self._gemm(da.t, C, qkv.t, 3 * C, dP, T, T, T, ch, b_kn=False, nb1=nh, nb2=B,
                  sA=(ch, T * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), b_off=vo)
         dS = self._scr_flat("s1", nmat * T * T)
         dST = self._scr_flat("s2", nmat * T * T)
@@ -304,11 +314,11 @@ class UNetEngine:
         dqkv = self._scr("b", M, 3 * C)
         sQ = (hs, T * 3 * C)
         # dq = alpha * dS k ; dk = alpha * dS^T q ; dv = P^T da
-        ops.gemm(dS, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+        self._gemm(dS, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
                  sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=ko, c_off=qo)
-        ops.gemm(dST, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+        self._gemm(dST, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
                  sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=qo, c_off=ko)
-        ops.gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+        self._gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                  sA=(T * T, nh * T * T), sB=(ch, T * C), sC=sQ, c_off=vo)
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)

@@ -81,7 +81,8 @@ def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True, wfmt:
 def gemm(A: torch.Tensor, lda: int, Bm: torch.Tensor, ldb: int, Cm: torch.Tensor, ldc: int, M: int, N: int,
          K: int, b_kn: bool = False, alpha: float = 1.0, nb1: int = 1, nb2: int = 1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, res: Optional[torch.Tensor] = None, ldr: int = 0,
-         accumulate: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0):
+         accumulate: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0,
+         splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None):
     """Raw-pointer GEMM: element offsets (in floats) select sub-matrices of the backing tensors."""
     d = GemmDesc()
     d.A, d.Bm, d.C = ptr(A) + 4 * a_off, ptr(Bm) + 4 * b_off, ptr(Cm) + 4 * c_off
@@ -93,7 +94,8 @@ def gemm(A: torch.Tensor, lda: int, Bm: torch.Tensor, ldb: int, Cm: torch.Tensor
     d.sA1, d.sA2 = sA
     d.sB1, d.sB2 = sB
     d.sC1, d.sC2 = sC
-    call("osm_gemm", C.byref(d), _s(), keep=(A, Bm, Cm, bias, res))
+    d.splitk, d.splitk_ws = splitk, ptr(splitk_ws)
+    call("osm_gemm", C.byref(d), _s(), keep=(A, Bm, Cm, bias, res, splitk_ws))
 
 
 def splitk_hint(M, N, K, taps, nbatch=1) -> int:

@@ -99,15 +99,18 @@ def test_pack_weight_exact(ops):
 
 
 @pytest.mark.parametrize("b_kn", [False, True])
-def test_gemm_batched(ops, b_kn):
-    g = torch.Generator().manual_seed(17)
-    nb1, nb2, M, N, K = 3, 2, 70, 36, 52
+@pytest.mark.parametrize("N,splitk", [(36, 1), (160, 1), (64, 3), (132, 2)])   # N <= 64 runs the narrow-N wave layout
+def test_gemm_batched(ops, b_kn, N, splitk):
+    g = torch.Generator().manual_seed(17 + N)
+    nb1, nb2, M, K = 3, 2, 70, 52 if splitk == 1 else 200
     A = torch.randn(nb2, nb1, M, K, generator=g)
     Bm = torch.randn(nb2, nb1, K, N, generator=g) if b_kn else torch.randn(nb2, nb1, N, K, generator=g)
-    ref = 0.5 * (A @ (Bm if b_kn else Bm.transpose(-1, -2)))
+    ref = 0.5 * (A.double() @ (Bm if b_kn else Bm.transpose(-1, -2)).double()).float()
     Cd = torch.zeros(nb2, nb1, M, N, device=DEV)
+    ws = torch.empty(splitk * nb1 * nb2 * M * N, device=DEV) if splitk > 1 else None
     ops.gemm(A.to(DEV), K, Bm.to(DEV), N if b_kn else K, Cd, N, M, N, K, b_kn=b_kn, alpha=0.5,
-             nb1=nb1, nb2=nb2, sA=(M * K, nb1 * M * K), sB=(K * N, nb1 * K * N), sC=(M * N, nb1 * M * N))
+             nb1=nb1, nb2=nb2, sA=(M * K, nb1 * M * K), sB=(K * N, nb1 * K * N), sC=(M * N, nb1 * M * N),
+             splitk=splitk, splitk_ws=ws)
     assert relerr(Cd.cpu(), ref) < 2e-6
 
 
