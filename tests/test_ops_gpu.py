@@ -186,9 +186,9 @@ def test_pool_upsample(ops):
     assert torch.allclose(from_nhwc(y3, 1, 2, 2), F.avg_pool2d(x3, 2, 2), atol=1e-6)
 
 
-def test_softmax_rows_fwd_bwd(ops):
-    g = torch.Generator().manual_seed(9)
-    nmat, T = 3, 100
+@pytest.mark.parametrize("nmat,T", [(3, 100), (3, 128), (2, 64), (1, 320)])   # T % 64 == 0: tiled kernels
+def test_softmax_rows_fwd_bwd(ops, nmat, T):
+    g = torch.Generator().manual_seed(9 + T)
     S = (torch.randn(nmat, T, T, generator=g) * 3).requires_grad_(True)
     P = torch.softmax(S, dim=-1)
     dP = torch.randn(nmat, T, T, generator=g)
