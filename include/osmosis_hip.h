@@ -101,6 +101,10 @@ int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C, int G, flo
 int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,
                  long long ldfilm, int silu, void* stream);
+/* stats + apply in one call (one launch for HW <= 256); `stats` is written (kept for the backward). */
+int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
+               float* part, float* stats, const float* gamma, const float* beta, const float* film,
+               long long ldfilm, int silu, void* stream);
 /* dx = dGN(dy) (+ addend).  part: workspace as above. */
 int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                const float* addend, long long ldadd, int B, int HW, int C, int G,

@@ -163,9 +163,8 @@ class UNetEngine:
         HW = H * W
         M = B * HW
         st1 = self._small(B * G * 2)
-        ops.gn_stats(x, B, HW, G, self.gn_part, st1)
         a1 = self._scr("a", M, blk.cin)
-        ops.gn_apply(x, a1, B, HW, G, st1, blk.n1.g, blk.n1.b, silu=True)
+        ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True)
         if blk.up:
             ho, wo = 2 * H, 2 * W
             a1r = self._scr("b", B * ho * wo, blk.cin)
@@ -187,9 +186,8 @@ class UNetEngine:
         film = torch.empty(B, 2 * blk.cout, device=self.dev, dtype=torch.float32)
         ops.linear(self.emb, blk.ew, blk.eb, film, B, self.ted, 2 * blk.cout, silu_in=True)
         st2 = self._small(B * G * 2)
-        ops.gn_stats(h1, B, ho * wo, G, self.gn_part, st2)
         a2 = self._scr("a", Mo, blk.cout)
-        ops.gn_apply(h1, a2, B, ho * wo, G, st2, blk.n2.g, blk.n2.b, film=film, silu=True)
+        ops.gn_fwd(h1, a2, B, ho * wo, G, self.gn_part, st2, blk.n2.g, blk.n2.b, film=film, silu=True)
         if blk.skip is not None:
             self._conv(xs, blk.skip, dst, (ho, wo))
             res = dst
@@ -272,9 +270,8 @@ class UNetEngine:
         C, nh = blk.ch, blk.heads
         ch, (qo, ko, vo), hs = self._attn_offsets(blk)
         st = self._small(B * G * 2)
-        ops.gn_stats(x, B, T, G, self.gn_part, st)
         xn = self._scr("a", M, C)
-        ops.gn_apply(x, xn, B, T, G, st, blk.norm.g, blk.norm.b, silu=False)
+        ops.gn_fwd(x, xn, B, T, G, self.gn_part, st, blk.norm.g, blk.norm.b, silu=False)
         qkv = self._buf(M, 3 * C)
         self._conv(xn, blk.qkv, qkv, hw)
         nmat = B * nh
@@ -432,9 +429,8 @@ class UNetEngine:
         # ---- head: GN, SiLU, conv3x3 -> NCHW
         self.h_last = h
         self.st_out = self._small(B * G * 2)
-        ops.gn_stats(h, B, H * W, G, self.gn_part, self.st_out)
         a = self._scr("a", B * H * W, h.cols)
-        ops.gn_apply(h, a, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, silu=True)
+        ops.gn_fwd(h, a, B, H * W, G, self.gn_part, self.st_out, self.out_norm.g, self.out_norm.b, silu=True)
         o = self._buf(B * H * W, self.cout)
         self._conv(a, self.out_conv, o, (H, W))
         ops.nhwc_to_nchw(o, self.out, B, self.cout, H * W)

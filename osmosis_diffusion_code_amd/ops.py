@@ -123,6 +123,13 @@ def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=N
          int(silu), _s(), keep=(x.t, y.t, stats, gamma, beta, film))
 
 
+def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, film=None, silu=True, eps: float = 1e-5):
+    """statistics (written to `stats`) + normalise/FiLM/SiLU; a single launch for HW <= 1024."""
+    fp, ldf = _film(film)
+    call("osm_gn_fwd", x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
+         fp, ldf, int(silu), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film))
+
+
 def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
            film=None, silu=True, addend: Optional[Mat] = None):
     fp, ldf = _film(film)

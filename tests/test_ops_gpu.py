@@ -126,7 +126,8 @@ def test_gemm_asymmetric_identity(ops):
 
 @pytest.mark.parametrize("C,HW,film,silu", [(64, 64, True, True), (256, 256, False, True),
                                              (96, 100, True, False), (32, 64, False, False),
-                                             (1536, 64, True, True), (2048, 16, False, True)])
+                                             (1536, 64, True, True), (2048, 16, False, True),
+                                             (512, 1024, True, True), (128, 4096, True, True)])
 def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
     g = torch.Generator().manual_seed(C + HW)
     B, G = 2, 32
@@ -161,6 +162,13 @@ def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
     ops.gn_apply(xm, ops.Mat.of(yd), B, HW, G, stats, gd, bd, film=ed, silu=silu)
     got = yd.cpu().reshape(B, HW, C).permute(0, 2, 1)
     assert float((got - y.detach()).abs().max()) < 2e-5
+
+    # one-call forward (a single launch for HW <= 1024) must agree with stats + apply
+    yd2 = torch.empty(B * HW, C, device=DEV)
+    stats2 = torch.empty(B * G * 2, device=DEV)
+    ops.gn_fwd(xm, ops.Mat.of(yd2), B, HW, G, part, stats2, gd, bd, film=ed, silu=silu)
+    assert float((yd2 - yd).abs().max()) < 2e-5
+    assert float((stats2 - stats).abs().max()) < 1e-4 * float(stats.abs().max())
 
     dxd = torch.empty(B * HW, C, device=DEV)
     ops.gn_bwd(xm, ops.Mat.of(nhwc(dy)), ops.Mat.of(dxd), B, HW, G, stats, gd, bd, part, gstats,
