@@ -140,6 +140,21 @@ class Recorder:
             if rc != 0:
                 raise OsmosisHipError(f"{fn.__name__} failed ({rc}): {load().osm_last_error().decode()}")
 
+    def to_graph(self):
+        """Capture the recorded launches into a hipGraph (torch.cuda.CUDAGraph).  Every recorded call ends
+        with its stream argument, which is re-targeted to the capture stream."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=side):
+            sp = torch.cuda.current_stream().cuda_stream
+            for fn, args in self.calls:
+                rc = fn(*args[:-1], sp)
+                if rc != 0:
+                    raise OsmosisHipError(f"{fn.__name__} failed during capture ({rc}): "
+                                          f"{load().osm_last_error().decode()}")
+        return g
+
     def replay_timed(self, select):
         """Replay with HIP events around the selected launches (events are recorded on the stream
         the kernels run on).  `select(fn_name, args)` returns a tag or None.  Returns [(tag, ms)]."""

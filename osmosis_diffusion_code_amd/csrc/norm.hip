@@ -32,8 +32,9 @@ struct GNArgs {
   const float* addend;
   float* out;
   float* part;
-  float* fin;           // finalized statistics written by the one-launch kernel
+  float* fin;           // finalized statistics written by the one-launch kernel / the fused apply prologue
   double n;             // elements per group
+  int fuse;             // apply kernels: combine the chunk partials in the prologue (no finalize launch)
   long long ldx, lddy, ldo, ldadd, ldf;
   int B, HW, C, G, gs, nchunk, ppc, silu;
   float eps;
@@ -187,6 +188,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
   const int rowT = 256 / colT;
   const int nj = (vpr + 255) / 256;
   const int tc = tid % colT, tr = tid / colT;
+  // fused finalize (nchunk <= GN_FUSE_CHUNKS): every workgroup combines the chunk partials of its image in
+  // the same fixed order (fp64), so all of them see identical statistics; chunk 0 publishes them.
+  __shared__ float sst[2 * 256];
+  if (a.fuse) {
+    const int lane = tid & 63;
+    for (int g = tid >> 6; g < a.G; g += 4) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = lane; k < a.nchunk; k += 64) {
+        const float2 pp = *reinterpret_cast<const float2*>(a.part + (((long long)b * a.nchunk + k) * a.G + g) * 2);
+        s1 += (double)pp.x;
+        s2 += (double)pp.y;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if (lane == 0) {
+        float o0, o1;
+        if (MODE == 0) {
+          const double mu = s1 / a.n;
+          double var = s2 / a.n - mu * mu;
+          if (var < 0.0) var = 0.0;
+          o0 = (float)mu;
+          o1 = (float)(1.0 / sqrt(var + (double)a.eps));
+        } else {
+          o0 = (float)(s1 / a.n);
+          o1 = (float)(s2 / a.n);
+        }
+        sst[2 * g] = o0;
+        sst[2 * g + 1] = o1;
+        if (chunk == 0) {
+          a.fin[(b * a.G + g) * 2] = o0;
+          a.fin[(b * a.G + g) * 2 + 1] = o1;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (tr >= rowT) return;
   const int p0 = chunk * a.ppc;
   const int p1 = min(a.HW, p0 + a.ppc);
@@ -197,12 +237,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
     if (j >= nj || v >= vpr) break;
     const int c = v * VEC;
     const int g = c / a.gs;
-    const float mean = a.stats[(b * a.G + g) * 2];
-    const float rstd = a.stats[(b * a.G + g) * 2 + 1];
+    const float mean = (MODE == 0 && a.fuse) ? sst[2 * g] : a.stats[(b * a.G + g) * 2];
+    const float rstd = (MODE == 0 && a.fuse) ? sst[2 * g + 1] : a.stats[(b * a.G + g) * 2 + 1];
     float m1 = 0.f, m2 = 0.f;
     if (MODE == 1) {
-      m1 = a.gstats[(b * a.G + g) * 2];
-      m2 = a.gstats[(b * a.G + g) * 2 + 1];
+      m1 = a.fuse ? sst[2 * g] : a.gstats[(b * a.G + g) * 2];
+      m2 = a.fuse ? sst[2 * g + 1] : a.gstats[(b * a.G + g) * 2 + 1];
     }
     float ga[VEC], be[VEC], sc[VEC], sh[VEC];
 #pragma unroll
@@ -413,8 +453,10 @@ int check_common(const GNArgs& a, const char* who) {
   return OSM_OK;
 }
 
+constexpr int GN_FUSE_CHUNKS = 256;   // apply kernels re-combine up to this many chunk partials themselves
+
 template <int MODE>
-int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
+int run_reduce(GNArgs& a, float* finalized, hipStream_t st, bool finalize = true) {
   a.ppc = gn_ppc(a.HW);
   a.nchunk = (a.HW + a.ppc - 1) / a.ppc;
   a.gs = a.C / a.G;
@@ -426,7 +468,7 @@ int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
   else
     hipLaunchKernelGGL((gn_reduce_kernel<1, MODE>), grid, dim3(256), 0, st, a);
   int rc = osm::check_launch("gn_reduce_kernel");
-  if (rc) return rc;
+  if (rc || !finalize) return rc;
   const int n = a.B * a.G;
   hipLaunchKernelGGL((gn_finalize_kernel<MODE>), dim3((n + 3) / 4), dim3(256), 0, st, a.part, finalized, a.B,
                      a.G, a.nchunk, (double)a.HW * a.gs, a.eps);
@@ -436,6 +478,7 @@ int run_reduce(GNArgs& a, float* finalized, hipStream_t st) {
 template <int MODE>
 int run_apply(GNArgs& a, hipStream_t st) {
   a.gs = a.C / a.G;
+  a.n = (double)a.HW * a.gs;
   a.ppc = gn_ppc(a.HW);
   a.nchunk = (a.HW + a.ppc - 1) / a.ppc;
   const bool v4 = use_vec4(a);
@@ -501,7 +544,9 @@ extern "C" int osm_gn_bwd(const float* x, long long ldx, const float* dy, long l
   int rc = check_common(a, "osm_gn_bwd");
   if (rc) return rc;
   if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
-  rc = run_reduce<1>(a, gstats, (hipStream_t)stream);
+  a.fuse = osm_gn_nchunk(HW) <= GN_FUSE_CHUNKS;
+  a.fin = gstats;
+  rc = run_reduce<1>(a, gstats, (hipStream_t)stream, !a.fuse);
   if (rc) return rc;
   return run_apply<1>(a, (hipStream_t)stream);
 }
@@ -517,7 +562,9 @@ extern "C" int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy
   int rc = check_common(a, "osm_gn_fwd");
   if (rc) return rc;
   if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
-  rc = run_reduce<0>(a, stats, (hipStream_t)stream);
+  a.fuse = osm_gn_nchunk(HW) <= GN_FUSE_CHUNKS;
+  a.fin = stats;
+  rc = run_reduce<0>(a, stats, (hipStream_t)stream, !a.fuse);
   if (rc) return rc;
   return run_apply<0>(a, (hipStream_t)stream);
 }

@@ -20,6 +20,7 @@ Per ResBlock (unet.py:315-335):   GN+SiLU -> [pool|upsample] -> conv3x3 -> GN*(1
 Per AttentionBlock (:378-433):    GN -> qkv 1x1 -> per-head softmax(q k^T / sqrt(ch)) v -> proj 1x1 (+x)
 """
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -90,6 +91,9 @@ class UNetEngine:
         self._bwd_plan: Optional[Recorder] = None
         self._plan_stream = None
         self._splitk_ws = None
+        # OSM_GRAPH=1: replay the recorded plans as hipGraphs instead of ~700 individual launches
+        self.use_graph = os.environ.get("OSM_GRAPH", "0") == "1"
+        self._fwd_graph = self._bwd_graph = None
 
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
@@ -110,6 +114,18 @@ class UNetEngine:
         self.outb = [seq(s) for s in model.output_blocks]
         self.out_norm = _Norm(model.out.at(0), dev)
         self.out_conv = _Conv(model.out.at(2), dev, wfmt)
+
+        # every ResBlock's FiLM projection Linear(SiLU(emb)) depends on emb only: one stacked weight, ONE launch
+        res_blocks = [m for seqs in (self.inp, [self.mid], self.outb) for sq in seqs for m in sq if isinstance(m, _Res)]
+        off = 0
+        for m in res_blocks:
+            m.film_off = off
+            off += 2 * m.cout
+        self.film_cols = off
+        self.ew_all = torch.cat([m.ew for m in res_blocks], 0).contiguous()
+        self.eb_all = torch.cat([m.eb for m in res_blocks], 0).contiguous()
+        for m in res_blocks:
+            m.ew = m.eb = None
 
         f32 = dict(device=dev, dtype=torch.float32)
         self.x_in = torch.zeros(B, self.cin, H, W, **f32)
@@ -183,8 +199,7 @@ class UNetEngine:
         Mo = B * ho * wo
         h1 = self._buf(Mo, blk.cout)
         self._conv(a1r, blk.c1, h1, (ho, wo))
-        film = torch.empty(B, 2 * blk.cout, device=self.dev, dtype=torch.float32)
-        ops.linear(self.emb, blk.ew, blk.eb, film, B, self.ted, 2 * blk.cout, silu_in=True)
+        film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         a2 = self._scr("a", Mo, blk.cout)
         ops.gn_fwd(h1, a2, B, ho * wo, G, self.gn_part, st2, blk.n2.g, blk.n2.b, film=film, silu=True)
@@ -375,6 +390,8 @@ class UNetEngine:
         ops.linear(temb, self.te0[0], self.te0[1], e1, B, self.mc, self.ted, silu_out=True)
         self.emb = torch.empty(B, self.ted, **f32)
         ops.linear(e1, self.te2[0], self.te2[1], self.emb, B, self.ted, self.ted)
+        self.film_all = torch.empty(B, self.film_cols, **f32)
+        ops.linear(self.emb, self.ew_all, self.eb_all, self.film_all, B, self.ted, self.film_cols, silu_in=True)
 
         # ---- channel bookkeeping for the zero-copy concatenations
         stem: _Conv = self.inp[0][0]
@@ -472,6 +489,7 @@ class UNetEngine:
         if self._plan_stream is not None and s != self._plan_stream:
             # plans are bound to the stream they were recorded on
             self._fwd_plan = self._bwd_plan = None
+            self._fwd_graph = self._bwd_graph = None
         self._plan_stream = s
 
     def load_inputs(self, x: torch.Tensor, timesteps: torch.Tensor):
@@ -484,9 +502,14 @@ class UNetEngine:
         self.ticket += 1
         if self._fwd_plan is None:
             self._bwd_plan = None
+            self._fwd_graph = self._bwd_graph = None
             with Recorder() as rec:
                 self._forward_impl()
             self._fwd_plan = rec
+        elif self.use_graph:
+            if self._fwd_graph is None:
+                self._fwd_graph = self._fwd_plan.to_graph()
+            self._fwd_graph.replay()
         else:
             self._fwd_plan.replay()
 
@@ -499,6 +522,10 @@ class UNetEngine:
             with Recorder() as rec:
                 self._backward_impl()
             self._bwd_plan = rec
+        elif self.use_graph:
+            if self._bwd_graph is None:
+                self._bwd_graph = self._bwd_plan.to_graph()
+            self._bwd_graph.replay()
         else:
             self._bwd_plan.replay()
 
