@@ -16,6 +16,8 @@ Sections (SURVEY.md section 8c recipe):
   tiny_unet.npz   create_model(tiny) with oracle.unet_ref.seeded_state_dict weights: y, dL/dx
   loop_<op>.npz   10-step guided p_sample_loop for each of the 3 physical operators with the
                   exact noise tensors the reference drew, per-step traces
+  prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
+  postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
 """
 import os
 import sys
@@ -299,12 +301,45 @@ def gen_prior():
                         cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
 
 
+def gen_postprocess():
+    """Output post-processing helpers of osmosis_utils/utils.py (min_max_norm_range :46-74,
+    min_max_norm_range_percentile :77-114, depth_tensor_to_color_image :748-763, convert_depth :544-566)
+    on seeded depth maps: what osmosis_sampling.py:208-223 applies to the final pred_xstart."""
+    from osmosis_utils import utils as R_u
+    g = torch.Generator().manual_seed(21)
+    d3 = torch.randn(1, 24, 20, generator=g) * 0.7 + 0.1          # [1,H,W] depth channel
+    d4 = torch.randn(1, 3, 12, 10, generator=g)                   # [B=1,C,H,W]
+    const = torch.full((1, 6, 5), 0.25)
+    out = {"d3": npy(d3), "d4": npy(d4), "const": npy(const),
+           "mm_d3": npy(R_u.min_max_norm_range(d3)),
+           "mm_d3_range": npy(R_u.min_max_norm_range(d3, vmin=-1, vmax=3)),
+           "mm_d3_u8": npy(R_u.min_max_norm_range(d3, is_uint8=True)),
+           "mm_d4": npy(R_u.min_max_norm_range(d4)),
+           "mm_const": npy(R_u.min_max_norm_range(const)),
+           "pmm_d3": npy(R_u.min_max_norm_range_percentile(d3, vmin=0, vmax=1, percent_low=0.03, percent_high=0.99,
+                                                           is_uint8=False)),
+           "pmm_d3_u8": npy(R_u.min_max_norm_range_percentile(d3, percent_low=0.1, percent_high=0.9, is_uint8=True)),
+           "pmm_const": npy(R_u.min_max_norm_range_percentile(const, percent_low=0.03, percent_high=0.99))}
+    pmm = R_u.min_max_norm_range_percentile(d3, vmin=0, vmax=1, percent_low=0.03, percent_high=0.99, is_uint8=False)
+    out["color_pmm_d3"] = npy(R_u.depth_tensor_to_color_image(pmm))
+    rep = d3.repeat(3, 1, 1)
+    out["cd_gamma"] = npy(R_u.convert_depth(rep, depth_type="gamma", value="1.4,1.4,1"))
+    out["cd_original"] = npy(R_u.convert_depth(rep, depth_type="original", value="1.4,1.4,1"))
+    out["cd_move"] = npy(R_u.convert_depth(rep, depth_type="move", value=2.0))
+    np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:                 # regenerate selected sections only: gen_golden.py postprocess prior ...
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_schedules()
     gen_blocks()
     gen_tiny_unet()
     gen_loops()
     gen_prior()
+    gen_postprocess()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

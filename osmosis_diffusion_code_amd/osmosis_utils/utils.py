@@ -49,7 +49,7 @@ def depth_code_and_values(depth_type, value):
 def convert_depth(depth, depth_type, **kwargs):
     """Tensor version (host/visualisation use; the sampler's hot path evaluates this inside the
     physics kernels)."""
-    value = get_depth_value(kwargs.get("value", None)) if kwargs.get("value", None) is not None else None
+    value = get_depth_value(kwargs.get("value", None))   # value=None raises NotImplementedError (utils.py:551-552)
     if depth_type == "move":
         return depth + value
     if depth_type == "gamma":
@@ -110,3 +110,58 @@ def set_alternate_length(sample_pattern, time_index, num_timesteps):
     if time_index > sample_pattern["s_start"] * T or time_index < sample_pattern["s_end"] * T:
         return 1
     return sample_pattern["local_M"]
+
+
+# ----------------------------------------------------------------------------- output post-processing (N2)
+# Host-side (CPU tensors, like the reference: the driver works on `pred_xstart.cpu()`).
+def _min_max(img):
+    """(min, max) per image for [B,C,H,W], global for [C,H,W] (utils.py:46-62)."""
+    if img.dim() == 4:
+        flat = img.reshape(img.size(0), -1)
+        return flat.min(dim=1)[0].view(-1, 1, 1, 1), flat.max(dim=1)[0].view(-1, 1, 1, 1)
+    if img.dim() == 3:
+        return img.min(), img.max()
+    raise NotImplementedError
+
+
+def _rescale(img, vmin, vmax, is_uint8):
+    lo, hi = _min_max(img)
+    if lo == hi:            # a batch (numel > 1) raises here exactly like the reference's `if img_min == img_max`
+        out = torch.zeros_like(img)
+    else:
+        out = (img - lo) * ((float(vmax) - float(vmin)) / (hi - lo)) + float(vmin)
+    if is_uint8:
+        out = (255 * out).to(torch.uint8)
+    return out
+
+
+def min_max_norm_range(img, vmin=0, vmax=1, is_uint8=False):
+    """utils.py:46-74: affine map of [min, max] onto [vmin, vmax]; a constant image maps to zeros."""
+    return _rescale(img, vmin, vmax, is_uint8)
+
+
+def min_max_norm_range_percentile(img, vmin=0, vmax=1, percent_low=0., percent_high=1., is_uint8=False):
+    """utils.py:77-114: clamp to the [percent_low, percent_high] quantiles first, then min-max normalise."""
+    lo, hi = torch.quantile(img, q=percent_low), torch.quantile(img, q=percent_high)
+    return _rescale(torch.clamp(img, lo, hi), vmin, vmax, is_uint8)
+
+
+def depth_tensor_to_color_image(tensor_image, colormap="viridis"):
+    """utils.py:748-763: [H,W] / [1,H,W] / [1,1,H,W] depth in [0,1] -> [3,H,W] colour-mapped (float64 like matplotlib)."""
+    import matplotlib
+    cm = matplotlib.colormaps[colormap] if hasattr(matplotlib, "colormaps") else __import__("matplotlib.pyplot").pyplot.get_cmap(colormap)
+    if tensor_image.dim() == 4:
+        tensor_image = tensor_image.squeeze()
+    if tensor_image.dim() == 3:
+        tensor_image = tensor_image[0]
+    assert tensor_image.dim() == 2
+    rgba = cm(tensor_image.numpy())
+    return torch.tensor(rgba[:, :, 0:3]).permute(2, 0, 1)
+
+
+def psnr(img, ref, data_range=1.0):
+    """Peak signal-to-noise ratio in dB per image ([B,C,H,W] -> [B], [C,H,W] -> scalar tensor).  The reference
+    computes no quality metric; SURVEY.md 8(f) N2 asks for one for the simulated config."""
+    d = (img.double() - ref.double()) ** 2
+    mse = d.flatten(1).mean(dim=1) if d.dim() == 4 else d.mean()
+    return 10.0 * torch.log10((float(data_range) ** 2) / mse)

@@ -1,0 +1,166 @@
+"""the per-image driver contract and output post-processing.
+
+CPU tests: the product's host-side helpers (osmosis_utils/utils.py, sampling.postprocess) and the oracle
+restatement (oracle/postprocess_ref.py) against golden vectors produced by the reference's own functions
+(tests/golden/postprocess.npz, oracle/tools/gen_golden.py::gen_postprocess).
+GPU test: sampling.restore_image end-to-end on the tiny seeded UNet against the oracle loop + oracle recomposition.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess_ref as PR
+from osmosis_diffusion_code_amd import sampling
+from osmosis_diffusion_code_amd.osmosis_utils import utils as U
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def test_min_max_norm_range_matches_reference():
+    assert np.array_equal(U.min_max_norm_range(t("d3")).numpy(), G["mm_d3"])
+    assert np.array_equal(U.min_max_norm_range(t("d3"), vmin=-1, vmax=3).numpy(), G["mm_d3_range"])
+    assert np.array_equal(U.min_max_norm_range(t("d3"), is_uint8=True).numpy(), G["mm_d3_u8"])
+    assert np.array_equal(U.min_max_norm_range(t("d4")).numpy(), G["mm_d4"])
+    assert np.array_equal(U.min_max_norm_range(t("const")).numpy(), G["mm_const"])      # constant image -> zeros
+    with pytest.raises(NotImplementedError):
+        U.min_max_norm_range(torch.zeros(4, 4))
+
+
+def test_percentile_norm_and_colour_match_reference():
+    pmm = U.min_max_norm_range_percentile(t("d3"), vmin=0, vmax=1, percent_low=0.03, percent_high=0.99)
+    assert np.array_equal(pmm.numpy(), G["pmm_d3"])
+    assert np.array_equal(U.min_max_norm_range_percentile(t("d3"), percent_low=0.1, percent_high=0.9,
+                                                          is_uint8=True).numpy(), G["pmm_d3_u8"])
+    assert np.array_equal(U.min_max_norm_range_percentile(t("const"), percent_low=0.03, percent_high=0.99).numpy(),
+                          G["pmm_const"])
+    col = U.depth_tensor_to_color_image(pmm)
+    assert col.shape == (3, 24, 20) and np.array_equal(col.numpy(), G["color_pmm_d3"])
+
+
+def test_convert_depth_matches_reference_and_raises_like_it():
+    rep = t("d3").repeat(3, 1, 1)
+    assert np.array_equal(U.convert_depth(rep, depth_type="gamma", value="1.4,1.4,1").numpy(), G["cd_gamma"])
+    assert np.array_equal(U.convert_depth(rep, depth_type="original", value="1.4,1.4,1").numpy(), G["cd_original"])
+    assert np.array_equal(U.convert_depth(rep, depth_type="move", value=2.0).numpy(), G["cd_move"])
+    with pytest.raises(NotImplementedError):
+        U.convert_depth(rep, depth_type="original", value=None)      # utils.py:551-552
+    with pytest.raises(NotImplementedError):
+        U.convert_depth(rep, depth_type="log", value=1.0)
+
+
+def test_oracle_restatement_matches_reference():
+    assert np.allclose(PR.min_max_norm_range(G["d3"]), G["mm_d3"], atol=1e-6)
+    assert np.allclose(PR.min_max_norm_range(G["d4"]), G["mm_d4"], atol=1e-6)
+    assert np.array_equal(PR.min_max_norm_range(G["const"]), G["mm_const"])
+    assert np.allclose(PR.min_max_norm_range_percentile(G["d3"], 0, 1, 0.03, 0.99), G["pmm_d3"], atol=1e-6)
+    rep = np.repeat(G["d3"], 3, axis=0)
+    assert np.allclose(PR.convert_depth(rep, "gamma", "1.4,1.4,1"), G["cd_gamma"], atol=1e-6)
+    assert np.allclose(PR.convert_depth(rep, "original", "1.4,1.4,1"), G["cd_original"], atol=1e-7)
+    assert np.allclose(PR.convert_depth(rep, "move", 2.0), G["cd_move"], atol=1e-7)
+
+
+OPS = {
+    "underwater_physical_revised": dict(phi_a=[1.1, 0.95, 0.9], phi_b=[0.9, 0.8, 0.7], phi_inf=[0.2, 0.4, 0.5]),
+    "underwater_physical": dict(phi_ab=[1.0, 0.9, 0.8], phi_inf=[0.2, 0.4, 0.5]),
+    "haze_physical": dict(phi_ab=[0.8], phi_inf=[0.7, 0.7, 0.7]),
+}
+
+
+@pytest.mark.parametrize("name", list(OPS))
+@pytest.mark.parametrize("depth_type,value", [("gamma", "1.4,1.4,1"), ("original", "1.4,1.4,1")])
+def test_postprocess_matches_oracle_recomposition(name, depth_type, value):
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(1, 4, 16, 12, generator=g) * 0.6
+    ref = torch.rand(1, 3, 16, 12, generator=g) * 1.6 - 0.8
+    phi = {k: torch.tensor(v, dtype=torch.float32).view(1, -1, 1, 1) for k, v in OPS[name].items()}
+    post = sampling.postprocess(x0, phi, ref, {"name": name, "depth_type": depth_type, "value": value}, loss=[1.5])
+    want = PR.recompose(x0[0].numpy(), {k: np.asarray(v) for k, v in OPS[name].items()}, ref[0].numpy(), name,
+                        depth_type, value)
+    for k in ("rgb_01", "rgb_01_clip", "depth_calc", "backscatter", "attenuation", "forward_predicted", "degraded",
+              "rgb_recon"):
+        assert np.allclose(post[k].numpy(), want[k], atol=2e-6, rtol=2e-6), k
+    assert abs(post["norm_loss_final"] - want["norm_loss_final"]) <= 1.5e-3
+    assert np.allclose(post["depth_mm"].numpy(), PR.min_max_norm_range(x0[0, 3:4].numpy()), atol=1e-6)
+    assert np.allclose(post["depth_pmm"].numpy(), PR.min_max_norm_range_percentile(x0[0, 3:4].numpy(), 0, 1, 0.03, 0.99),
+                       atol=1e-6)
+    assert sampling.depth_color(post).shape == (3, 16, 12)
+
+
+def test_driver_helpers():
+    assert sampling.global_iterations({"pattern": "original"}) == 1
+    assert sampling.global_iterations({"pattern": "pcgs", "global_N": 3}) == 3
+    with pytest.raises(ValueError, match="Unrecognized sample pattern"):
+        sampling.global_iterations({"pattern": "other"})
+    y = torch.tensor([-1.0, 0.0, 1.0])
+    assert torch.allclose(sampling.degamma(y), torch.tensor([-1.0, 2 * 0.5 ** 2.2 - 1, 1.0]))
+    a, b = torch.rand(2, 3, 8, 8), torch.rand(2, 3, 8, 8)
+    p = U.psnr(a, b)
+    assert p.shape == (2,) and abs(float(p[0]) - PR.psnr(a[0].numpy(), b[0].numpy())) < 1e-9
+
+
+@pytest.mark.gpu
+def test_restore_image_end_to_end_matches_oracle():
+    """sampling.restore_image (fresh operator / conditioner / sampler, degamma, seeded x_T, guided loop on the HIP
+    UNet, post-processing) vs the CPU oracle loop + oracle recomposition on the last 3 steps of a 100-step chain."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as UR
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    dev = "cuda:0"
+    kw = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2",
+              attention_resolutions="128,64", num_head_channels=16, num_heads=4, learn_sigma=True,
+              use_scale_shift_norm=True, resblock_updown=True, pretrain_model="osmosis")
+    ucfg = UR.UNetConfig.from_create_model_kwargs(**kw)
+    sd = UR.seeded_state_dict(ucfg, 1234)
+    model = unet.create_model(**kw)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    okw = dict(depth_type="gamma", value="1.4,1.4,1", phi_ab="1.0", phi_inf="0.14, 0.29, 0.49")
+    ckw = dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1", scale="7,7,7,0.9",
+               gradient_x_prev=True, gradient_clip="True,0.005")
+    pattern = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0,
+                   n_iter=20, start_guidance=1, stop_guidance=0)
+    aux = {"avrg_loss": 0.5, "val_loss": 20}
+    cfg = dict(
+        measurement=dict(operator=dict(name="haze_physical", optimizer="sgd", phi_ab_eta="1e-5", phi_inf_eta="1e-5",
+                                       phi_ab_learn_flag=True, phi_inf_learn_flag=True, **okw),
+                         noise=dict(name="clean")),
+        conditioning=dict(method="osmosis", params=ckw), sample_pattern=pattern, aux_loss=dict(aux_loss=aux),
+        diffusion=dict(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                       model_var_type="learned_range", dynamic_threshold=False, clip_denoised=False,
+                       rescale_timesteps=False, timestep_respacing="100"),
+        unet_model=dict(pretrain_model="osmosis"), manual_seed=3, degamma_input=True, rgb_guidance=False)
+    g = torch.Generator().manual_seed(11)
+    ref = torch.rand(1, 3, 32, 32, generator=g) * 1.6 - 0.8
+    noise = torch.randn(3, 1, 4, 32, 32, generator=g)
+    nd = noise.to(dev)
+    res = sampling.restore_image(model, ref.to(dev), cfg, index_range=(2, 0), noise_fn=lambda k, shape: nd[k])
+    assert len(res) == 1
+    post = res[0]
+
+    torch.manual_seed(3)
+    x_T = torch.randn(1, 4, 32, 32, device=dev).cpu()          # what the driver drew
+    y = sampling.degamma(ref)
+    assert torch.allclose(post["measurement"], y, atol=1e-6)
+    rop = D.PhysOperator("haze_physical", batch_size=1, **okw)
+    rg = D.OsmosisGuidance(rop, n_iter=20, scale=ckw["scale"], gradient_clip=ckw["gradient_clip"], aux=aux)
+    tb = D.Tables(gd.get_named_beta_schedule("linear", 1000), range(0, 30, 10))
+    rimg, rvars, rloss, rx0 = D.p_sample_loop(lambda x, t: UR.unet_forward(sd, ucfg, x, t), tb, x_T, y, rg, pattern,
+                                              [n for n in noise])
+    assert float((post["sample"] - rimg).abs().max()) < 1e-3
+    assert float((post["pred_xstart"] - rx0).abs().max()) < 1e-3
+    assert np.allclose(post["loss"], rloss, rtol=1e-4)
+    want = PR.recompose(rx0[0].numpy(), {k: v.numpy().ravel() for k, v in rvars.items()}, ref[0].numpy(),
+                        "haze_physical", "gamma", "1.4,1.4,1")
+    for k in ("rgb_01_clip", "forward_predicted", "degraded", "rgb_recon"):
+        assert np.allclose(post[k].numpy(), want[k], atol=1e-3), k
+    assert abs(post["norm_loss_final"] - want["norm_loss_final"]) < 5e-3
+    assert float(U.psnr(post["rgb_01_clip"], torch.from_numpy(want["rgb_01_clip"]))) > 55.0
