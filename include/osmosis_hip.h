@@ -91,6 +91,32 @@ int osm_gemm(const osm_gemm_desc* d, void* stream);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
 
+/* ------------------------------------------------------------------ fused attention core (low resolutions)
+ * QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467) for T in {64, 256} tokens and
+ * ch in {16, 32, 64}:  a = softmax(scale * q k^T) v  per (image, head), logits never leave the CU.
+ * qkv is the [B*T][ldqkv] token matrix; head h has q / k / v at columns q_off / k_off / v_off + h*head_stride
+ * (legacy order: offsets 0, ch, 2ch, stride 3ch; new order: 0, C, 2C, stride ch).  Forward writes `out`
+ * [B*T][ldout] (head h at columns h*ch).  Backward takes d(out) in `dout` and writes dq | dk | dv into `dqkv`
+ * (same column layout as qkv; every q/k/v column of the used heads is overwritten); `ws` is scratch of
+ * 2*B*heads*T*T floats.  P is recomputed in the backward: nothing is kept from the forward. */
+typedef struct osm_attn_desc {
+  const float* qkv;
+  long long ldqkv;
+  int q_off, k_off, v_off, head_stride;
+  int B, T, heads, ch;
+  float scale;
+  float* out;
+  long long ldout;
+  const float* dout;
+  long long lddout;
+  float* dqkv;
+  long long lddqkv;
+  float* ws;
+} osm_attn_desc;
+int osm_attn_small_supported(int T, int ch);
+int osm_attn_small_fwd(const osm_attn_desc* d, void* stream);
+int osm_attn_small_bwd(const osm_attn_desc* d, void* stream);
+
 /* ------------------------------------------------------------------ GroupNorm(32)+SiLU(+FiLM)
  * nn.py:17-19,93-100 GroupNorm32; unet.py:263,287 SiLU; unet.py:327-331 scale-shift.
  * stats: [B][G][2] = (mean, rstd).  part: workspace of B*nchunk*G*2 floats,

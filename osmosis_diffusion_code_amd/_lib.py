@@ -44,6 +44,14 @@ class GemmDesc(C.Structure):
                 ("splitk", C.c_int), ("splitk_ws", C.c_void_p)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("ldqkv", C.c_longlong),
+                ("q_off", C.c_int), ("k_off", C.c_int), ("v_off", C.c_int), ("head_stride", C.c_int),
+                ("B", C.c_int), ("T", C.c_int), ("heads", C.c_int), ("ch", C.c_int), ("scale", C.c_float),
+                ("out", C.c_void_p), ("ldout", C.c_longlong), ("dout", C.c_void_p), ("lddout", C.c_longlong),
+                ("dqkv", C.c_void_p), ("lddqkv", C.c_longlong), ("ws", C.c_void_p)]
+
+
 class PhysDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("depth_type", C.c_int), ("dval", C.c_float * 3),
                 ("weight_type", C.c_int), ("wdepth_type", C.c_int), ("wval", C.c_float * 3),
@@ -62,6 +70,9 @@ _SIGS = {
     "osm_gemm": [C.POINTER(GemmDesc), _P],
     "osm_pack_conv_weight_bf16s": [_P, _P, _P, _I, _I, _I, _I, _P],
     "osm_splitk_hint": [_I, _I, _I, _I, _I],
+    "osm_attn_small_supported": [_I, _I],
+    "osm_attn_small_fwd": [C.POINTER(AttnDesc), _P],
+    "osm_attn_small_bwd": [C.POINTER(AttnDesc), _P],
     "osm_gn_nchunk": [_I],
     "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
     "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P],

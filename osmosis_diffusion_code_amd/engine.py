@@ -290,18 +290,26 @@ class UNetEngine:
         qkv = self._buf(M, 3 * C)
         self._conv(xn, blk.qkv, qkv, hw)
         nmat = B * nh
-        S = self._scr_flat("s0", nmat * T * T)
         alpha = 1.0 / math.sqrt(ch)     # (q*ch^-1/4)·(k*ch^-1/4)
-        self._gemm(qkv.t, 3 * C, qkv.t, 3 * C, S, T, T, T, ch, b_kn=False, alpha=alpha, nb1=nh, nb2=B,
-                 sA=(hs, T * 3 * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), a_off=qo, b_off=ko)
-        P = self._small(nmat * T * T)
-        PT = self._small(nmat * T * T)
-        ops.softmax_rows(S, P, PT, nmat, T)
         a = self._scr("b", M, C)
-        self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
-                 sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
+        # fused core: measured faster at T = 64 (3 launches instead of 14); at T = 256 its fp32 FMA work sits on
+        # only 64 workgroups and the unfused GEMM pipeline wins (OSM_ATTN_FUSED=all / 0 to force either way)
+        mode = os.environ.get("OSM_ATTN_FUSED", "64")
+        fused = ops.attn_small_supported(T, ch) and (mode == "all" or (mode != "0" and T <= 64))
+        P = PT = None
+        if fused:      # 8x8 / 16x16: logits stay on the CU, one launch, nothing kept for the backward
+            ops.attn_small_fwd(qkv, a, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+        else:
+            S = self._scr_flat("s0", nmat * T * T)
+            self._gemm(qkv.t, 3 * C, qkv.t, 3 * C, S, T, T, T, ch, b_kn=False, alpha=alpha, nb1=nh, nb2=B,
+                       sA=(hs, T * 3 * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), a_off=qo, b_off=ko)
+            P = self._small(nmat * T * T)
+            PT = self._small(nmat * T * T)
+            ops.softmax_rows(S, P, PT, nmat, T)
+            self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+                       sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
         self._conv(a, blk.proj, dst, hw, res=x)
-        blk.saved = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw)
+        blk.saved = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused)
         return hw
 
     def _attn_bwd(self, blk: _Attn, dy: Mat, dx_dst: Mat, accumulate: bool):
@@ -317,21 +325,25 @@ class UNetEngine:
         alpha = 1.0 / math.sqrt(ch)
         da = self._scr("a", M, C)
         self._conv(dy, blk.proj, da, hw, dgrad=True)
-        dP = self._scr_flat("s0", nmat * T * T)
-        self._gemm(da.t, C, qkv.t, 3 * C, dP, T, T, T, ch, b_kn=False, nb1=nh, nb2=B,
-                 sA=(ch, T * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), b_off=vo)
-        dS = self._scr_flat("s1", nmat * T * T)
-        dST = self._scr_flat("s2", nmat * T * T)
-        ops.softmax_rows_bwd(P, dP, dS, dST, nmat, T)
         dqkv = self._scr("b", M, 3 * C)
-        sQ = (hs, T * 3 * C)
-        # dq = alpha * dS k ; dk = alpha * dS^T q ; dv = P^T da
-        self._gemm(dS, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
-                 sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=ko, c_off=qo)
-        self._gemm(dST, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
-                 sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=qo, c_off=ko)
-        self._gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
-                 sA=(T * T, nh * T * T), sB=(ch, T * C), sC=sQ, c_off=vo)
+        if s["fused"]:
+            ws = self._scr_flat("s0", 2 * nmat * T * T)
+            ops.attn_small_bwd(qkv, da, dqkv, ws, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+        else:
+            dP = self._scr_flat("s0", nmat * T * T)
+            self._gemm(da.t, C, qkv.t, 3 * C, dP, T, T, T, ch, b_kn=False, nb1=nh, nb2=B,
+                       sA=(ch, T * C), sB=(hs, T * 3 * C), sC=(T * T, nh * T * T), b_off=vo)
+            dS = self._scr_flat("s1", nmat * T * T)
+            dST = self._scr_flat("s2", nmat * T * T)
+            ops.softmax_rows_bwd(P, dP, dS, dST, nmat, T)
+            sQ = (hs, T * 3 * C)
+            # dq = alpha * dS k ; dk = alpha * dS^T q ; dv = P^T da
+            self._gemm(dS, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+                       sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=ko, c_off=qo)
+            self._gemm(dST, T, qkv.t, 3 * C, dqkv.t, 3 * C, T, ch, T, b_kn=True, alpha=alpha, nb1=nh, nb2=B,
+                       sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=qo, c_off=ko)
+            self._gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
+                       sA=(T * T, nh * T * T), sB=(ch, T * C), sC=sQ, c_off=vo)
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
         if accumulate:

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, GemmDesc, PhysDesc, call, current_stream_ptr, ptr, query
+from ._lib import AttnDesc, ConvDesc, GemmDesc, PhysDesc, call, current_stream_ptr, ptr, query
 
 
 @dataclass
@@ -96,6 +96,34 @@ def gemm(A: torch.Tensor, lda: int, Bm: torch.Tensor, ldb: int, Cm: torch.Tensor
     d.sC1, d.sC2 = sC
     d.splitk, d.splitk_ws = splitk, ptr(splitk_ws)
     call("osm_gemm", C.byref(d), _s(), keep=(A, Bm, Cm, bias, res, splitk_ws))
+
+
+def attn_small_supported(T: int, ch: int) -> bool:
+    return bool(query("osm_attn_small_supported", T, ch))
+
+
+def _attn_desc(qkv: Mat, B, T, heads, ch, offsets, head_stride, scale) -> AttnDesc:
+    d = AttnDesc()
+    d.qkv, d.ldqkv = qkv.p, qkv.ld
+    d.q_off, d.k_off, d.v_off = offsets
+    d.head_stride, d.B, d.T, d.heads, d.ch, d.scale = head_stride, B, T, heads, ch, scale
+    return d
+
+
+def attn_small_fwd(qkv: Mat, out: Mat, B, T, heads, ch, offsets, head_stride, scale):
+    """out = softmax(scale q k^T) v per (image, head) in one launch (T in {64, 256})."""
+    d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
+    d.out, d.ldout = out.p, out.ld
+    call("osm_attn_small_fwd", C.byref(d), _s(), keep=(d, qkv.t, out.t))
+
+
+def attn_small_bwd(qkv: Mat, dout: Mat, dqkv: Mat, ws: torch.Tensor, B, T, heads, ch, offsets, head_stride, scale):
+    """dq | dk | dv (qkv column layout) from d(out); ws: 2*B*heads*T*T floats of scratch."""
+    d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
+    d.dout, d.lddout = dout.p, dout.ld
+    d.dqkv, d.lddqkv = dqkv.p, dqkv.ld
+    d.ws = ptr(ws)
+    call("osm_attn_small_bwd", C.byref(d), _s(), keep=(d, qkv.t, dout.t, dqkv.t, ws))
 
 
 def splitk_hint(M, N, K, taps, nbatch=1) -> int:

@@ -213,6 +213,49 @@ def test_softmax_rows_fwd_bwd(ops, nmat, T):
     assert torch.equal(dSTd.cpu(), dSd.cpu().transpose(1, 2))
 
 
+@pytest.mark.parametrize("new_order", [False, True])
+@pytest.mark.parametrize("B,T,heads,ch", [(1, 64, 4, 16), (2, 256, 2, 64), (1, 256, 3, 32), (2, 64, 2, 64)])
+def test_attn_small_fwd_bwd(ops, B, T, heads, ch, new_order):
+    """Fused attention core vs the reference formulation (unet.py:416-433 legacy / :459-467 new order) in fp64."""
+    g = torch.Generator().manual_seed(T + heads + ch)
+    C = heads * ch
+    qkv = torch.randn(B, T, 3 * C, generator=g)
+    dout = torch.randn(B, T, C, generator=g)
+    if new_order:
+        offs, hs = (0, C, 2 * C), ch
+    else:
+        offs, hs = (0, ch, 2 * ch), 3 * ch
+    x = qkv.double().requires_grad_(True)
+
+    def head(comp, h):
+        return x[:, :, offs[comp] + h * hs: offs[comp] + h * hs + ch]
+    outs = []
+    for h in range(heads):
+        w = torch.softmax(torch.einsum("btc,bsc->bts", head(0, h), head(1, h)) / math.sqrt(ch), dim=-1)
+        outs.append(torch.einsum("bts,bsc->btc", w, head(2, h)))
+    ref = torch.cat(outs, dim=-1)
+    (dref,) = torch.autograd.grad(ref, x, dout.double())
+
+    qd = qkv.reshape(B * T, 3 * C).to(DEV)
+    od = torch.full((B * T, C), float("nan"), device=DEV)
+    ops.attn_small_fwd(ops.Mat.of(qd), ops.Mat.of(od), B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch))
+    assert relerr(od.cpu().reshape(B, T, C), ref.float()) < 3e-6
+    dq = torch.full((B * T, 3 * C), float("nan"), device=DEV)
+    ws = torch.empty(2 * B * heads * T * T, device=DEV)
+    ops.attn_small_bwd(ops.Mat.of(qd), ops.Mat.of(dout.reshape(B * T, C).to(DEV)), ops.Mat.of(dq), ws, B, T, heads,
+                       ch, offs, hs, 1.0 / math.sqrt(ch))
+    assert relerr(dq.cpu().reshape(B, T, 3 * C), dref.float()) < 5e-6
+
+
+def test_attn_small_rejects_other_shapes(ops):
+    from osmosis_diffusion_code_amd._lib import OsmosisHipError
+    assert not ops.attn_small_supported(1024, 64) and not ops.attn_small_supported(64, 48)
+    q = torch.zeros(128, 3 * 64, device=DEV)
+    with pytest.raises(OsmosisHipError, match="unsupported shape"):
+        ops.attn_small_fwd(ops.Mat.of(q), ops.Mat.of(torch.zeros(128, 64, device=DEV)), 1, 128, 1, 64, (0, 64, 128),
+                           192, 0.125)
+
+
 def test_timestep_embedding_and_linear(ops):
     from oracle.unet_ref import timestep_embedding
     t = torch.tensor([0.0, 1.0, 37.0, 999.0])
