@@ -55,6 +55,11 @@ typedef struct osm_conv_desc {
   int wfmt;            /* weight image: 0 = fp32 [tap][Cout][Cin] (exact-f32 MFMA);
                           3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
                           (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16) */
+  const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 16, H >= 8 only):
+                          x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
+                          (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
+                          osm_gn_prep; NULL = plain convolution */
+  int gn_silu;           /* act = SiLU when != 0 */
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
 
@@ -131,6 +136,11 @@ int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, 
 int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
                float* part, float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, void* stream);
+/* Statistics only + the per-channel table a convolution applies itself (osm_conv_desc.gn_table):
+ * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
+int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
+                const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
+                void* stream);
 /* dx = dGN(dy) (+ addend).  part: workspace as above. */
 int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                const float* addend, long long ldadd, int B, int HW, int C, int G,

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("y", C.c_void_p), ("splitk_ws", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("ksize", C.c_int), ("splitk", C.c_int), ("accumulate", C.c_int),
-                ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong), ("wfmt", C.c_int)]
+                ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong), ("wfmt", C.c_int),
+                ("gn_table", C.c_void_p), ("gn_silu", C.c_int)]
 
 
 class GemmDesc(C.Structure):
@@ -77,6 +78,7 @@ _SIGS = {
     "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
     "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P],
     "osm_gn_fwd": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _I, _P],
+    "osm_gn_prep": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _P, _P],
     "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P],
     "osm_pool2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_upsample2x": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],

@@ -26,7 +26,7 @@ constexpr int H_PLANE = HALO_ROWS * S_ROWB;      // bytes per plane
 constexpr int B_RING = 3;                        // weight-fragment register sets (divides the 18 steps of a slab)
 constexpr int B_DIST = 2;                        // steps between a weight fragment's load and its use
 
-template <int NP>
+template <int NP, bool GNF>
 __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const unsigned char* a_rd = As + ((lr >> 4) * (4 * HALO_P) + (lr & 15)) * S_ROWB + 16 * lk;
 
   float4 ra[6];
+  float4 gm, gr, gg, gb;   // GNF: mean | rstd | g | b of this thread's 4 channels of the current slab
+  gm = gr = gg = gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
   unsigned okm = 0;
   uint4 bq[B_RING][NP];   // rolling weight-fragment sets: step g lives in bq[g % B_RING]
 
@@ -101,6 +104,13 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
     okm = cok_ ? vmask : 0u;                                                               \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                          \
       ra[j] = *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)));     \
+    if (GNF) {                                                                             \
+      const float* gt_ = gtab + (cok_ ? (cc_) * BK + 4 * cg : 0);                          \
+      gm = *reinterpret_cast<const float4*>(gt_);                                          \
+      gr = *reinterpret_cast<const float4*>(gt_ + p.K);                                    \
+      gg = *reinterpret_cast<const float4*>(gt_ + 2 * p.K);                                \
+      gb = *reinterpret_cast<const float4*>(gt_ + 3 * p.K);                                \
+    }                                                                                      \
   }
 // weight fragments of step s_ (tap s_/2, k16 half s_&1) of slab cc_
 #define OSM_H_LOAD_B(slot_, cc_, s_)                                                       \
@@ -137,7 +147,17 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         uint2 pl[NP];
-        split_planes<NP>(sel4((okm >> j) & 1u, ra[j]), pl);
+        float4 v = ra[j];
+        if (GNF) {   // GroupNorm(+FiLM)(+SiLU) of the input on the fly; the zero padding applies to the result
+          v.x = ((v.x - gm.x) * gr.x) * gg.x + gb.x;
+          v.y = ((v.y - gm.y) * gr.y) * gg.y + gb.y;
+          v.z = ((v.z - gm.z) * gr.z) * gg.z + gb.z;
+          v.w = ((v.w - gm.w) * gr.w) * gg.w + gb.w;
+          if (p.gn_silu) {
+            v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w);
+          }
+        }
+        split_planes<NP>(sel4((okm >> j) & 1u, v), pl);
 #pragma unroll
         for (int q2 = 0; q2 < NP; ++q2)
           *reinterpret_cast<uint2*>(As + q2 * H_PLANE + woff[j]) = pl[q2];

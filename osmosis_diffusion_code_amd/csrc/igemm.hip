@@ -55,6 +55,8 @@ struct IGemmParams {
   int mtiles, ntiles;
   int nchunks;
   int nbatch;
+  const float* gn_table;   // halo kernel: fused GroupNorm(+FiLM)(+SiLU) of the input, [B][4][K]
+  int gn_silu;
 };
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
@@ -347,10 +349,14 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
-    if (wfmt == 3)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3>), g2, dim3(256), 0, st, p.A, Bp, p);
+    if (wfmt == 3 && p.gn_table)
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3, true>), g2, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 3)
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3, false>), g2, dim3(256), 0, st, p.A, Bp, p);
+    else if (wfmt == 2 && p.gn_table)
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, true>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 2)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2>), g2, dim3(256), 0, st, p.A, Bp, p);
+      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, false>), g2, dim3(256), 0, st, p.A, Bp, p);
     else
       return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
   } else if (wfmt != 0) {
@@ -424,6 +430,13 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   p.lda = d->ldx; p.ldb = d->Cin; p.ldc = d->ldy; p.ldr = d->ldr;
   p.tapstrideB = (long long)d->Cout * d->Cin;
   p.nb1 = 1; p.nbatch = 1;
+  if (d->gn_table) {
+    OSM_REQUIRE(d->wfmt != 0 && d->ksize == 3 && d->W >= 16 && d->H >= 8 && halo_enabled(),
+                "osm_conv2d_nhwc: gn_table needs the halo-tile kernel (3x3, split-bf16 weights, W >= 16, H >= 8)");
+    OSM_REQUIRE(osm::aligned16(d->gn_table), "osm_conv2d_nhwc: gn_table must be 16-byte aligned");
+    p.gn_table = d->gn_table;
+    p.gn_silu = d->gn_silu;
+  }
   if (d->wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
     OSM_REQUIRE(d->wfmt == 2 || d->wfmt == 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
     p.nt32 = (d->Cout + 31) / 32;

@@ -175,6 +175,49 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// Finalize (as gn_finalize_kernel<0>) and expand to the per-channel table a convolution applies while staging:
+// table[b][0..3][c] = mean | rstd | gamma (1 + scale) | beta (1 + scale) + shift.   One wave per (b, g).
+__global__ __launch_bounds__(256) void gn_finalize_table_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                 float* __restrict__ table, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ film,
+                                                                 long long ldf, int B, int G, int C, int nchunk, double n,
+                                                                 float eps) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B * G) return;
+  const int b = i / G, g = i % G;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < nchunk; k += 64) {
+    const float2 pp = *reinterpret_cast<const float2*>(part + (((long long)b * nchunk + k) * G + g) * 2);
+    s1 += (double)pp.x;
+    s2 += (double)pp.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (lane == 0) {
+    out[i * 2] = mean;
+    out[i * 2 + 1] = rstd;
+  }
+  const int gs = C / G;
+  float* t = table + (long long)b * 4 * C;
+  for (int e = lane; e < gs; e += 64) {
+    const int c = g * gs + e;
+    const float sc = film ? film[(long long)b * ldf + c] : 0.f;
+    const float sh = film ? film[(long long)b * ldf + C + c] : 0.f;
+    t[c] = mean;
+    t[C + c] = rstd;
+    t[2 * C + c] = gamma[c] * (1.0f + sc);
+    t[3 * C + c] = beta[c] * (1.0f + sc) + sh;
+  }
+}
+
 // MODE 0: y = act(GN(x)).   MODE 1: dx = dGN(dy) (+ addend)
 // Same (chunk, image) grid and (column-vector, row) thread mapping as the reduce pass: a thread owns
 // fixed channel vector(s), so gamma/beta/FiLM/statistics are loaded once and the row loop is pure
@@ -516,6 +559,23 @@ extern "C" int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C,
   int rc = check_common(a, "osm_gn_stats");
   if (rc) return rc;
   return run_reduce<0>(a, stats, (hipStream_t)stream);
+}
+
+extern "C" int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part,
+                           float* stats, const float* gamma, const float* beta, const float* film,
+                           long long ldfilm, float* table, void* stream) {
+  OSM_REQUIRE(x && part && stats && gamma && beta && table, "osm_gn_prep: null pointer");
+  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_prep: ldfilm smaller than 2*C");
+  GNArgs a{};
+  a.x = x; a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
+  int rc = check_common(a, "osm_gn_prep");
+  if (rc) return rc;
+  rc = run_reduce<0>(a, stats, (hipStream_t)stream, false);
+  if (rc) return rc;
+  const int n = B * G;
+  hipLaunchKernelGGL(gn_finalize_table_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, stats, table,
+                     gamma, beta, film, ldfilm, B, G, C, a.nchunk, (double)HW * (C / G), eps);
+  return osm::check_launch("gn_finalize_table_kernel");
 }
 
 extern "C" int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C,

@@ -94,6 +94,7 @@ class UNetEngine:
         # OSM_GRAPH=1: replay the recorded plans as hipGraphs instead of ~700 individual launches
         self.use_graph = os.environ.get("OSM_GRAPH", "0") == "1"
         self._fwd_graph = self._bwd_graph = None
+        self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0"   # GN apply inside the consuming 3x3 conv
 
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
@@ -159,7 +160,7 @@ class UNetEngine:
         return t[:n]
 
     def _conv(self, x: Mat, cv: _Conv, y: Mat, hw: Tuple[int, int], dgrad=False, res: Optional[Mat] = None,
-              accumulate=False):
+              accumulate=False, gn_table=None, gn_silu=True):
         H, W = hw
         M = self.B * H * W
         cin = cv.cout if dgrad else cv.cin
@@ -170,7 +171,22 @@ class UNetEngine:
         if sk > 1:
             ws = self._scr_flat("splitk", sk * M * cout)
         ops.conv2d(x, cv.wd if dgrad else cv.wf, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
-                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt)
+                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt, gn_table=gn_table, gn_silu=gn_silu)
+
+    def _gn_conv(self, x: Mat, norm: _Norm, st, cv: _Conv, y: Mat, hw, film=None, res: Optional[Mat] = None):
+        """y = conv3x3(SiLU(GN(+FiLM)(x))) (+res).  Where the halo-tile kernel runs (split-bf16 weights, W >= 16,
+        H >= 8) the normalised tensor is never materialised: statistics -> per-channel table -> applied by the
+        convolution while it stages its input; otherwise GN writes a scratch tensor first."""
+        B = self.B
+        H, W = hw
+        if self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256:
+            table = self._scr_flat("gnt", B * 4 * x.cols)
+            ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
+            self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True)
+        else:
+            a = self._scr("a", B * H * W, x.cols)
+            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
+            self._conv(a, cv, y, hw, res=res)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):
@@ -179,36 +195,38 @@ class UNetEngine:
         HW = H * W
         M = B * HW
         st1 = self._small(B * G * 2)
-        a1 = self._scr("a", M, blk.cin)
-        ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True)
-        if blk.up:
-            ho, wo = 2 * H, 2 * W
-            a1r = self._scr("b", B * ho * wo, blk.cin)
-            ops.upsample2x(a1, a1r, B, H, W, 1.0)
-            xs = self._scr("c", B * ho * wo, blk.cin)
-            ops.upsample2x(x, xs, B, H, W, 1.0)
-        elif blk.down:
-            ho, wo = H // 2, W // 2
-            a1r = self._scr("b", B * ho * wo, blk.cin)
-            ops.pool2x2(a1, a1r, B, H, W, 0.25)
-            xs = self._scr("c", B * ho * wo, blk.cin)
-            ops.pool2x2(x, xs, B, H, W, 0.25)
+        if blk.up or blk.down:
+            a1 = self._scr("a", M, blk.cin)
+            ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True)
+            if blk.up:
+                ho, wo = 2 * H, 2 * W
+                a1r = self._scr("b", B * ho * wo, blk.cin)
+                ops.upsample2x(a1, a1r, B, H, W, 1.0)
+                xs = self._scr("c", B * ho * wo, blk.cin)
+                ops.upsample2x(x, xs, B, H, W, 1.0)
+            else:
+                ho, wo = H // 2, W // 2
+                a1r = self._scr("b", B * ho * wo, blk.cin)
+                ops.pool2x2(a1, a1r, B, H, W, 0.25)
+                xs = self._scr("c", B * ho * wo, blk.cin)
+                ops.pool2x2(x, xs, B, H, W, 0.25)
+            Mo = B * ho * wo
+            h1 = self._buf(Mo, blk.cout)
+            self._conv(a1r, blk.c1, h1, (ho, wo))
         else:
             ho, wo = H, W
-            a1r, xs = a1, x
-        Mo = B * ho * wo
-        h1 = self._buf(Mo, blk.cout)
-        self._conv(a1r, blk.c1, h1, (ho, wo))
+            xs = x
+            Mo = M
+            h1 = self._buf(Mo, blk.cout)
+            self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
-        a2 = self._scr("a", Mo, blk.cout)
-        ops.gn_fwd(h1, a2, B, ho * wo, G, self.gn_part, st2, blk.n2.g, blk.n2.b, film=film, silu=True)
         if blk.skip is not None:
             self._conv(xs, blk.skip, dst, (ho, wo))
             res = dst
         else:
             res = xs
-        self._conv(a2, blk.c2, dst, (ho, wo), res=res)
+        self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res)
         blk.saved = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo))
         return (ho, wo)
 
@@ -458,10 +476,8 @@ class UNetEngine:
         # ---- head: GN, SiLU, conv3x3 -> NCHW
         self.h_last = h
         self.st_out = self._small(B * G * 2)
-        a = self._scr("a", B * H * W, h.cols)
-        ops.gn_fwd(h, a, B, H * W, G, self.gn_part, self.st_out, self.out_norm.g, self.out_norm.b, silu=True)
         o = self._buf(B * H * W, self.cout)
-        self._conv(a, self.out_conv, o, (H, W))
+        self._gn_conv(h, self.out_norm, self.st_out, self.out_conv, o, (H, W))
         ops.nhwc_to_nchw(o, self.out, B, self.cout, H * W)
         self.x_nhwc = x_nhwc
 

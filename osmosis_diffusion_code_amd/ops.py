@@ -41,7 +41,8 @@ def _s():
 
 def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat, B: int, H: int, W: int,
            ksize: int, res: Optional[Mat] = None, accumulate: bool = False,
-           splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0):
+           splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0,
+           gn_table: Optional[torch.Tensor] = None, gn_silu: bool = True):
     d = ConvDesc()
     d.x, d.w, d.bias = x.p, ptr(w_packed), ptr(bias)
     d.res = res.p if res is not None else None
@@ -51,7 +52,9 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.ksize, d.splitk, d.accumulate = ksize, splitk, int(accumulate)
     d.ldx, d.ldy, d.ldr = x.ld, y.ld, (res.ld if res is not None else 0)
     d.wfmt = wfmt
-    call("osm_conv2d_nhwc", C.byref(d), _s(), keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws))
+    d.gn_table, d.gn_silu = ptr(gn_table), int(gn_silu)
+    call("osm_conv2d_nhwc", C.byref(d), _s(),
+         keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table))
 
 
 # conv arithmetic modes: weight-image format code of the C ABI
@@ -156,6 +159,13 @@ def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, fi
     fp, ldf = _film(film)
     call("osm_gn_fwd", x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
          fp, ldf, int(silu), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film))
+
+
+def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5):
+    """statistics (-> `stats`) + per-channel table [B][4][C] that conv2d(gn_table=...) applies while staging."""
+    fp, ldf = _film(film)
+    call("osm_gn_prep", x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
+         ptr(table), _s(), keep=(x.t, part, stats, gamma, beta, film, table))
 
 
 def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
