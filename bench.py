@@ -183,10 +183,12 @@ def roofline(model, args):
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
-            for k in json.load(open(path))["kernels"]:
-                if k["kernel"].replace(" ", "").startswith({"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
-                                                            "bf16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]):
-                    traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
+                    "bf16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]
+            hit = [k for k in json.load(open(path))["kernels"] if k["kernel"].replace(" ", "").startswith(pref)]
+            if hit:   # launch-weighted mean over the template instances of the dominant kernel
+                traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in hit) / sum(k["launches"] for k in hit))
+                traffic_src = os.path.relpath(path, ROOT)
         except Exception:
             pass
     convs3 = {k: v for k, v in per_shape.items()
