@@ -269,12 +269,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    # OSM_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a single-GPU box (ranks share device 0); the
+    # driver's multi-GPU runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("OSM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     model, dt, finite = run_gpu(args, rank, world, dev)
     units = world * args.batch * args.steps

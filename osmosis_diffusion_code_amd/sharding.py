@@ -18,6 +18,8 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None                    # gloo reduces host tensors
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -29,6 +31,8 @@ def gather_per_image(values: Sequence[float], n_items: int, device=None) -> List
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return list(values)
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo":
+        device = None
     per = (n_items + world - 1) // world
     mine = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
     mine[:len(values)] = torch.tensor(list(values), dtype=torch.float64, device=device)
