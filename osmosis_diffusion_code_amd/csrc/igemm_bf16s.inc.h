@@ -61,7 +61,7 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
 
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-template <int TAPS, int NP, int DBG = 0>
+template <int TAPS, int NP>
 __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Bglob,
                                                               IGemmParams p) {
