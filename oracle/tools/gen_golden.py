@@ -17,6 +17,7 @@ Sections (SURVEY.md section 8c recipe):
   loop_<op>.npz   10-step guided p_sample_loop for each of the 3 physical operators with the
                   exact noise tensors the reference drew, per-step traces
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
+  loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
 """
 import os
@@ -301,6 +302,55 @@ def gen_prior():
                         cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
 
 
+def gen_ps():
+    """rgb-guidance path: `ps` conditioning (condition_methods.py:234-251) + `rgb_guidance` operator
+    (measurements.py:80-96) + gaussian noiser, through DDPM.p_sample / DDIM.p_sample (gaussian_diffusion.py:494-535),
+    10 low-t steps on the tiny seeded UNet.  All randn_like draws are logged in call order (p_sample's noise, then
+    q_sample's) so that a replay reproduces the chain exactly."""
+    m, cfg, sd = tiny_model()
+    out = {}
+    for name in ("ddpm", "ddim"):
+        operator = get_operator(name="rgb_guidance", device=torch.device("cpu"), batch_size=1)
+        noiser = get_noise(name="gaussian", sigma=0.05)
+        cond = get_conditioning_method("ps", operator, noiser, scale="0.6,0.5,0.4,0.0")
+        sampler = R_gd.get_sampler(name)(use_timesteps=range(0, 100, 10),
+                                         betas=R_gd.get_named_beta_schedule("linear", 1000),
+                                         model_mean_type="epsilon", model_var_type="learned_range",
+                                         dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
+        x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(2))
+        y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(9)) * 1.6 - 0.8
+        draws, losses = [], []
+        orig = torch.randn_like
+
+        def logged(t, **kw):
+            r = orig(t, **kw)
+            draws.append(r.clone())
+            return r
+
+        orig_cond = cond.conditioning
+
+        def traced(**kw):
+            ret = orig_cond(**kw)
+            losses.append(float(ret[1]))
+            return ret
+
+        torch.manual_seed(0)
+        torch.randn_like = logged
+        try:
+            img = sampler.p_sample_loop(model=m, x_start=x_T.clone().requires_grad_(), measurement=y,
+                                        measurement_cond_fn=traced, record=False, save_root=None,
+                                        pretrain_model="osmosis", rgb_guidance=True, sample_pattern=PATTERN)
+        finally:
+            torch.randn_like = orig
+        out[f"{name}.x_T"], out[f"{name}.y"], out[f"{name}.final_img"] = npy(x_T), npy(y), npy(img)
+        out[f"{name}.loss"] = np.array(losses, dtype=np.float32)
+        out[f"{name}.draw_is_x"] = np.array([d.shape[1] == 4 for d in draws])
+        out[f"{name}.draws_x"] = np.stack([npy(d) for d in draws if d.shape[1] == 4])
+        out[f"{name}.draws_y"] = np.stack([npy(d) for d in draws if d.shape[1] == 3])
+        print(name, "draws", len(draws), "final loss", losses[-1])
+    np.savez_compressed(os.path.join(OUT, "loop_ps.npz"), **out)
+
+
 def gen_postprocess():
     """Output post-processing helpers of osmosis_utils/utils.py (min_max_norm_range :46-74,
     min_max_norm_range_percentile :77-114, depth_tensor_to_color_image :748-763, convert_depth :544-566)
@@ -341,5 +391,6 @@ if __name__ == "__main__":
     gen_loops()
     gen_prior()
     gen_postprocess()
+    gen_ps()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

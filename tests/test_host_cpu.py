@@ -205,3 +205,23 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+def test_create_model_loads_a_checkpoint_file_and_survives_a_bad_path(tmp_path, capsys):
+    """N4 / unet.py:86-97: `model_path` is th.load-ed into the module (reference keys, OIHW shapes); any failure is
+    caught, reported as 'Got exception: ... / Randomly initialize', and the model is still returned."""
+    from oracle import unet_ref as U
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    kw = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+              num_head_channels=16, num_heads=4, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+              pretrain_model="osmosis")
+    sd = U.seeded_state_dict(U.UNetConfig.from_create_model_kwargs(**kw), 77)
+    path = tmp_path / "ckpt.pt"
+    torch.save(sd, path)
+    m = unet.create_model(model_path=str(path), **kw)
+    assert "Got exception" not in capsys.readouterr().out
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    m2 = unet.create_model(model_path=str(tmp_path / "missing.pt"), **kw)
+    assert "Got exception" in capsys.readouterr().out          # message printed, nothing raised
+    assert set(m2.state_dict()) == set(sd)

@@ -155,3 +155,47 @@ def test_batched_images_equal_single_image_runs(pkg):
         assert np.allclose(both[2][i], one[2][0], rtol=1e-5)
         for n in both[1]:
             assert torch.allclose(both[1][n][i:i + 1], one[1][n], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["ddpm", "ddim"])
+def test_rgb_guidance_ps_chain_matches_reference(pkg, name, monkeypatch):
+    """`ps` conditioning + `rgb_guidance` operator + gaussian noiser through DDPM.p_sample and
+    DDIM.p_sample (generic autograd path over the HIP UNet) vs the chain the reference produced with the same draws
+    (tests/golden/loop_ps.npz; torch.randn_like replayed in the reference's call order)."""
+    unet, gd, M, CM = pkg
+    g = np.load(os.path.join(GOLD, "loop_ps.npz"))
+    model = make_model(unet)
+    operator = M.get_operator("rgb_guidance", device=DEV, batch_size=1)
+    cond = CM.get_conditioning_method("ps", operator, M.get_noise("gaussian", sigma=0.05), scale="0.6,0.5,0.4,0.0")
+    sampler = gd.get_sampler(name)(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                   model_mean_type="epsilon", model_var_type="learned_range", dynamic_threshold=False,
+                                   clip_denoised=False, rescale_timesteps=False)
+    is_x = list(g[f"{name}.draw_is_x"])
+    dx, dy = iter(g[f"{name}.draws_x"]), iter(g[f"{name}.draws_y"])
+    order = iter(is_x)
+
+    def replay(t, **kw):
+        want_x = next(order)
+        d = torch.from_numpy(next(dx) if want_x else next(dy))
+        assert tuple(d.shape) == tuple(t.shape), "draw order differs from the reference's"
+        return d.to(t.device)
+
+    monkeypatch.setattr(torch, "randn_like", replay)
+    losses = []
+    orig = cond.conditioning
+
+    def traced(**kw):
+        ret = orig(**kw)
+        losses.append(float(ret[1]))
+        return ret
+
+    img = sampler.p_sample_loop(model=model, x_start=torch.from_numpy(g[f"{name}.x_T"]).to(DEV).requires_grad_(),
+                                measurement=torch.from_numpy(g[f"{name}.y"]).to(DEV), measurement_cond_fn=traced,
+                                record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=True,
+                                sample_pattern=PATTERN)
+    monkeypatch.undo()
+    assert next(order, None) is None                      # every reference draw was consumed, in order
+    assert np.allclose(losses, g[f"{name}.loss"], rtol=1e-4)
+    err = float((img.detach().cpu() - torch.from_numpy(g[f"{name}.final_img"])).abs().max())
+    print(name, "rgb-guidance chain max-abs error", err)
+    assert err < 1e-3
