@@ -18,18 +18,27 @@
 // LDS rows = 5 x 16) below lanes 0-15, every ds_read_b128 lane group of gfx950 ({0-3,12-15,20-27}, ...) sees
 // 16 distinct bank quads for every tap shift -> 4 LDS cycles per fragment read (pitch 18 / adjacent rows: 8).
 
-constexpr int HALO_W = 18;                       // 16 + 2 staged pixels per halo row
-constexpr int HALO_P = 20;                       // LDS pitch of a halo row, in pixels
-constexpr int HALO_PIX = 180;                    // 10 x 18 staged pixels
-constexpr int HALO_ROWS = 10 * HALO_P + 8;       // LDS pixel rows (+ a dump row for the unused staging slots)
-constexpr int H_PLANE = HALO_ROWS * S_ROWB;      // bytes per plane
+// PW = patch width: 16 (8 x 16 patch = 128 GEMM rows, 4 MFMA row blocks) for W >= 16, or 8 (8 x 8 patch = 64 rows,
+// 2 row blocks: the 8x8 layers, where an 8 x 16 patch would be mostly halo).
+template <int PW> struct HaloGeom {
+  static constexpr int HW = PW + 2;                 // staged pixels per halo row
+  static constexpr int HP = PW == 16 ? 20 : 10;     // LDS pitch of a halo row, in pixels
+  static constexpr int PIX = 10 * HW;               // staged pixels
+  static constexpr int NJ = (PIX * 8 + 255) / 256;  // float4 staging loads per thread and slab
+  static constexpr int ROWS = 10 * HP + 8;          // LDS pixel rows (+ a dump row for unused staging slots)
+  static constexpr int PLANE = ROWS * S_ROWB;       // bytes per plane
+  static constexpr int RB = PW / 4;                 // MFMA row blocks (32 rows each)
+};
 constexpr int B_RING = 3;                        // weight-fragment register sets (divides the 18 steps of a slab)
 constexpr int B_DIST = 2;                        // steps between a weight fragment's load and its use
 
-template <int NP, bool GNF>
+template <int NP, bool GNF, int PW = 16>
 __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
+  using GEO = HaloGeom<PW>;
+  constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
+                RB = GEO::RB;
   __shared__ __attribute__((aligned(16))) unsigned char As[NP * H_PLANE];
 
   const int tid = threadIdx.x;
@@ -42,9 +51,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
-  const int tpx = (p.W + 15) >> 4, tpy = (p.H + 7) >> 3;
+  const int tpx = (p.W + PW - 1) / PW, tpy = (p.H + 7) >> 3;
   const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
-  const int x0 = tx * 16, y0 = ty * 8, n0 = tile_n * BN;
+  const int x0 = tx * PW, y0 = ty * 8, n0 = tile_n * BN;
 
   const int ks = blockIdx.y;
   const int nslab = (p.K + BK - 1) / BK;
@@ -56,9 +65,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const int cg = tid & 7;
   const long long rowB = (long long)p.lda * 4;
   const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
-  unsigned voff[6], woff[6], vmask = 0;
+  unsigned voff[NJ], woff[NJ], vmask = 0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int hp = (tid >> 3) + 32 * j;
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
     woff[j] = (unsigned)((hp < HALO_PIX ? hy * HALO_P + hx : 10 * HALO_P) * S_ROWB + 8 * cg);
@@ -81,16 +90,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const char* __restrict__ sbaseB0 =
       b_ok ? reinterpret_cast<const char*>(Bglob) : reinterpret_cast<const char*>(g_zero_page);
 
-  f32x16 acc[4];
+  f32x16 acc[RB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
+  // lane row lr of row block i: PW = 16 -> patch pixel (i + 4 (lr >> 4), lr & 15);  PW = 8 -> (4 i + (lr >> 3), lr & 7)
   const int lr = lane & 31, lk = lane >> 5;
-  const unsigned char* a_rd = As + ((lr >> 4) * (4 * HALO_P) + (lr & 15)) * S_ROWB + 16 * lk;
+  const unsigned char* a_rd =
+      As + (PW == 16 ? (lr >> 4) * (4 * HALO_P) + (lr & 15) : (lr >> 3) * HALO_P + (lr & 7)) * S_ROWB + 16 * lk;
+  constexpr int RB_STRIDE = (PW == 16 ? HALO_P : 4 * HALO_P) * S_ROWB;   // bytes between row blocks
 
-  float4 ra[6];
+  float4 ra[NJ];
   float4 gm, gr, gg, gb;   // GNF: mean | rstd | g | b of this thread's 4 channels of the current slab
   gm = gr = gg = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
     const bool cok_ = (cc_) * BK + 4 * cg < p.K;                                           \
     const unsigned d_ = (unsigned)((cc_) * (BK * 4) + 16 * cg);                            \
     okm = cok_ ? vmask : 0u;                                                               \
-    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                          \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
       ra[j] = *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)));     \
     if (GNF) {                                                                             \
       const float* gt_ = gtab + (cok_ ? (cc_) * BK + 4 * cg : 0);                          \
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
       _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                    \
         f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + q2 * H_PLANE +               \
-                                                       (2 * h_ + t) * (HALO_P * S_ROWB) + off_);     \
+                                                       (2 * h_ + t) * RB_STRIDE + off_);             \
   }
 #define OSM_H_MMA(f_, slot_, h_)                                                           \
   _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
     for (int c = kc0; c < kc1; ++c) {
       // split the staged halo of slab c into LDS (masked lanes / slots store zeros)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         uint2 pl[NP];
         float4 v = ra[j];
         if (GNF) {   // GroupNorm(+FiLM)(+SiLU) of the input on the fly; the zero padding applies to the result
@@ -167,18 +179,34 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
       __syncthreads();
       bf16x8_t fx[2][NP], fy[2][NP];
       OSM_H_READ(fx, 0)
+      if constexpr (PW == 16) {
 #define OSM_H_STEP(s_)                                                                     \
-      OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
-      OSM_H_READ(fy, 2 * (s_) + 1)                                                         \
-      OSM_H_MMA(fx, (s_) % B_RING, 0)                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                   \
-      if ((s_) + 1 < 18) OSM_H_READ(fx, (2 * (s_) + 2) % 36)                               \
-      OSM_H_MMA(fy, (s_) % B_RING, 1)                                                           \
-      __builtin_amdgcn_sched_barrier(0);
-      OSM_H_STEP(0) OSM_H_STEP(1) OSM_H_STEP(2) OSM_H_STEP(3) OSM_H_STEP(4) OSM_H_STEP(5)
-      OSM_H_STEP(6) OSM_H_STEP(7) OSM_H_STEP(8) OSM_H_STEP(9) OSM_H_STEP(10) OSM_H_STEP(11)
-      OSM_H_STEP(12) OSM_H_STEP(13) OSM_H_STEP(14) OSM_H_STEP(15) OSM_H_STEP(16) OSM_H_STEP(17)
+        OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
+        OSM_H_READ(fy, 2 * (s_) + 1)                                                       \
+        OSM_H_MMA(fx, (s_) % B_RING, 0)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if ((s_) + 1 < 18) OSM_H_READ(fx, (2 * (s_) + 2) % 36)                             \
+        OSM_H_MMA(fy, (s_) % B_RING, 1)                                                    \
+        __builtin_amdgcn_sched_barrier(0);
+        OSM_H_STEP(0) OSM_H_STEP(1) OSM_H_STEP(2) OSM_H_STEP(3) OSM_H_STEP(4) OSM_H_STEP(5)
+        OSM_H_STEP(6) OSM_H_STEP(7) OSM_H_STEP(8) OSM_H_STEP(9) OSM_H_STEP(10) OSM_H_STEP(11)
+        OSM_H_STEP(12) OSM_H_STEP(13) OSM_H_STEP(14) OSM_H_STEP(15) OSM_H_STEP(16) OSM_H_STEP(17)
 #undef OSM_H_STEP
+      } else {
+        // 64-row patch: one pair of row blocks per step; fx serves the even steps, fy the odd ones
+#define OSM_H_STEP2(s_)                                                                    \
+        OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
+        OSM_H_READ(fy, 2 * ((s_) + 1))                                                     \
+        OSM_H_MMA(fx, (s_) % B_RING, 0)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        OSM_H_LOAD_B(((s_) + 1 + B_DIST) % B_RING, ((s_) + 1 + B_DIST < 18 ? c : cn), ((s_) + 1 + B_DIST) % 18); \
+        if ((s_) + 2 < 18) OSM_H_READ(fx, 2 * ((s_) + 2))                                  \
+        OSM_H_MMA(fy, ((s_) + 1) % B_RING, 0)                                              \
+        __builtin_amdgcn_sched_barrier(0);
+        OSM_H_STEP2(0) OSM_H_STEP2(2) OSM_H_STEP2(4) OSM_H_STEP2(6) OSM_H_STEP2(8) OSM_H_STEP2(10)
+        OSM_H_STEP2(12) OSM_H_STEP2(14) OSM_H_STEP2(16)
+#undef OSM_H_STEP2
+      }
       __syncthreads();                       // every wave is done reading this slab's LDS image
     }
   }
@@ -195,17 +223,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const int n = n0 + 32 * wave + lr;
   if (n >= p.N) return;
   const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
-  // element e of row block tm is patch pixel (tm + 4 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
+  // element e of row block tm is patch pixel  PW = 16: (tm + 4 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
+  //                                            PW = 8 : (4 tm + (e >> 2), (e & 3) + 4 lk)
   const int xl = x0 + 4 * lk;
   const long long pix0 = (long long)img * p.H * p.W + (long long)y0 * p.W + xl;
   float* __restrict__ cp = Cb + pix0 * ldc + n;
   const float* __restrict__ rp = Rb ? Rb + pix0 * p.ldr + n : nullptr;
   const long long crow = (long long)p.W * ldc, rrow = (long long)p.W * p.ldr;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
+  for (int tm = 0; tm < RB; ++tm) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int dy = tm + 4 * (e >> 3), dx = (e & 3) + 8 * ((e >> 2) & 1);
+      const int dy = PW == 16 ? tm + 4 * (e >> 3) : 4 * tm + (e >> 2);
+      const int dx = PW == 16 ? (e & 3) + 8 * ((e >> 2) & 1) : (e & 3);
       if (y0 + dy >= p.H || xl + dx >= p.W) continue;
       float* c = cp + dy * crow + dx * ldc;
       float v = acc[tm][e];

@@ -341,24 +341,26 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > p.nchunks) p.splitk = p.nchunks;
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
-  if (wfmt != 0 && taps == 9 && p.W >= 16 && p.H >= 8 && halo_enabled()) {
-    // halo-tile kernel: M-tiles are 8 x 16 pixel patches, K is consumed in 32-channel slabs of all 9 taps
+  if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
+    // halo-tile kernel: M-tiles are 8 x 16 (W >= 16) or 8 x 8 pixel patches, K is consumed in 32-channel slabs of all 9 taps
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
+    const bool wide = p.W >= 16;
     const int nimg = p.M / (p.H * p.W);
-    p.mtiles = nimg * ((p.H + 7) / 8) * ((p.W + 15) / 16);
+    p.mtiles = nimg * ((p.H + 7) / 8) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
-    if (wfmt == 3 && p.gn_table)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3, true>), g2, dim3(256), 0, st, p.A, Bp, p);
-    else if (wfmt == 3)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<3, false>), g2, dim3(256), 0, st, p.A, Bp, p);
-    else if (wfmt == 2 && p.gn_table)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, true>), g2, dim3(256), 0, st, p.A, Bp, p);
-    else if (wfmt == 2)
-      hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, false>), g2, dim3(256), 0, st, p.A, Bp, p);
-    else
-      return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+    if (wfmt != 2 && wfmt != 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+#define OSM_HALO_LAUNCH(NP_, GN_, PW_) \
+    hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_>), g2, dim3(256), 0, st, p.A, Bp, p)
+    if (wfmt == 3) {
+      if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(3, true, 16); else OSM_HALO_LAUNCH(3, false, 16); }
+      else      { if (p.gn_table) OSM_HALO_LAUNCH(3, true, 8);  else OSM_HALO_LAUNCH(3, false, 8); }
+    } else {
+      if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(2, true, 16); else OSM_HALO_LAUNCH(2, false, 16); }
+      else      { if (p.gn_table) OSM_HALO_LAUNCH(2, true, 8);  else OSM_HALO_LAUNCH(2, false, 8); }
+    }
+#undef OSM_HALO_LAUNCH
   } else if (wfmt != 0) {
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
@@ -431,8 +433,8 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   p.tapstrideB = (long long)d->Cout * d->Cin;
   p.nb1 = 1; p.nbatch = 1;
   if (d->gn_table) {
-    OSM_REQUIRE(d->wfmt != 0 && d->ksize == 3 && d->W >= 16 && d->H >= 8 && halo_enabled(),
-                "osm_conv2d_nhwc: gn_table needs the halo-tile kernel (3x3, split-bf16 weights, W >= 16, H >= 8)");
+    OSM_REQUIRE(d->wfmt != 0 && d->ksize == 3 && d->W >= 8 && d->H >= 8 && halo_enabled(),
+                "osm_conv2d_nhwc: gn_table needs the halo-tile kernel (3x3, split-bf16 weights, W >= 8, H >= 8)");
     OSM_REQUIRE(osm::aligned16(d->gn_table), "osm_conv2d_nhwc: gn_table must be 16-byte aligned");
     p.gn_table = d->gn_table;
     p.gn_silu = d->gn_silu;

@@ -312,7 +312,9 @@ def test_bad_arguments_return_errors(ops):
     (1, 256, 128, 8, 8, 3, 4), (2, 64, 64, 8, 8, 1, 1), (1, 128, 256, 32, 32, 3, 1), (1, 36, 44, 8, 8, 3, 2),
     # halo-tile kernel (W >= 16, H >= 8): ragged patches, several images, channel tail, split-K over slabs
     (2, 64, 96, 24, 40, 3, 1), (1, 40, 36, 9, 17, 3, 1), (1, 256, 128, 16, 16, 3, 4), (2, 128, 128, 64, 64, 3, 2),
-    (1, 96, 32, 8, 16, 3, 8)])
+    (1, 96, 32, 8, 16, 3, 8),
+    # 8-wide patches (8 <= W < 16): ragged second patch, ragged rows, several images
+    (1, 64, 64, 8, 12, 3, 1), (2, 96, 160, 10, 9, 3, 1), (1, 1024, 256, 8, 8, 3, 16)])
 def test_conv_split_bf16_modes(ops, mode, tol, B, Cin, Cout, H, W, k, splitk):
     """Split-bf16 MFMA path (fp32 = 3 bf16 terms): bf16x6 must be fp32-class, bf16x3 ~2^-16."""
     wfmt = ops.WFMT[mode]
