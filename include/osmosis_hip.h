@@ -55,7 +55,7 @@ typedef struct osm_conv_desc {
   int wfmt;            /* weight image: 0 = fp32 [tap][Cout][Cin] (exact-f32 MFMA);
                           3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
                           (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16) */
-  const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 16, H >= 8 only):
+  const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
                           osm_gn_prep; NULL = plain convolution */
