@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void guide_update_kernel(const float* __restri
     if (g) grad = c0 * g[i] + (dxu ? dxu[i] : 0.f);
     if (grad_out) grad_out[i] = grad;
     float gc = grad;
-    if (clip > 0.f) gc = fminf(fmaxf(grad, -clip), clip);
+    if (clip > 0.f) gc = (grad != grad) ? grad : fminf(fmaxf(grad, -clip), clip);   // torch.clamp keeps NaN (fminf/fmaxf would drop it)
     float xt = mean[i] - (g ? scale4[c] * gc : 0.f);
     if (noise_on != 0.f && noise) xt += expf(0.5f * logvar[i]) * noise[i];
     x_next[i] = xt;

@@ -85,7 +85,7 @@ def depth_color(post):
     return utilso.depth_tensor_to_color_image(post["depth_pmm"])
 
 
-def restore_image(model, ref_img, cfg, device=None, image_idx=0, **loop_kwargs):
+def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, **loop_kwargs):
     """One image through the reference's per-image sequence: fresh operator / noiser / conditioning method /
     sampler (:142-155), y = noiser(ref) (+ degamma), manual_seed + x_T ~ N(0, I) per global iteration
     (:191-196), guided p_sample_loop, post-processing.  Returns a list with one dict per global iteration."""
@@ -109,6 +109,8 @@ def restore_image(model, ref_img, cfg, device=None, image_idx=0, **loop_kwargs):
     for global_ii in range(global_iterations(cfg["sample_pattern"])):
         torch.manual_seed(cfg.get("manual_seed", 0))
         x_start = torch.randn(shape, device=device)
+        if x_scale != 1.0:          # sub-chains started at a low timestep (tools/full_chain.py --last)
+            x_start = x_start * x_scale
         sample, variable_dict, loss, out_xstart = sampler.p_sample_loop(
             model=model, x_start=x_start, measurement=y_n, measurement_cond_fn=cond.conditioning,
             record=False, save_root=None, pretrain_model=pretrain, image_idx=image_idx,
