@@ -185,7 +185,9 @@ def roofline(model, args):
         try:
             pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
                     "bf16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]
-            hit = [k for k in json.load(open(path))["kernels"] if k["kernel"].replace(" ", "").startswith(pref)]
+            hit = [k for k in json.load(open(path))["kernels"]
+                   if k["kernel"].replace(" ", "").startswith(pref)
+                   and (args.conv_mode == "f32" or k["kernel"].replace(" ", "").endswith(",16>"))]   # 8 x 16 patches
             if hit:   # launch-weighted mean over the template instances of the dominant kernel
                 traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in hit) / sum(k["launches"] for k in hit))
                 traffic_src = os.path.relpath(path, ROOT)
