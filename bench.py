@@ -10,11 +10,12 @@ schedule, epsilon mean, learned-range variance), `underwater_physical_revised` o
 guidance with n_iter=20 inner phi iterations, scale 7,7,7,0.9, clip 0.005, aux losses 0.5/20.
 One "step" = one iteration of the reference loop (gaussian_diffusion.py:213): UNet forward, posterior,
 20x (physics loss + phi SGD), UNet input-gradient, guidance update, noise.  Timed steps are taken
-from the phi-update regime (t <= 0.7 T), i.e. the expensive 70 % of the chain.  Weights are seeded
+from the phi-update regime (t <= 0.7 T, the expensive 70 % of the chain), starting at t = 0.3 T from a bounded
+x_t so that the un-trained network's x0 prediction stays inside the physical model's range.  Weights are seeded
 synthetic (no checkpoint is available offline), inputs synthetic; timing is value independent.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (3x3 implicit-GEMM conv,
-fp32 MFMA): algorithmic FLOPs of every 3x3-conv launch of one guided step divided by the
+split-bf16 MFMA): algorithmic FLOPs of every 3x3-conv launch of one guided step divided by the
 HIP-event-measured duration of those launches (events on the launch stream).  `cpu_baseline` times
 the CPU oracle (oracle/, torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1.
 """
@@ -92,7 +93,12 @@ def run_gpu(args, rank, world, dev):
     x_T, y = synthetic_inputs(shard(world, rank, world)[0], B, S)
     x_T, y = x_T.to(dev), y.to(dev)
     T = sampler.num_timesteps
-    first = min(int(0.7 * T) - 1, T - 1)
+    # Timed window inside the phi-update regime (t <= 0.7 T), started at t = 0.3 T from a bounded x_t: the seeded
+    # synthetic weights do not denoise, so from t = 0.7 T the x0 prediction (x_t / sqrt(alpha_bar) ...) leaves the
+    # physical model's range and the squared residual overflows fp32.  Kernel time is value-independent;
+    # this only keeps the reported outputs finite.
+    first = min(int(0.3 * T) - 1, T - 1)
+    x_T = 0.5 * x_T
 
     def run(n_steps, start):
         return sampler.p_sample_loop(model=model, x_start=x_T, measurement=y, measurement_cond_fn=cond.conditioning,
@@ -294,7 +300,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
-                               "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime t<=0.7T",
+                               "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime (t <= 0.3T)",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
                    "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode, "parallelism": f"images[rank::{world}] (no collective on the path)",
                    "finite_outputs": finite},
