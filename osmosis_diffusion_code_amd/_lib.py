@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libosmosis_hip.so")
+LIB_PATH = os.environ.get("OSM_LIB") or os.path.join(_HERE, "libosmosis_hip.so")   # OSM_LIB: A/B builds
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 

@@ -285,25 +285,43 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
   }
 }
 
-// C = alpha * sum_s ws[s] + bias + res (+ C)
+// C = alpha * sum_s ws[s] + bias + res (+ C)      (fixed summation order: deterministic)
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
-  const long long total = (long long)p.nbatch * p.M * p.N;
-  const long long slice = total;
+  const long long slice = (long long)p.nbatch * p.M * p.N;
+  const long long total = slice / VEC;
+  const int nv = p.N / VEC;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % p.N);
-    const long long mz = i / p.N;
+    const int n = (int)(i % nv) * VEC;
+    const long long mz = i / nv;
     const int m = (int)(mz % p.M);
     const int z = (int)(mz / p.M);
-    float s = 0.f;
-    for (int k = 0; k < p.splitk; ++k) s += p.ws[k * slice + i];
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    const float* w = p.ws + i * VEC;
+    for (int k = 0; k < p.splitk; ++k) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(w + k * slice);
+        s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+      } else {
+        s[0] += w[k * slice];
+      }
+    }
     const int b1 = z % p.nb1, b2 = z / p.nb1;
     const long long coff = b1 * p.sC1 + b2 * p.sC2;
-    float v = s * p.alpha + (p.bias ? p.bias[n] : 0.f);
-    if (p.res) v += p.res[coff + (long long)m * p.ldr + n];
     float* c = p.C + coff + (long long)m * p.ldc + n;
-    if (p.accumulate) v += *c;
-    *c = v;
+    const float* rs = p.res ? p.res + coff + (long long)m * p.ldr + n : nullptr;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = s[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+      if (rs) v += rs[e];
+      if (p.accumulate) v += c[e];
+      s[e] = v;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(c) = make_float4(s[0], s[1], s[2], s[3]);
+    else c[0] = s[0];
   }
 }
 
@@ -389,10 +407,13 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   int rc = osm::check_launch("igemm_f32_kernel");
   if (rc) return rc;
   if (p.splitk > 1) {
-    const long long total = (long long)p.nbatch * p.M * p.N;
+    const bool v4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && osm::aligned16(p.C) &&
+                    osm::aligned16(p.ws) && (!p.res || osm::aligned16(p.res)) && p.sC1 % 4 == 0 && p.sC2 % 4 == 0;
+    const long long total = (long long)p.nbatch * p.M * p.N / (v4 ? 4 : 1);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     rc = osm::check_launch("splitk_reduce_kernel");
   }
   return rc;
