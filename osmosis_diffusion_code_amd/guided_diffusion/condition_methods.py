@@ -18,7 +18,6 @@ Two ways in:
 """
 from abc import ABC, abstractmethod
 
-import numpy as np
 import torch
 
 from .. import ops

@@ -17,7 +17,6 @@ combination falls back to a generic loop that follows the reference control flow
 same kernels through torch.autograd.
 """
 import math
-from typing import Optional
 
 import numpy as np
 import torch

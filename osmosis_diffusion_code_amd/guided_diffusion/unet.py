@@ -17,7 +17,7 @@ What is different: the module holds parameters only.  The computation is a recor
 kernel calls over NHWC buffers (UNetEngine); there is no CPU / eager fallback.
 """
 import os
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.nn as nn

@@ -3,7 +3,6 @@ same op.  Integer/index work is exact; floating point tolerance is stated per te
 exact-fp32 fmaf chain, so differences are summation-order only)."""
 import math
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
