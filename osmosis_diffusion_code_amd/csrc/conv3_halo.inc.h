@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   const unsigned b_plane = b_tap * 9u;
   const char* __restrict__ sbaseB0 =
       b_ok ? reinterpret_cast<const char*>(Bglob) : reinterpret_cast<const char*>(g_zero_page);
+  // buffer resource over the weight image: loads are `buffer_load_dwordx4 v, v_lane, s[rsrc], s_step offen` -- the
+  // per-step offset stays in an SGPR and the only address VGPR is the (constant) lane offset
+  const __amdgpu_buffer_rsrc_t brsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbaseB0), 0, 0x7fffffff, 0x00020000);
 
   f32x16 acc[RB];
 #pragma unroll
@@ -129,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   {                                                                                        \
     const unsigned so_ = (unsigned)((s_) >> 1) * b_tap + (unsigned)(2 * (cc_) + ((s_) & 1)) * b_step; \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
-      bq[slot_][q2] = *reinterpret_cast<const uint4*>(sbaseB0 + (so_ + q2 * b_plane) + b_lane); \
+      bq[slot_][q2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(    \
+          brsrc, (int)b_lane, (int)(so_ + q2 * b_plane), 0));                              \
   }
 // A fragments of half-step hs_ (step hs_/2, row blocks 2 (hs_&1) and 2 (hs_&1) + 1)
 #define OSM_H_READ(f_, hs_)                                                                \
