@@ -132,6 +132,37 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const float* s = S + row * T;
+  const long long mat = row / T;
+  const int t = (int)(row - mat * T);
+  if (T <= 1024) {   // the row lives in registers (<= 16 values per lane): one read, one write
+    float v[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      v[k] = i < T ? s[i] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = osm::wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = expf(v[k] - mx);          // exp(-inf) = 0 for the padding lanes
+      sum += v[k];
+    }
+    sum = osm::wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      if (i < T) {
+        const float pv = v[k] * inv;
+        P[row * T + i] = pv;
+        if (PT) PT[(mat * T + i) * T + t] = pv;
+      }
+    }
+    return;
+  }
   float mx = -INFINITY;
   for (int i = lane; i < T; i += 64) mx = fmaxf(mx, s[i]);
   mx = osm::wave_max(mx);
@@ -139,8 +170,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int i = lane; i < T; i += 64) sum += expf(s[i] - mx);
   sum = osm::wave_sum(sum);
   const float inv = 1.0f / sum;
-  const long long mat = row / T;
-  const int t = (int)(row - mat * T);
   for (int i = lane; i < T; i += 64) {
     const float pv = expf(s[i] - mx) * inv;
     P[row * T + i] = pv;
@@ -158,11 +187,33 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
   if (row >= nrows) return;
   const float* pr = P + row * T;
   const float* dp = dP + row * T;
+  const long long mat = row / T;
+  const int t = (int)(row - mat * T);
+  if (T <= 1024) {
+    float pv[16], dv[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      pv[k] = i < T ? pr[i] : 0.f;
+      dv[k] = i < T ? dp[i] : 0.f;
+      dot += pv[k] * dv[k];
+    }
+    dot = osm::wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      if (i < T) {
+        const float v = pv[k] * (dv[k] - dot);
+        dS[row * T + i] = v;
+        if (dST) dST[(mat * T + i) * T + t] = v;
+      }
+    }
+    return;
+  }
   float dot = 0.f;
   for (int i = lane; i < T; i += 64) dot += pr[i] * dp[i];
   dot = osm::wave_sum(dot);
-  const long long mat = row / T;
-  const int t = (int)(row - mat * T);
   for (int i = lane; i < T; i += 64) {
     const float v = pr[i] * (dp[i] - dot);
     dS[row * T + i] = v;
