@@ -257,16 +257,21 @@ template <int CH, int NJ>
 int run(const AttnArgs& a, int which, hipStream_t st) {
   const int T = 16 * NJ;
   const dim3 grid(T / 64, a.heads, a.B);
-  static bool attr_done = false;   // LDS above the 64 KB default needs the opt-in once per kernel instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_fwd_kernel<CH, NJ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qtile(T, CH));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_bwd_q_kernel<CH, NJ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qtile(T, CH));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_bwd_k_kernel<CH, NJ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ktile(T, CH));
-    attr_done = true;
-  }
+  // LDS above the 64 KB default needs an opt-in per kernel instantiation (done once, thread-safe static init)
+  static const hipError_t attr_rc = [] {
+    constexpr int T_ = 16 * NJ;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_fwd_kernel<CH, NJ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qtile(T_, CH));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_bwd_q_kernel<CH, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qtile(T_, CH));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_bwd_k_kernel<CH, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ktile(T_, CH));
+    return e;
+  }();
+  if (attr_rc != hipSuccess)
+    return osm::fail(OSM_ERR_LAUNCH, "osm_attn_small: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc));
   if (which == 0) {
     hipLaunchKernelGGL((attn_small_fwd_kernel<CH, NJ>), grid, dim3(256), lds_qtile(T, CH), st, a);
     return osm::check_launch("attn_small_fwd_kernel");
