@@ -91,8 +91,9 @@ class UNetEngine:
         self._bwd_plan: Optional[Recorder] = None
         self._plan_stream = None
         self._splitk_ws = None
-        # OSM_GRAPH=1: replay the recorded plans as hipGraphs instead of ~700 individual launches
-        self.use_graph = os.environ.get("OSM_GRAPH", "0") == "1"
+        # the recorded plans are replayed as hipGraphs (one graph launch instead of ~600 host-side launches per pass:
+        # 0.4 ms instead of 12 ms of host time per step); OSM_GRAPH=0 replays launch by launch
+        self.use_graph = os.environ.get("OSM_GRAPH", "1") != "0"
         self._fwd_graph = self._bwd_graph = None
         self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0"   # GN apply inside the consuming 3x3 conv
 
@@ -534,6 +535,8 @@ class UNetEngine:
             with Recorder() as rec:
                 self._forward_impl()
             self._fwd_plan = rec
+            if self.use_graph:          # capture now (nothing executes) so that the next call is already a graph launch
+                self._fwd_graph = self._fwd_plan.to_graph()
         elif self.use_graph:
             if self._fwd_graph is None:
                 self._fwd_graph = self._fwd_plan.to_graph()
@@ -550,6 +553,8 @@ class UNetEngine:
             with Recorder() as rec:
                 self._backward_impl()
             self._bwd_plan = rec
+            if self.use_graph:
+                self._bwd_graph = self._bwd_plan.to_graph()
         elif self.use_graph:
             if self._bwd_graph is None:
                 self._bwd_graph = self._bwd_plan.to_graph()

@@ -144,11 +144,11 @@ def test_hipgraph_replay_is_bitwise_identical(create_model):
         eng.run_backward()
         return y, eng.dx.clone()
 
-    run()                       # records the plans
-    y0, dx0 = run()             # plain replay
-    eng.use_graph = True
-    run()                       # captures both graphs
-    y1, dx1 = run()             # graph replay
+    run()                       # records the plans (and captures them when graphs are on)
     eng.use_graph = False
+    y0, dx0 = run()             # launch-by-launch replay
+    eng.use_graph = True
+    run()                       # captures both graphs if they were not yet
+    y1, dx1 = run()             # graph replay
     assert eng._fwd_graph is not None and eng._bwd_graph is not None
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
