@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Host-side cost of one UNet forward + backward: launch-by-launch replay of the recorded plan vs hipGraph replay.
+Prints host ms/step (time until the launch calls return) and total ms/step (after synchronize) for both.
+
+    python tools/host_time.py          # MI355X: replay 11.8 / 29.8 ms, graph 0.4 / 29.7 ms
+"""
 import sys, time, os, contextlib, io
 sys.path.insert(0, '/root/repo')
 import torch
