@@ -272,6 +272,15 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started plainly with --gpus N: become the one-process-per-GPU job the contract describes
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
