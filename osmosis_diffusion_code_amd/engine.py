@@ -95,7 +95,8 @@ class UNetEngine:
         # 0.4 ms instead of 12 ms of host time per step); OSM_GRAPH=0 replays launch by launch
         self.use_graph = os.environ.get("OSM_GRAPH", "1") != "0"
         self._fwd_graph = self._bwd_graph = None
-        self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0"   # GN apply inside the consuming 3x3 conv
+        # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
+        self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
 
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
