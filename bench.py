@@ -214,7 +214,9 @@ def roofline(model, args):
     }[args.conv_mode]
     return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / peak, 4),
+            "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # 157.3 TF: the exact-fp32 MFMA / vector peak
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": round(alg_bytes),
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
             "avg_launch_ms": c["ms_per_step"] / c["launches_per_step"],
