@@ -398,3 +398,34 @@ def test_split_bf16_weight_planes_reconstruct_exactly(ops):
     assert float(rec[:, Cout:].abs().max()) == 0.0 and float(rec[:, :, Cin:].abs().max()) == 0.0
     recd = unpack(wd, Cin, Cout)
     assert torch.equal(recd[:, :Cin, :Cout], w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Cin, Cout))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k", [(1, 256, 256, 256, 256, 3), (1, 512, 256, 128, 128, 3), (1, 1024, 1024, 8, 8, 3),
+                                             (1, 1024, 2048, 16, 16, 3), (1, 256, 512, 256, 256, 1), (1, 512, 1536, 32, 32, 1),
+                                             (2, 256, 256, 64, 64, 3)])
+def test_conv_full_size_adjoint_and_linearity(ops, B, Cin, Cout, H, W, k):
+    """Size-independent properties at the real layer sizes (no oracle needed): the data-gradient kernel is the adjoint of
+    the forward kernel, <conv(x), y> = <x, dgrad(y)>, and conv is linear, conv(a + 2 b) = conv(a) + 2 conv(b)."""
+    g = torch.Generator(device=DEV).manual_seed(Cin + Cout + H)
+    M = B * H * W
+    x = torch.randn(M, Cin, device=DEV, generator=g)
+    x2 = torch.randn(M, Cin, device=DEV, generator=g)
+    y = torch.randn(M, Cout, device=DEV, generator=g)
+    w = torch.randn(Cout, Cin, k, k, device=DEV, generator=g) / math.sqrt(Cin * k * k)
+    wf, wd = ops.pack_conv_weight(w, wfmt=3)
+
+    def run(inp, wimg, cin, cout):
+        out = torch.empty(M, cout, device=DEV)
+        sk = ops.splitk_hint(M, cout, cin, k * k, 1)
+        ws = torch.empty(sk * M * cout, device=DEV) if sk > 1 else None
+        ops.conv2d(ops.Mat.of(inp), wimg, None, ops.Mat.of(out), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=3)
+        return out
+
+    cx = run(x, wf, Cin, Cout)
+    dy = run(y, wd, Cout, Cin)
+    lhs = float((cx.double() * y.double()).sum())
+    rhs = float((x.double() * dy.double()).sum())
+    scale = float(cx.double().norm() * y.double().norm())
+    assert abs(lhs - rhs) < 2e-6 * scale, (lhs, rhs, scale)
+    lin = run(x + 2 * x2, wf, Cin, Cout) - (cx + 2 * run(x2, wf, Cin, Cout))
+    assert float(lin.abs().max()) < 2e-5 * float(cx.abs().max())

@@ -199,3 +199,44 @@ def test_rgb_guidance_ps_chain_matches_reference(pkg, name, monkeypatch):
     err = float((img.detach().cpu() - torch.from_numpy(g[f"{name}.final_img"])).abs().max())
     print(name, "rgb-guidance chain max-abs error", err)
     assert err < 1e-3
+
+
+def test_full_size_batch_equals_independent_images(pkg):
+    """BASELINE-size property (no oracle needed): a B = 2 batch through the fused guided loop at 256x256 on the
+    552.8 M-parameter network equals two B = 1 chains (images are independent Markov chains: per-image reductions,
+    per-image phi), including phi after the SGD updates."""
+    unet, gd, M, CM = pkg
+    import contextlib
+    import io
+    import bench
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = unet.create_model(**bench.UNET_KW)
+    model.reset_parameters(1234)
+    model = model.to(DEV).eval()
+    sampler = gd.create_sampler(**bench.DIFFUSION)
+    g = torch.Generator().manual_seed(5)
+    x_T = 0.5 * torch.randn(2, 4, 256, 256, generator=g)
+    y = torch.rand(2, 3, 256, 256, generator=g) * 1.6 - 0.8
+    noise = torch.randn(3, 2, 4, 256, 256, generator=g)
+
+    def chain(sl):
+        b = sl.stop - sl.start
+        op = M.get_operator("underwater_physical_revised", device=DEV, batch_size=b, **bench.OPERATOR)
+        cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **bench.COND, **bench.PATTERN,
+                                          aux_loss=bench.AUX)
+        nd = noise[:, sl].to(DEV)
+        img, variables, loss, x0 = sampler.p_sample_loop(
+            model=model, x_start=x_T[sl].to(DEV), measurement=y[sl].to(DEV), measurement_cond_fn=cond.conditioning,
+            record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False, sample_pattern=bench.PATTERN,
+            index_range=(202, 200), noise_fn=lambda k, shape: nd[k])
+        return img.cpu(), {k: v.cpu() for k, v in variables.items()}, np.asarray(loss), x0
+
+    both = chain(slice(0, 2))
+    singles = [chain(slice(i, i + 1)) for i in range(2)]
+    for i in range(2):
+        assert torch.isfinite(both[0][i]).all()
+        assert float((both[0][i] - singles[i][0][0]).abs().max()) < 1e-5
+        assert float((both[3][i] - singles[i][3][0]).abs().max()) < 1e-5
+        assert abs(both[2][i] - singles[i][2][0]) < 1e-4 * abs(singles[i][2][0])
+        for k in both[1]:
+            assert torch.allclose(both[1][k][i], singles[i][1][k][0], atol=1e-7), k
