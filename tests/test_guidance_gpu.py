@@ -112,3 +112,31 @@ def test_guide_update_kernel(mods):
     ops.guide_update(mean.to(DEV), lv.to(DEV), gg.to(DEV), dxu.to(DEV), nz.to(DEV), coef, scale4.to(DEV), 0.005,
                      out, None, B, HW)
     assert torch.allclose(out.cpu(), mean - scale4[None, :, None] * grad.clamp(-0.005, 0.005), atol=1e-6)
+
+
+@pytest.mark.parametrize("t", [999, 500, 3])
+def test_posterior_round_trip_at_full_size(mods, t):
+    """Size-independent property at BASELINE size (B = 8, 256x256): noising a clean image with q(x_t | x_0) and handing
+    the TRUE noise to the posterior kernel must give x_0 back (pred_xstart), and the posterior mean must equal
+    coef1 x_0 + coef2 x_t; the learned-range log-variance stays between its two bounds."""
+    ops, _, _ = mods
+    tb = D.make_tables(1000, "linear", 1000)
+    g = torch.Generator(device=DEV).manual_seed(t)
+    B, HW = 8, 256 * 256
+    x0 = torch.rand(B, 4, HW, device=DEV, generator=g) * 2 - 1
+    eps = torch.randn(B, 4, HW, device=DEV, generator=g)
+    v = torch.rand(B, 4, HW, device=DEV, generator=g) * 2 - 1
+    ab = float(tb.alphas_cumprod[t])
+    x_t = np.float32(np.sqrt(ab)) * x0 + np.float32(np.sqrt(1 - ab)) * eps
+    coef = torch.tensor([np.float32(tb.sqrt_recip_alphas_cumprod[t]), np.float32(tb.sqrt_recipm1_alphas_cumprod[t]),
+                         np.float32(tb.posterior_mean_coef1[t]), np.float32(tb.posterior_mean_coef2[t]),
+                         np.float32(tb.posterior_log_variance_clipped[t]), np.float32(tb.log_betas[t]), 1.0, t],
+                        dtype=torch.float32, device=DEV)
+    px0, mean, lv = (torch.empty(B, 4, HW, device=DEV) for _ in range(3))
+    ops.posterior(torch.cat([eps, v], dim=1).contiguous(), x_t, coef, px0, mean, lv, B, HW)
+    amp = float(tb.sqrt_recip_alphas_cumprod[t])                    # error amplification of the inversion (158 at t = 999)
+    assert float((px0 - x0).abs().max()) < 4e-6 * amp * 5
+    want = np.float32(tb.posterior_mean_coef1[t]) * px0 + np.float32(tb.posterior_mean_coef2[t]) * x_t
+    assert float((mean - want).abs().max()) < 1e-5
+    lo, hi = float(tb.posterior_log_variance_clipped[t]), float(tb.log_betas[t])
+    assert float(lv.min()) >= min(lo, hi) - 1e-5 and float(lv.max()) <= max(lo, hi) + 1e-5
