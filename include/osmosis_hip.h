@@ -215,17 +215,19 @@ int osm_phys_grad(const osm_phys_desc* d, const float* x0, const float* y, const
 int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream);
 /* condition_methods.py:211-224 + gaussian_diffusion.py:266-268:
  *   grad = c0*g + dx_unet ; x_t = mean - scale[c]*clamp(grad,+-clip) ; x_next = x_t + exp(.5*logvar)*noise*noise_on
- * grad_out (optional) receives the unclipped gradient. clip<=0 disables clipping. */
+ * grad_out (optional) receives the unclipped gradient. clip < 0 disables clipping; clip >= 0 clamps to +-clip
+ * (clip = 0 zeroes the guidance term, as torch.clamp(g, -0, 0) does). */
 int osm_guide_update(const float* mean, const float* logvar, const float* g, const float* dx_unet,
                      const float* noise, const float* coef, const float* scale4, float clip,
                      float* x_next, float* grad_out, int B, int HW, void* stream);
 /* unconditional ancestral step of the RGBD prior sampler (osmosis_utils/diffusion.py:94-122), NCHW:
  *   eps = model_out[:, :C]; x_next = c_a (x - c_b eps) + c_s z; x0 = c_r x - c_m eps (x0, z optional)
- * coef: device float[8] = {c_a, c_b, c_s, c_r, c_m, -, -, t} */
+ * coef: device float[8] = {c_a, c_b, c_s, c_r, c_m, -, -, t}.  x_next may alias x (in-place update). */
 int osm_ancestral_step(const float* model_out, const float* x, const float* z, const float* coef,
                        float* x_next, float* x0, int B, int C, int Cout, int HW, void* stream);
-/* coef_out[8] = table[*step][8]; t_out[b] = coef_out[7]; then *step += delta (graph-replayable) */
-int osm_fetch_coefs(const float* table, int* step, int delta, float* coef_out, float* t_out, int B,
+/* coef_out[8] = table[clamp(*step, 0, n_rows-1)][8]; t_out[b] = coef_out[7]; then *step += delta
+ * (graph-replayable; B <= 256) */
+int osm_fetch_coefs(const float* table, int n_rows, int* step, int delta, float* coef_out, float* t_out, int B,
                     void* stream);
 
 #ifdef __cplusplus

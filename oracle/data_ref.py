@@ -3,8 +3,9 @@
   ToTensor (uint8 HWC / 255 -> CHW float32), Resize(256) = bilinear interpolation with half-pixel centres
   (src = (dst + 0.5) * in/out - 0.5, clamped at 0; no antialiasing), smaller edge -> 256 and the longer edge
   int(256 * long / short), CenterCrop (offset round((H - h) / 2)), Normalize ((x - 0.5) / 0.5).
-PARITY UNPINNED against the reference itself: torchvision is not installed in the build container, so no golden
-vector of the real chain exists; this file pins the formula.
+Pinned by tests/golden/resize_chain.npz (oracle/tools/gen_resize_golden.py): the output of the ATen interpolate call
+torchvision 0.14.x makes for tensor inputs.  torchvision itself is not installed in the build container, so the
+pin is at that operator, not at the torchvision wrapper.
 """
 import numpy as np
 

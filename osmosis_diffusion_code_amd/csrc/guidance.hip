@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void guide_update_kernel(const float* __restri
     if (g) grad = c0 * g[i] + (dxu ? dxu[i] : 0.f);
     if (grad_out) grad_out[i] = grad;
     float gc = grad;
-    if (clip > 0.f) gc = (grad != grad) ? grad : fminf(fmaxf(grad, -clip), clip);   // torch.clamp keeps NaN (fminf/fmaxf would drop it)
+    if (clip >= 0.f) gc = (grad != grad) ? grad : fminf(fmaxf(grad, -clip), clip);   // torch.clamp keeps NaN (fminf/fmaxf would drop it)
     float xt = mean[i] - (g ? scale4[c] * gc : 0.f);
     if (noise_on != 0.f && noise) xt += expf(0.5f * logvar[i]) * noise[i];
     x_next[i] = xt;
@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256) void guide_update_kernel(const float* __restri
 //   eps = model_out[:, :C] ; x_next = c_a (x - c_b eps) + c_s z ; x0 = c_r x - c_m eps
 // coef = {c_a, c_b, c_s, c_r, c_m, -, -, t}
 __global__ __launch_bounds__(256) void ancestral_step_kernel(const float* __restrict__ mo,
-                                                              const float* __restrict__ x,
+                                                              const float* x,   // may alias x_next (in place)
                                                               const float* __restrict__ z,
                                                               const float* __restrict__ coef,
-                                                              float* __restrict__ x_next, float* __restrict__ x0,
+                                                              float* x_next, float* __restrict__ x0,
                                                               int B, int C, int Cout, int HW) {
   const long long total = (long long)B * C * HW;
   const float ca = coef[0], cb = coef[1], cs = coef[2], cr = coef[3], cm = coef[4];
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void ancestral_step_kernel(const float* __rest
 }
 
 __global__ void fetch_coefs_kernel(const float* __restrict__ table, int* __restrict__ step, int delta,
-                                   float* __restrict__ coef_out, float* __restrict__ t_out, int B) {
-  const int s = *step;
+                                   float* __restrict__ coef_out, float* __restrict__ t_out, int B, int n_rows) {
+  const int s = min(max(*step, 0), n_rows - 1);   // a counter that ran off the table re-reads its last row
   if (threadIdx.x < 8) coef_out[threadIdx.x] = table[s * 8 + threadIdx.x];
   if (threadIdx.x < B) t_out[threadIdx.x] = table[s * 8 + 7];
   __syncthreads();
@@ -354,11 +354,11 @@ extern "C" int osm_guide_update(const float* mean, const float* logvar, const fl
   return osm::check_launch("guide_update_kernel");
 }
 
-extern "C" int osm_fetch_coefs(const float* table, int* step, int delta, float* coef_out, float* t_out, int B,
-                               void* stream) {
-  OSM_REQUIRE(table && step && coef_out && t_out && B > 0 && B <= 256, "osm_fetch_coefs: bad argument");
+extern "C" int osm_fetch_coefs(const float* table, int n_rows, int* step, int delta, float* coef_out, float* t_out,
+                               int B, void* stream) {
+  OSM_REQUIRE(table && step && coef_out && t_out && B > 0 && B <= 256 && n_rows > 0, "osm_fetch_coefs: bad argument");
   hipLaunchKernelGGL(fetch_coefs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, step, delta, coef_out,
-                     t_out, B);
+                     t_out, B, n_rows);
   return osm::check_launch("fetch_coefs_kernel");
 }
 

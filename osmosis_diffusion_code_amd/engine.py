@@ -59,7 +59,6 @@ class _Res:
         self.n2 = _Norm(p.out_layers.at(0), dev)
         self.c2 = _Conv(p.out_layers.at(3), dev, wfmt)
         self.skip = _Conv(p.skip_connection, dev, wfmt) if p.skip_connection is not None else None
-        self.saved = None
 
 
 class _Attn:
@@ -68,35 +67,22 @@ class _Attn:
         self.norm = _Norm(p.norm, dev)
         self.qkv = _Conv(p.qkv, dev, wfmt)
         self.proj = _Conv(p.proj_out, dev, wfmt)
-        self.saved = None
 
 
-class UNetEngine:
-    def __init__(self, model, B: int, H: int, W: int, dev, conv_mode: str = "f32"):
-        self.B, self.H, self.W, self.dev = B, H, W, dev
+class UNetWeights:
+    """Device images of one model's parameters in one conv arithmetic: packed ONCE (2 x 3.3 GB of split-bf16
+    fragment images for the 552.8 M-parameter net) and shared by every engine of that model, whatever its
+    (B, H, W) -- engines own activations and launch plans only."""
+
+    def __init__(self, model, dev, conv_mode: str = "f32"):
         if conv_mode not in ops.WFMT:
             raise ValueError(f"conv_mode must be one of {sorted(ops.WFMT)}, got {conv_mode!r}")
-        self.conv_mode = conv_mode
+        self.dev, self.conv_mode = dev, conv_mode
         wfmt = ops.WFMT[conv_mode]
         self.mc = model.model_channels
         self.ted = 4 * self.mc
         self.cin, self.cout = model.in_channels, model.out_channels
-        nlev = len(model.channel_mult)
-        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
-            raise ValueError(f"H, W must be divisible by {1 << (nlev - 1)}")
-        self.ticket = 0
-        self.params_version = None
-        self._scratch: Dict[str, torch.Tensor] = {}
-        self._fwd_plan: Optional[Recorder] = None
-        self._bwd_plan: Optional[Recorder] = None
-        self._plan_stream = None
-        self._splitk_ws = None
-        # the recorded plans are replayed as hipGraphs (one graph launch instead of ~600 host-side launches per pass:
-        # 0.4 ms instead of 12 ms of host time per step); OSM_GRAPH=0 replays launch by launch
-        self.use_graph = os.environ.get("OSM_GRAPH", "1") != "0"
-        self._fwd_graph = self._bwd_graph = None
-        # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
-        self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
+        self.nlev = len(model.channel_mult)
 
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
@@ -129,6 +115,98 @@ class UNetEngine:
         self.eb_all = torch.cat([m.eb for m in res_blocks], 0).contiguous()
         for m in res_blocks:
             m.ew = m.eb = None
+
+
+def activation_bytes_per_image(w: UNetWeights, H: int, W: int, itemsize: int = 4) -> int:
+    """HBM bytes one image keeps resident in an engine (forward activations kept for the data-gradient pass,
+    the gradient buffers of the recorded backward plan, attention probabilities, scratch): a dry walk over the
+    same allocation logic as `UNetEngine._forward_impl / _backward_impl`.  Used to size the number of images
+    processed per pass (`UNetModel.images_in_flight`): ~8 GB per 256 x 256 image for the 552.8 M-parameter net."""
+    fixed = 0          # persistent buffers, elements of the activation type
+    f32 = 0            # fp32 elements (attention logits / probabilities)
+    scratch = {"a": 0, "b": 0, "c": 0, "s": 0}
+
+    def scr(slot, n):
+        scratch[slot] = max(scratch[slot], n)
+
+    def seq_cost(layers, hw, cin, last_has_dst):
+        nonlocal fixed, f32
+        c = cin
+        for i, l in enumerate(layers):
+            last = i == len(layers) - 1
+            if isinstance(l, _Res):
+                ho = (hw[0] * 2, hw[1] * 2) if l.up else ((hw[0] // 2, hw[1] // 2) if l.down else hw)
+                M, Mo = hw[0] * hw[1], ho[0] * ho[1]
+                fixed += Mo * l.cout                       # h1
+                if not (last and last_has_dst):
+                    fixed += Mo * l.cout                   # block output
+                fixed += M * l.cin if i > 0 else 0         # backward: d/d(input) of a non-first layer
+                scr("a", max(M * l.cin, Mo * l.cout))
+                scr("b", max(Mo * l.cin, Mo * l.cout, M * l.cin))
+                scr("c", max(Mo * l.cin, M * l.cin))
+                hw, c = ho, l.cout
+            else:
+                T = hw[0] * hw[1]
+                fixed += T * 3 * l.ch                      # qkv
+                if T > 64:
+                    f32 += 2 * l.heads * T * T             # P, P^T
+                    scr("s", 3 * l.heads * T * T)          # S / dP, dS, dS^T
+                if not (last and last_has_dst):
+                    fixed += T * l.ch
+                fixed += T * l.ch if i > 0 else 0
+                scr("a", T * l.ch)
+                scr("b", T * 3 * l.ch)
+        return hw, c
+
+    stem = w.inp[0][0]
+    chans, hws = [stem.cout], [(H, W)]
+    hw, c = (H, W), stem.cout
+    fixed += H * W * (w.cin + w.cout) * 3                  # x / out / gradients in NHWC
+    for layers in w.inp[1:]:
+        hw, c = seq_cost(layers, hw, c, True)
+        chans.append(c)
+        hws.append(hw)
+    hw, c = seq_cost(w.mid, hw, c, True)
+    n_in = len(w.inp)
+    for i, layers in enumerate(w.outb):
+        j = n_in - 1 - i
+        fixed += 2 * hws[j][0] * hws[j][1] * (c + chans[j])   # concat buffer + its gradient
+        hw, c = seq_cost(layers, hws[j], c + chans[j], i + 1 < len(w.outb))
+    fixed += 2 * H * W * c
+    scr("a", H * W * c)
+    splitk = 4 * 1024 * 1024                               # split-K partials (bounded by the ~1 workgroup / CU target)
+    return int(itemsize * (fixed + scratch["a"] + scratch["b"] + scratch["c"]) + 4 * (f32 + scratch["s"] + splitk))
+
+
+class UNetEngine:
+    def __init__(self, weights: UNetWeights, B: int, H: int, W: int):
+        dev = weights.dev
+        self.B, self.H, self.W, self.dev = B, H, W, dev
+        self.weights = weights
+        self.conv_mode = weights.conv_mode
+        self.mc, self.ted, self.cin, self.cout = weights.mc, weights.ted, weights.cin, weights.cout
+        nlev = weights.nlev
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
+            raise ValueError(f"H, W must be divisible by {1 << (nlev - 1)}")
+        self.ticket = 0
+        self._saved: Dict[int, dict] = {}       # per-block activations kept for the data-gradient pass
+        self.params_version = None
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self._fwd_plan: Optional[Recorder] = None
+        self._bwd_plan: Optional[Recorder] = None
+        self._plan_stream = None
+        self._splitk_ws = None
+        # the recorded plans are replayed as hipGraphs (one graph launch instead of ~600 host-side launches per pass:
+        # 0.4 ms instead of 12 ms of host time per step); OSM_GRAPH=0 replays launch by launch
+        self.use_graph = os.environ.get("OSM_GRAPH", "1") != "0"
+        self._fwd_graph = self._bwd_graph = None
+        # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
+        self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
+
+        w = weights
+        self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
+        self.out_norm, self.out_conv = w.out_norm, w.out_conv
+        self.film_cols, self.ew_all, self.eb_all = w.film_cols, w.ew_all, w.eb_all
 
         f32 = dict(device=dev, dtype=torch.float32)
         self.x_in = torch.zeros(B, self.cin, H, W, **f32)
@@ -229,11 +307,11 @@ class UNetEngine:
         else:
             res = xs
         self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res)
-        blk.saved = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo))
+        self._saved[id(blk)] = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo))
         return (ho, wo)
 
     def _res_bwd(self, blk: _Res, dy: Mat, dx_dst: Mat, accumulate: bool):
-        s = blk.saved
+        s = self._saved[id(blk)]
         B = self.B
         H, W = s["hw"]
         ho, wo = s["hwo"]
@@ -329,11 +407,11 @@ class UNetEngine:
             self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                        sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
         self._conv(a, blk.proj, dst, hw, res=x)
-        blk.saved = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused)
+        self._saved[id(blk)] = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused)
         return hw
 
     def _attn_bwd(self, blk: _Attn, dy: Mat, dx_dst: Mat, accumulate: bool):
-        s = blk.saved
+        s = self._saved[id(blk)]
         B = self.B
         hw = s["hw"]
         T = hw[0] * hw[1]
@@ -403,7 +481,7 @@ class UNetEngine:
         for i in range(len(layers) - 1, -1, -1):
             l = layers[i]
             first = i == 0
-            x_saved = l.saved["x"]
+            x_saved = self._saved[id(l)]["x"]
             d = dx_dst if first else self._buf(x_saved.rows, x_saved.cols)
             acc = accumulate if first else False
             if isinstance(l, _Res):

@@ -105,7 +105,9 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
     # ---------------------------------------------------------------- device state
     @property
     def clip_value(self) -> float:
-        return float(self.gradient_clip_value) if self.gradient_clip else 0.0
+        """Clamp bound handed to osm_guide_update: < 0 = no clipping.  The reference clamps only in its
+        gradient_x_prev branch (condition_methods.py:213-221); `gradient_clip: "True,0"` clamps to zero there."""
+        return float(self.gradient_clip_value) if (self.gradient_clip and self.gradient_x_prev) else -1.0
 
     def scale4(self, device):
         s = self.scale.to(torch.float32)
@@ -149,15 +151,21 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         self._state = st
         return st
 
-    def loss_grad_x0(self, x0, y, freeze_phi=False, g_out=None):
+    def loss_grad_x0(self, x0, y, freeze_phi=False, g_out=None, phi=None, loss_out=None):
         """Inner phi-optimisation + dL/dx0.  x0 [B,4,H,W], y [B,3,H,W] contiguous device fp32.
-        Returns (g [B,4,H,W] view of an internal buffer (or g_out), per-image data loss [B] (device))."""
+        Returns (g [B,4,H,W] view of an internal buffer (or g_out), per-image data loss [B] (device)).
+        `phi` / `loss_out`: rows of the operator's [B][9] state / of a [B] loss vector when the caller walks
+        a batch in chunks of independent images (default: the operator's whole state)."""
         B, HW = x0.shape[0], x0.shape[2] * x0.shape[3]
         if y.shape[0] != B or y.shape[1] != 3 or x0.shape[1] != 4:
             raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
         st = self._prepare(B, HW, x0.device)
         d, part, red, loss = st["desc"], st["part"], st["red"], st["loss"]
-        phi = self.operator.phi
+        if loss_out is not None:
+            loss = loss_out
+        phi = self.operator.phi if phi is None else phi
+        if phi.shape[0] != B or not phi.is_contiguous():
+            raise ValueError("phi must be a contiguous [B][9] block")
         g = g_out if g_out is not None else st["g"]
         x0c, yc = x0.contiguous(), y.contiguous()
         n_inner = 1 if freeze_phi else self.n_iter
@@ -209,7 +217,9 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         else:
             grad = g
         with torch.no_grad():
-            gc = torch.clamp(grad, -self.gradient_clip_value, self.gradient_clip_value) if self.gradient_clip else grad
+            # the reference clamps in the gradient_x_prev branch only (:213-221); the x0-gradient branch is unclipped
+            clip = self.gradient_clip and self.gradient_x_prev
+            gc = torch.clamp(grad, -self.gradient_clip_value, self.gradient_clip_value) if clip else grad
             x_t -= scale * gc
         aux = self.aux_values()
         aux = {k: v.detach().cpu().sum() for k, v in aux.items()} if aux is not None else None

@@ -208,71 +208,130 @@ class GaussianDiffusion:
         T = self.num_timesteps
         return sample_pattern["start_guidance"] * T >= idx >= sample_pattern["stop_guidance"] * T
 
-    def _fused_loop(self, model, cond, x_start, measurement, sample_pattern, kwargs):
+    def _fused_loop(self, model, cond, x_start, measurement, sample_pattern, kwargs, record=False, record_every=150):
         dev = x_start.device
         B, C, H, W = x_start.shape
         HW = H * W
         T = self.num_timesteps
-        eng = model.engine(B, H, W)
+        # optional sub-range of the chain (benchmarks / resumed chains): idx = first .. last, descending
+        first, last = kwargs.get("index_range", (T - 1, 0))
+        if not (0 <= last <= first <= T - 1):
+            raise ValueError(f"index_range must satisfy 0 <= last <= first <= {T - 1}, got ({first}, {last})")
+        # Images are independent chains: a batch whose kept activations would not fit the device
+        # (~8 GB per 256 x 256 image in fp32) is walked in equal chunks per step, through ONE engine of the chunk
+        # size; per-image state (x_t, phi, losses) stays in [B]-sized tensors, the chunks are contiguous row blocks.
+        cap = model.images_in_flight(B, H, W)
+        Bc = max(d for d in range(1, min(B, cap) + 1) if B % d == 0)
+        chunks = [(c0, c0 + Bc) for c0 in range(0, B, Bc)]
+        eng = model.engine(Bc, H, W)
         f32 = dict(device=dev, dtype=torch.float32)
         table = torch.from_numpy(self.coef_table()).to(dev)
-        step = torch.tensor([T - 1], device=dev, dtype=torch.int32)
+        step = torch.tensor([first], device=dev, dtype=torch.int32)
         coef = torch.zeros(8, **f32)
         x0, mean, logvar = (torch.empty(B, 4, H, W, **f32) for _ in range(3))
         g = torch.empty(B, 4, H, W, **f32)
         noise = torch.zeros(B, 4, H, W, **f32)
+        loss_all = torch.zeros(B, **f32)
         scale4 = cond.scale4(dev)
         y = measurement.detach().to(dev, torch.float32).contiguous()
-        eng.x_in.copy_(x_start.detach())
+        phi = cond.operator.phi
+        single = len(chunks) == 1
+        x_state = eng.x_in if single else torch.empty(B, 4, H, W, **f32)
+        x_state.copy_(x_start.detach())
         noise_fn = kwargs.get("noise_fn", None)           # (k, shape) -> tensor : injected noise (parity runs)
         trace = kwargs.get("trace", None)                 # list collecting per-step tensors (tests)
         draw_measurement_noise = kwargs.get("reference_rng_order", noise_fn is None)
-        loss = None
-        # optional sub-range of the chain (benchmarks / resumed chains): idx = first .. last, descending
-        first, last = kwargs.get("index_range", (T - 1, 0))
-        step.fill_(first)
+        records = kwargs.get("record_out", [] if record else None)   # (idx, pred_xstart cpu) snapshots
+        # every image of the batch receives the SAME noise (what separate, identically seeded batch-1 runs would draw)
+        noise1 = torch.zeros(1, 4, H, W, **f32) if kwargs.get("shared_noise", False) and B > 1 else None
+        have_loss = False
         for k, idx in enumerate(range(first, last - 1, -1)):
             guided = self._guidance_flag(sample_pattern, idx)
             freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
-            if draw_measurement_noise:
-                torch.randn_like(y)                       # q_sample's unused draw (reference :241) keeps RNG order
+            if draw_measurement_noise:                    # q_sample's unused draw (reference :241) keeps RNG order
+                torch.randn_like(y[:1] if noise1 is not None else y)
             if noise_fn is not None:
                 noise.copy_(noise_fn(k, noise.shape))
+            elif noise1 is not None:
+                noise1.normal_()
+                noise.copy_(noise1.expand_as(noise))
             else:
                 noise.normal_()
-            ops.fetch_coefs(table, step, -1, coef, eng.t_dev, B)
-            eng.run_forward()
-            ops.posterior(eng.out, eng.x_in, coef, x0, mean, logvar, B, HW)
+            ops.fetch_coefs(table, step, -1, coef, eng.t_dev, Bc)
             if trace is not None:
-                rec = {"x_in": eng.x_in.clone(), "x0": x0.clone(), "mean": mean.clone()}
-            if guided:
-                _, loss = cond.loss_grad_x0(x0, y, freeze_phi=freeze, g_out=g)
-                ops.posterior_bwd(g, coef, eng.d_out, B, HW)
-                eng.run_backward()
-                grad_out = None
-                if trace is not None:
-                    grad_out = rec["grad"] = torch.empty_like(g)
-                ops.guide_update(mean, logvar, g, eng.dx, noise, coef, scale4, cond.clip_value, eng.x_in,
-                                 grad_out, B, HW)
-            else:
-                ops.guide_update(mean, logvar, None, None, noise, coef, None, 0.0, eng.x_in, None, B, HW)
+                rec = {"x_in": x_state.clone()}
+                grad_all = torch.empty_like(g) if guided else None
+            for c0, c1 in chunks:
+                if not single:
+                    eng.x_in.copy_(x_state[c0:c1])
+                eng.run_forward()
+                ops.posterior(eng.out, eng.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW)
+                if guided:
+                    cond.loss_grad_x0(x0[c0:c1], y[c0:c1], freeze_phi=freeze, g_out=g[c0:c1], phi=phi[c0:c1],
+                                      loss_out=loss_all[c0:c1])
+                    have_loss = True
+                    ops.posterior_bwd(g[c0:c1], coef, eng.d_out, Bc, HW)
+                    eng.run_backward()
+                    grad_out = grad_all[c0:c1] if trace is not None else None
+                    ops.guide_update(mean[c0:c1], logvar[c0:c1], g[c0:c1], eng.dx, noise[c0:c1], coef, scale4,
+                                     cond.clip_value, x_state[c0:c1], grad_out, Bc, HW)
+                else:
+                    ops.guide_update(mean[c0:c1], logvar[c0:c1], None, None, noise[c0:c1], coef, None, -1.0,
+                                     x_state[c0:c1], None, Bc, HW)
             if trace is not None:
-                rec["x_out"] = eng.x_in.clone()
-                rec["loss"] = loss.clone() if loss is not None else None
-                rec["phi"] = cond.operator.phi.clone()
+                rec.update(x0=x0.clone(), mean=mean.clone(), x_out=x_state.clone(),
+                           loss=loss_all.clone() if have_loss else None, phi=phi.clone())
+                if guided:
+                    rec["grad"] = grad_all
                 trace.append(rec)
-        img = eng.x_in.clone()
+            # snapshots of pred_xstart during the chain (reference :308-327): same steps, one D2H copy each
+            if records is not None and ((idx % record_every == 0) or idx == 0 or idx == 999):
+                records.append((idx, x0.detach().cpu()))
+        img = x_state.clone()
         variables = cond.operator.optimize(freeze_phi=True)
-        loss_np = loss.detach().cpu().numpy() if loss is not None else None
+        loss_np = loss_all.detach().cpu().numpy() if have_loss else None
+        if record and records:
+            self._save_process_grid(records, kwargs.get("save_grids_path"), kwargs.get("original_file_name"))
         return img, variables, loss_np, x0.detach().cpu()
+
+    @staticmethod
+    def _save_process_grid(records, save_grids_path, original_file_name):
+        """`<name>_process.png` of the reference (:308-333): clipped RGB of image 0 on the first row, the
+        percentile-normalised viridis depth on the second, one column per recorded step (2-pixel padding, as
+        torchvision.utils.make_grid lays it out)."""
+        if save_grids_path is None:
+            return None
+        import os
+
+        from PIL import Image
+        rgb = [torch.clamp(0.5 * (x0[0, 0:3] + 1), 0, 1) for _, x0 in records]
+        dep = [utilso.depth_tensor_to_color_image(
+            utilso.min_max_norm_range_percentile(x0[:, 3], percent_low=0.05, percent_high=0.99)) for _, x0 in records]
+        dep = [d.reshape(3, *d.shape[-2:]) for d in dep]
+        tiles, ncol, pad = rgb + dep, len(rgb), 2
+        h, w = tiles[0].shape[-2:]
+        nrow = (len(tiles) + ncol - 1) // ncol
+        grid = torch.zeros(3, nrow * (h + pad) + pad, ncol * (w + pad) + pad)
+        for i, t in enumerate(tiles):
+            r, c = divmod(i, ncol)
+            grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + c * (w + pad): pad + c * (w + pad) + w] = t
+        arr = (grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy()
+        path = os.path.join(save_grids_path, f"{original_file_name}_process.png")
+        Image.fromarray(arr).save(path)
+        return path
 
     # ------------------------------------------------------------------ public loop
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root,
                       pretrain_model=None, image_idx=None, record_every=150, rgb_guidance=False,
                       sample_pattern=None, **kwargs):
         cond = self._fast_path_ok(model, measurement_cond_fn, pretrain_model, rgb_guidance, sample_pattern)
-        if cond is not None and not record:
-            return self._fused_loop(model, cond, x_start, measurement, sample_pattern, kwargs)
+        if cond is not None:
+            return self._fused_loop(model, cond, x_start, measurement, sample_pattern, kwargs, record=record,
+                                    record_every=record_every)
+        if record:
+            import warnings
+            warnings.warn("record=True is honoured by the fused Osmosis loop only; this configuration runs the generic "
+                          "autograd loop, which does not record intermediate images")
         return self._generic_loop(model, x_start, measurement, measurement_cond_fn, pretrain_model,
                                   rgb_guidance, sample_pattern, kwargs)
 

@@ -22,7 +22,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
-from ..engine import UNetEngine
+from ..engine import UNetEngine, UNetWeights, activation_bytes_per_image
 
 NUM_CLASSES = 1000
 
@@ -152,6 +152,7 @@ class UNetModel(nn.Module):
         self.out = _Seq({0: _Slot((ch,), (ch,), "norm"), 2: _Slot((out_channels, ch, 3, 3), (out_channels,))})
         self.reset_parameters()
         self._engines: Dict[Tuple, UNetEngine] = {}
+        self._weights: Dict[Tuple, Tuple] = {}
         # arithmetic of the conv / 1x1 contractions: "f32" exact-fp32 MFMA (parity mode), "bf16x6"
         # (fp32 split into 3 bf16 terms, 6 MFMAs: fp32-class accuracy), "bf16x3" (2 terms, ~2^-16)
         self.conv_mode = os.environ.get("OSM_CONV_MODE", "bf16x6")
@@ -181,19 +182,54 @@ class UNetModel(nn.Module):
     def _params_version(self):
         return tuple(p._version for p in self.parameters())
 
-    def engine(self, B: int, H: int, W: int) -> UNetEngine:
+    def _device(self):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs only on a HIP device (model.to('cuda')); "
                                "there is no CPU fallback on the product path")
-        key = (B, H, W, str(dev), self.conv_mode)
-        eng = self._engines.get(key)
+        return dev
+
+    def packed_weights(self) -> UNetWeights:
+        """Weight images of the current parameters in the current conv arithmetic: packed once per
+        (device, conv_mode, parameter version) and shared by every engine, whatever its batch / image size."""
+        dev = self._device()
+        key = (str(dev), self.conv_mode)
         ver = self._params_version()
-        if eng is None or eng.params_version != ver:
-            eng = UNetEngine(self, B, H, W, dev, conv_mode=self.conv_mode)
-            eng.params_version = ver
-            self._engines = {key: eng}      # one live engine: activations are large
+        hit = self._weights.get(key)
+        if hit is None or hit[0] != ver:
+            self._engines = {}
+            self._weights = {key: (ver, UNetWeights(self, dev, conv_mode=self.conv_mode))}   # one arithmetic resident
+            hit = self._weights[key]
+        return hit[1]
+
+    def engine(self, B: int, H: int, W: int) -> UNetEngine:
+        w = self.packed_weights()
+        key = (B, H, W, str(w.dev), self.conv_mode)
+        eng = self._engines.get(key)
+        if eng is None or eng.weights is not w:
+            self._engines = {}              # one live engine: activations are large (~8 GB per 256 x 256 image)
+            eng = UNetEngine(w, B, H, W)
+            eng.params_version = self._params_version()
+            self._engines = {key: eng}
         return eng
+
+    def images_in_flight(self, B: int, H: int, W: int) -> int:
+        """How many of B independent images one pass should carry so that the activations kept for the
+        data-gradient pass fit the device (288 GB on MI355X): the largest divisor-free chunk <= B whose footprint
+        stays under `OSM_ACT_BUDGET_GB` (default: 80 % of the free memory).  Images are independent chains
+        (SURVEY.md F1/F2), so a batch processed in chunks is the same computation."""
+        w = self.packed_weights()
+        per = activation_bytes_per_image(w, H, W, 4)
+        env = os.environ.get("OSM_ACT_BUDGET_GB")
+        if env:
+            budget = float(env) * 2 ** 30
+        else:
+            free, _total = torch.cuda.mem_get_info(w.dev)
+            held = sum(e.B for e in self._engines.values() if (e.H, e.W) == (H, W)) * per   # reusable: the live engine
+            budget = 0.8 * (free + held)
+        cap = os.environ.get("OSM_MAX_BATCH")
+        n = max(1, min(B, int(budget // per), int(cap) if cap else B))
+        return n
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, timesteps, y=None):

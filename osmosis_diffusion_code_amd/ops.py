@@ -249,7 +249,8 @@ def guide_update(mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, gr
 
 
 def fetch_coefs(table, step, delta, coef_out, t_out, B):
-    call("osm_fetch_coefs", ptr(table), ptr(step), delta, ptr(coef_out), ptr(t_out), B, _s(),
+    """table: [n_rows][8] device fp32; the device-side row counter `step` is clamped to the table."""
+    call("osm_fetch_coefs", ptr(table), int(table.shape[0]), ptr(step), delta, ptr(coef_out), ptr(t_out), B, _s(),
          keep=(table, step, coef_out, t_out))
 
 

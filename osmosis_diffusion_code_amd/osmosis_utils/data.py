@@ -5,8 +5,9 @@ without torchvision / cv2 / natsort (none of them is in this image): PIL + torch
 
 Resize follows the pinned torchvision 0.14.1 behaviour for TENSOR inputs (the chain resizes after ToTensor):
 bilinear, align_corners=False, NO antialiasing, smaller edge -> `size`, longer edge -> int(size * long / short).
-PARITY UNPINNED for that one step: torchvision is absent, so the reference chain cannot be executed here; the
-oracle restatement (oracle/data_ref.py) pins this implementation to the published half-pixel bilinear formula.
+torchvision is absent here, so the pin is one level down: tests/golden/resize_chain.npz holds the output of the
+ATen call torchvision 0.14.x makes (`interpolate(..., "bilinear", align_corners=False, antialias=False)`,
+oracle/tools/gen_resize_golden.py); this module and the numpy restatement oracle/data_ref.py are both tested against it.
 Host-side code; the sampler takes the resulting [B,3,256,256] tensor in [-1, 1].
 """
 import glob

@@ -62,6 +62,9 @@ class GaussianDiffusion:
             x = torch.randn((1,) + tuple(shape), device=dev)
         start_t = self.T if start_t is None else start_t
         steps = self.T if steps is None else steps
+        if not (1 <= start_t <= self.T and 1 <= steps <= start_t):
+            raise ValueError(f"inverse(): need 1 <= start_t - steps + 1 <= start_t <= T = {self.T} "
+                             f"(got start_t = {start_t}, steps = {steps})")
         B, C, H, W = x.shape
         HW = H * W
         eng = net.engine(B, H, W)

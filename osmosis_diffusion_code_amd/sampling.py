@@ -85,10 +85,16 @@ def depth_color(post):
     return utilso.depth_tensor_to_color_image(post["depth_pmm"])
 
 
-def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, **loop_kwargs):
+def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, same_seed_per_image=False,
+                  **loop_kwargs):
     """One image through the reference's per-image sequence: fresh operator / noiser / conditioning method /
     sampler (:142-155), y = noiser(ref) (+ degamma), manual_seed + x_T ~ N(0, I) per global iteration
-    (:191-196), guided p_sample_loop, post-processing.  Returns a list with one dict per global iteration."""
+    (:191-196), guided p_sample_loop, post-processing.  Returns a list with one dict per global iteration.
+
+    `ref_img` may carry B > 1 images: one batch of independent chains.  With `same_seed_per_image` every image of
+    the batch starts from the SAME x_T and receives the SAME per-step noise -- exactly what B separate calls (each
+    re-seeded with `manual_seed`, as the reference driver does per image) would draw -- so an image's result does not
+    depend on how images are grouped into batches or spread over ranks."""
     device = device if device is not None else ref_img.device
     measure, cond_cfg = cfg["measurement"], cfg["conditioning"]
     op_cfg = dict(measure["operator"])
@@ -108,27 +114,75 @@ def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, **
     results = []
     for global_ii in range(global_iterations(cfg["sample_pattern"])):
         torch.manual_seed(cfg.get("manual_seed", 0))
-        x_start = torch.randn(shape, device=device)
+        if same_seed_per_image and shape[0] > 1:
+            x_start = torch.randn([1] + shape[1:], device=device).repeat(shape[0], 1, 1, 1)
+            loop_kwargs = dict(loop_kwargs, shared_noise=True)
+        else:
+            x_start = torch.randn(shape, device=device)
         if x_scale != 1.0:          # sub-chains started at a low timestep (tools/full_chain.py --last)
             x_start = x_start * x_scale
-        sample, variable_dict, loss, out_xstart = sampler.p_sample_loop(
+        rgb_guidance = cfg.get("rgb_guidance", False)
+        ret = sampler.p_sample_loop(
             model=model, x_start=x_start, measurement=y_n, measurement_cond_fn=cond.conditioning,
-            record=False, save_root=None, pretrain_model=pretrain, image_idx=image_idx,
-            rgb_guidance=cfg.get("rgb_guidance", False), sample_pattern=cfg["sample_pattern"],
-            global_iteration=global_ii, **loop_kwargs)
+            record=cfg.get("record_process", False) and loop_kwargs.get("save_grids_path") is not None, save_root=None,
+            pretrain_model=pretrain, image_idx=image_idx, record_every=cfg.get("record_every", 150),
+            rgb_guidance=rgb_guidance, sample_pattern=cfg["sample_pattern"], global_iteration=global_ii, **loop_kwargs)
+        if rgb_guidance or pretrain != "osmosis":
+            # the rgb-guidance / non-osmosis chain returns the sample only (gaussian_diffusion.py:340); the
+            # reference driver splits it into RGB and depth (osmosis_sampling.py:366-380): no phi, no recomposition
+            sample = ret.detach().cpu()
+            depth3 = sample[0, -1].repeat(3, 1, 1)
+            results.append({"sample": sample, "rgb": sample[0, 0:-1],
+                            "rgb_01_clip": torch.clamp(0.5 * (sample[0, 0:-1] + 1), 0, 1),
+                            "depth_mm": utilso.min_max_norm_range(depth3, vmin=0, vmax=1, is_uint8=False),
+                            "depth_pmm": utilso.min_max_norm_range_percentile(depth3, percent_low=0.05,
+                                                                              percent_high=0.99),
+                            "measurement": y_n.detach().cpu()})
+            continue
+        sample, variable_dict, loss, out_xstart = ret
         post = postprocess(out_xstart, variable_dict, ref_img, measure["operator"], loss)
         post.update(sample=sample.detach().cpu(), pred_xstart=out_xstart, measurement=y_n.detach().cpu())
         results.append(post)
     return results
 
 
-def restore_images(model, images, cfg, rank=0, world=1, device=None, gt_rgb=None):
+def postprocess_each(out_xstart, variable_dict, ref_img, operator_cfg, loss=None):
+    """`postprocess` for every image of a batch (the reference only ever has one)."""
+    outs = []
+    for b in range(out_xstart.shape[0]):
+        vd = {k: v[b:b + 1] for k, v in variable_dict.items()}
+        outs.append(postprocess(out_xstart[b:b + 1], vd, ref_img[b:b + 1], operator_cfg,
+                                None if loss is None else np.asarray(loss)[b:b + 1]))
+    return outs
+
+
+def restore_images(model, images, cfg, rank=0, world=1, device=None, gt_rgb=None, batch_size=1, **loop_kwargs):
     """images[rank::world] (no collective on the path; SURVEY.md 8e).  Returns {image index: result dict of the
-    last global iteration}; when `gt_rgb` (list of [3,H,W] in [0,1]) is given each result carries `psnr`."""
+    last global iteration}; when `gt_rgb` (list of [3,H,W] in [0,1]) is given each result carries `psnr`.
+
+    `batch_size` > 1 carries that many of this rank's images per pass (BASELINE config 4: 8 images per GPU): they
+    are independent chains with per-image phi, per-image reductions and -- like the reference's per-image
+    `manual_seed` -- the same x_T / noise stream each, so image i's result is the one a batch-1 run gives."""
     out = {}
-    for i in shard_indices(len(images), rank, world):
-        res = restore_image(model, images[i], cfg, device=device, image_idx=i)[-1]
-        if gt_rgb is not None:
-            res["psnr"] = float(utilso.psnr(res["rgb_01_clip"], gt_rgb[i]))
-        out[i] = res
+    mine = shard_indices(len(images), rank, world)
+    for k in range(0, len(mine), max(1, batch_size)):
+        idxs = mine[k:k + max(1, batch_size)]
+        if len(idxs) == 1:
+            res = [restore_image(model, images[idxs[0]], cfg, device=device, image_idx=idxs[0], **loop_kwargs)[-1]]
+        else:
+            ref = torch.cat([images[i] for i in idxs], 0)
+            full = restore_image(model, ref, cfg, device=device, image_idx=idxs[0], same_seed_per_image=True,
+                                 **loop_kwargs)[-1]
+            if "pred_xstart" in full:
+                res = postprocess_each(full["pred_xstart"], full["phi"], ref, cfg["measurement"]["operator"], full["loss"])
+                for b, r in enumerate(res):
+                    r.update(sample=full["sample"][b:b + 1], pred_xstart=full["pred_xstart"][b:b + 1],
+                             measurement=full["measurement"][b:b + 1])
+            else:
+                res = [{"sample": full["sample"][b:b + 1],
+                        "rgb_01_clip": torch.clamp(0.5 * (full["sample"][b, 0:3] + 1), 0, 1)} for b in range(len(idxs))]
+        for i, r in zip(idxs, res):
+            if gt_rgb is not None:
+                r["psnr"] = float(utilso.psnr(r["rgb_01_clip"], gt_rgb[i]))
+            out[i] = r
     return out

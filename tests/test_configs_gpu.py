@@ -1,0 +1,211 @@
+"""BASELINE.json configurations 3, 4 and 5 at FULL size (552.8 M-parameter UNet, 256 x 256) through the fused guided
+loop, plus one full-size guided step against the CPU oracle.  The reference sampler only works at batch 1 (SURVEY.md
+F1/F2), so batched results are defined -- and checked -- as "what batch-1 runs of the same images give".
+
+Seeded synthetic weights do not denoise, so chains are started at low t from a noised synthetic ground truth made with
+the operator's own image-formation model: pred_xstart then stays inside the physical model's range
+and the PSNR against the ground truth is a meaningful number."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import baseline_configs as BC
+from oracle import diffusion_ref as D
+from oracle import unet_ref as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = unet.create_model(**BC.UNET)
+    model.reset_parameters(1234)
+    return model.to(DEV).eval()
+
+
+def synthetic_scene(n, size=256, seed=0, kind="underwater_physical", phi_ab=(1.1, 0.95, 0.95), phi_inf=(0.2, 0.4, 0.7),
+                    depth_type="original"):
+    """n smooth RGBD ground-truth images in [-1, 1] and their degraded observations y = 2 I - 1 in [-1, 1]."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(n, 4, 8, 8, generator=g)
+    gt = torch.nn.functional.interpolate(low, size=(size, size), mode="bicubic", align_corners=False).clamp(0.02, 0.98)
+    gt = 2 * gt - 1
+    depth = D.convert_depth(gt[:, 3:4], depth_type, D.parse_value("1.4,1.4,1"))
+    pa = torch.tensor(phi_ab).view(1, 3, 1, 1)
+    pinf = torch.tensor(phi_inf).view(1, 3, 1, 1)
+    I = 0.5 * (gt[:, 0:3] + 1) * torch.exp(-pa * depth) + pinf * (1 - torch.exp(-pa * depth))
+    return gt, 2 * I - 1
+
+
+def noised_start(gt, sampler, idx, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    ab = float(sampler.alphas_cumprod[idx])
+    return np.sqrt(ab) * gt + np.sqrt(1 - ab) * torch.randn(gt.shape, generator=g)
+
+
+def run_chain(model, cfg, x_start, y, steps, noise, B=None):
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    B = x_start.shape[0]
+    opc = dict(cfg["measurement"]["operator"])
+    name = opc.pop("name")
+    op = M.get_operator(name, device=DEV, batch_size=B, **opc)
+    cond = CM.get_conditioning_method(cfg["conditioning"]["method"], op, M.get_noise("clean"),
+                                      **cfg["conditioning"]["params"], **cfg["sample_pattern"], **cfg["aux_loss"])
+    sampler = gd.create_sampler(**cfg["diffusion"])
+    nd = noise.to(DEV)
+    img, variables, loss, x0 = sampler.p_sample_loop(
+        model=model, x_start=x_start.to(DEV), measurement=y.to(DEV), measurement_cond_fn=cond.conditioning,
+        record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+        sample_pattern=cfg["sample_pattern"], index_range=(steps - 1, 0), noise_fn=lambda k, shape: nd[k])
+    return img.cpu(), {k: v.cpu() for k, v in variables.items()}, np.asarray(loss), x0
+
+
+def test_config3_simulation_batch8_psnr(full_model):
+    """osmosis_simulation_sample_config.yaml: B = 8, `underwater_physical`, depth_type original, val_loss 40, scale
+    4,4,4,1, clip 0.001 -- the last 3 steps of the 1000-step chain from a noised synthetic ground truth; restored RGB is
+    scored with PSNR against that ground truth; image 0 and 7 equal their batch-1 runs."""
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.osmosis_utils import utils as utilso
+    cfg = BC.SIMULATION
+    sampler = gd.create_sampler(**cfg["diffusion"])
+    gt, y = synthetic_scene(8, seed=3)
+    x_start = noised_start(gt, sampler, 2)
+    noise = torch.randn(3, 8, 4, 256, 256, generator=torch.Generator().manual_seed(9))
+    img, variables, loss, x0 = run_chain(full_model, cfg, x_start, y, 3, noise)
+    assert torch.isfinite(img).all() and torch.isfinite(x0).all() and np.isfinite(loss).all()
+    rgb = torch.clamp(0.5 * (x0[:, 0:3] + 1), 0, 1)
+    psnr = utilso.psnr(rgb, 0.5 * (gt[:, 0:3] + 1))
+    print("config 3: per-image PSNR (dB) vs synthetic GT", [round(float(p), 2) for p in psnr], "loss", loss)
+    assert psnr.shape == (8,) and float(psnr.min()) > 20.0
+    assert set(variables) == {"phi_ab", "phi_inf"} and variables["phi_ab"].shape == (8, 3, 1, 1)
+    for i in (0, 7):
+        s_img, s_vars, s_loss, s_x0 = run_chain(full_model, cfg, x_start[i:i + 1], y[i:i + 1], 3, noise[:, i:i + 1])
+        assert float((img[i] - s_img[0]).abs().max()) < 2e-5
+        assert float((x0[i] - s_x0[0]).abs().max()) < 2e-5
+        assert abs(loss[i] - s_loss[0]) < 1e-4 * abs(s_loss[0])
+        for k in variables:
+            assert torch.allclose(variables[k][i], s_vars[k][0], atol=1e-7), k
+
+
+def test_config4_eight_images_per_gpu(full_model):
+    """osmosis_sample_config.yaml on a 64-image set sharded 8 per GPU: this rank's share, `restore_images(...,
+    rank=3, world=8, batch_size=8)`, carried as ONE batch of 8 independent chains.  Every image must come out as the
+    batch-1 call gives it (same seed -> same x_T and noise stream per image, like the reference's per-image
+    manual_seed), and weight images are shared between the B = 8 and B = 1 engines (no re-pack)."""
+    from osmosis_diffusion_code_amd import sampling
+    cfg = BC.SAMPLE
+    gt, y = synthetic_scene(64, seed=11, phi_ab=(1.1, 0.95, 0.95), phi_inf=(0.14, 0.29, 0.49), depth_type="gamma")
+    images = [y[i:i + 1] for i in range(64)]
+    w0 = full_model.packed_weights()
+    out8 = sampling.restore_images(full_model, images, cfg, rank=3, world=8, device=DEV, batch_size=8,
+                                   gt_rgb=[0.5 * (gt[i, 0:3] + 1) for i in range(64)],
+                                   index_range=(2, 0), x_scale=0.05)
+    assert sorted(out8) == list(range(3, 64, 8))
+    assert all(np.isfinite(r["psnr"]) and torch.isfinite(r["pred_xstart"]).all() for r in out8.values())
+    one = sampling.restore_images(full_model, images, cfg, rank=3 + 8 * 5, world=64, device=DEV, batch_size=1,
+                                  index_range=(2, 0), x_scale=0.05)
+    assert list(one) == [43]
+    assert full_model.packed_weights() is w0        # B = 8 <-> B = 1: engines change, weight images do not
+    a, b = out8[43], one[43]
+    assert float((a["pred_xstart"] - b["pred_xstart"]).abs().max()) < 2e-5
+    assert float((a["sample"] - b["sample"]).abs().max()) < 2e-5
+    assert float((a["forward_predicted"] - b["forward_predicted"]).abs().max()) < 2e-5
+    for k in a["phi"]:
+        assert torch.allclose(a["phi"][k], b["phi"][k], atol=1e-7)
+
+
+def test_config5_haze_batch32_respaced(full_model, monkeypatch):
+    """osmosis_haze_sample_config.yaml as BASELINE.json quotes it: B = 32, `haze_physical`, degamma_input,
+    timestep_respacing 250; fp32 activations of 32 images (~260 GB) do not fit next to the weights, so the batch is
+    walked in chunks of independent images through one engine -- image 0 and image 31 (different chunks) equal their
+    batch-1 runs.  (The fp16-storage variant of this config is tests/test_fp16_gpu.py.)"""
+    from osmosis_diffusion_code_amd import sampling
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    cfg = BC.with_unet(BC.HAZE, BC.UNET)
+    sampler = gd.create_sampler(**cfg["diffusion"])
+    assert sampler.num_timesteps == 250 and sampler.timestep_map[:3] == [0, 4, 8]
+    gt, y = synthetic_scene(32, seed=21, phi_ab=(1.0, 1.0, 1.0), phi_inf=(0.14, 0.29, 0.49), depth_type="gamma")
+    y = 2 * torch.pow(0.5 * (y + 1), 1 / 2.2) - 1            # a gamma-encoded observation; the driver de-gammas it
+    yl = sampling.degamma(y)
+    x_start = noised_start(gt, sampler, 2)
+    noise = torch.randn(3, 32, 4, 256, 256, generator=torch.Generator().manual_seed(2))
+    img, variables, loss, x0 = run_chain(full_model, cfg, x_start, yl, 3, noise)
+    eng = next(iter(full_model._engines.values()))
+    print("config 5: images per pass", eng.B, "of 32; loss[:4]", loss[:4])
+    assert eng.B < 32 and 32 % eng.B == 0                    # chunked
+    assert torch.isfinite(img).all() and torch.isfinite(x0).all() and np.isfinite(loss).all()
+    assert variables["phi_ab"].shape == (32, 1, 1, 1) and variables["phi_inf"].shape == (32, 3, 1, 1)
+    for i in (0, 31):
+        s_img, s_vars, s_loss, s_x0 = run_chain(full_model, cfg, x_start[i:i + 1], yl[i:i + 1], 3, noise[:, i:i + 1])
+        assert float((img[i] - s_img[0]).abs().max()) < 2e-5
+        assert float((x0[i] - s_x0[0]).abs().max()) < 2e-5
+        for k in variables:
+            assert torch.allclose(variables[k][i], s_vars[k][0], atol=1e-7), k
+
+
+def test_full_size_guided_step_vs_oracle(full_model):
+    """ONE complete guided step of config 2 (B = 1, 256 x 256, 552.8 M parameters, n_iter = 20 phi iterations, UNet
+    forward + input gradient, posterior, clipped guidance update, noise) against the CPU oracle, same weights / x_t /
+    y / noise.  Tolerance: north-star 1e-3 max-abs on x_{t-1} and pred_xstart; the unclipped gradient to 2e-4 of
+    its max."""
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    cfg = BC.SAMPLE
+    ucfg = U.UNetConfig.from_create_model_kwargs(**BC.UNET)
+    sd = U.seeded_state_dict(ucfg, 1234)
+    full_model.load_state_dict(sd, strict=True)
+    try:
+        sampler = gd.create_sampler(**cfg["diffusion"])
+        gt, y = synthetic_scene(1, seed=5, phi_ab=(1.1, 0.95, 0.95), phi_inf=(0.14, 0.29, 0.49), depth_type="gamma")
+        idx = 3
+        x_t = noised_start(gt, sampler, idx)
+        noise = torch.randn(1, 1, 4, 256, 256, generator=torch.Generator().manual_seed(4))
+        trace = []
+        from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+        from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+        opc = dict(cfg["measurement"]["operator"])
+        name = opc.pop("name")
+        op = M.get_operator(name, device=DEV, batch_size=1, **opc)
+        cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **cfg["conditioning"]["params"],
+                                          **cfg["sample_pattern"], **cfg["aux_loss"])
+        nd = noise.to(DEV)
+        img, variables, loss, x0 = sampler.p_sample_loop(
+            model=full_model, x_start=x_t.to(DEV), measurement=y.to(DEV), measurement_cond_fn=cond.conditioning,
+            record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+            sample_pattern=cfg["sample_pattern"], index_range=(idx, idx), noise_fn=lambda k, shape: nd[k], trace=trace)
+        # ---- oracle: the body of the reference loop for this idx (oracle/diffusion_ref.py::p_sample_loop)
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        tb = D.make_tables(1000, "linear", 1000)
+        rop = D.PhysOperator(name, batch_size=1, depth_type=opc["depth_type"], value=opc["value"], phi_a=opc["phi_a"],
+                             phi_b=opc["phi_b"], phi_inf=opc["phi_inf"])
+        p = cfg["conditioning"]["params"]
+        rg = D.OsmosisGuidance(rop, n_iter=20, scale=p["scale"], gradient_clip=p["gradient_clip"],
+                               aux=cfg["aux_loss"]["aux_loss"])
+        xi = x_t.clone().requires_grad_(True)
+        out = D.p_mean_variance(tb, U.unet_forward(sd, ucfg, xi, torch.tensor([float(idx)])), xi, idx)
+        r_xt, r_loss, r_vars, r_grad = rg.conditioning(xi, out["mean"], out["pred_xstart"], y,
+                                                       D.is_freeze_phi(cfg["sample_pattern"], idx, 1000))
+        r_new = r_xt.detach() + torch.exp(0.5 * out["log_variance"].detach()) * noise[0]
+        e_img = float((img.cpu() - r_new).abs().max())
+        e_x0 = float((x0 - out["pred_xstart"].detach()).abs().max())
+        gmax = float(r_grad.abs().max())
+        e_g = float((trace[0]["grad"].cpu() - r_grad).abs().max())
+        print(f"full-size guided step vs oracle: x_(t-1) {e_img:.2e}  pred_xstart {e_x0:.2e}  "
+              f"grad {e_g:.2e} (max {gmax:.2e})  loss {float(loss[0]):.5f} vs {float(np.asarray(r_loss).ravel()[0]):.5f}")
+        assert e_img < 1e-3 and e_x0 < 1e-3
+        assert e_g < 2e-4 * gmax + 1e-9
+        assert abs(float(loss[0]) - float(np.asarray(r_loss).ravel()[0])) < 1e-3 * abs(float(loss[0]))
+        for k, v in r_vars.items():
+            assert torch.allclose(variables[k].cpu().reshape(-1), v.detach().reshape(-1), atol=5e-6), k
+    finally:
+        full_model.reset_parameters(1234)

@@ -126,7 +126,7 @@ def test_conditioning_config_parsing():
     assert c.gradient_clip and c.gradient_clip_value == 0.005 and c.n_iter == 20
     assert c.aux_loss.kernel_coefficients() == {"gamma_avrg": 0.5, "gamma_val": 20.0}
     c2 = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), scale=3.0, gradient_clip="False")
-    assert c2.scale.tolist() == [3.0] and not c2.gradient_clip and c2.clip_value == 0.0
+    assert c2.scale.tolist() == [3.0] and not c2.gradient_clip and c2.clip_value == -1.0
     assert utilso.parse_weight_function("gamma,1.4,1.4,1")[0] == "gamma"
     assert utilso.str2bool("Yes") and not utilso.str2bool("0")
     with pytest.raises(Exception):

@@ -81,7 +81,7 @@ def test_full_size_unet_256_vs_oracle(create_model):
               resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path="",
               pretrain_model="osmosis")
     m, cfg, sd = build(create_model, kw, seed=1234)
-    assert sum(v.numel() for v in sd.values()) == 552_821_000 + 0 or True
+    assert sum(v.numel() for v in sd.values()) == 552_821_000
     g = torch.Generator().manual_seed(0)
     x = 0.7 * torch.randn(1, 4, 256, 256, generator=g)
     t = torch.tensor([37.0])
