@@ -240,7 +240,7 @@ def cpu_baseline(args):
     # thread sweep: oneDNN on a 128-thread host is FASTER with fewer threads than cores for these shapes (round 1
     # ran it oversubscribed: 18 s/step at 128 threads vs 9.7 s on 8 cores).  One UNet forward per candidate, best wins.
     ncpu = os.cpu_count() or 1
-    cand = sorted({c for c in (8, 16, 32, 48, 64, 96, ncpu) if c <= ncpu})
+    cand = sorted({c for c in (8, 16, 32, 48, 64) if c <= ncpu} or {ncpu})   # > 64 threads: slower every time (measured)
     x_probe = torch.randn(1, 4, args.image_size, args.image_size)
     sweep = {}
     with torch.no_grad():

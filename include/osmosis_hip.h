@@ -54,7 +54,8 @@ typedef struct osm_conv_desc {
   long long ldx, ldy, ldr;
   int wfmt;            /* weight image: 0 = fp32 [tap][Cout][Cin] (exact-f32 MFMA);
                           3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
-                          (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16) */
+                          (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16);
+                          1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file */
   const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
@@ -84,7 +85,7 @@ typedef struct osm_gemm_desc {
   int splitk;          /* <=1: none; else K is cut into `splitk` slices ...            */
   float* splitk_ws;    /* ... with fp32 partials in splitk*nb1*nb2*M*N floats, reduced deterministically */
 } osm_gemm_desc;
-/* Split-bf16 weight images: `wfmt` planes of bf16 in MFMA-fragment order
+/* Split-bf16 (wfmt 2, 3) / fp16 (wfmt 1: ONE plane of IEEE half, round-to-nearest-even) weight images: `wfmt` planes in MFMA-fragment order
  * [plane][tap][k16-step s][n/32 j][lane l][8]: n = 32j + (l&31), k = 16s + 8(l>>5) + e, zero padded, an even
  * number of k16 steps; forward n=Cout,k=Cin; data-gradient n=Cin,k=Cout (taps flipped).  Sizes in uint16
  * elements from osm_packed_weight_elems (wfmt 0 -> float elements of osm_pack_conv_weight). */
@@ -229,6 +230,59 @@ int osm_ancestral_step(const float* model_out, const float* x, const float* z, c
  * (graph-replayable; B <= 256) */
 int osm_fetch_coefs(const float* table, int n_rows, int* step, int delta, float* coef_out, float* t_out, int B,
                     void* stream);
+
+/* ================================================================== fp16-storage family (`use_fp16: True`)
+ * The reference's fp16 mode (guided_diffusion/unet.py:544,697-703,733; fp16_util.py:13-20 convert_module_to_f16)
+ * keeps activations and conv weights in IEEE half, accumulates in fp32 (ATen/cuDNN) and runs GroupNorm32 in
+ * fp32 (nn.py:17-19).  The entry points below are the SAME operations on activations stored as half
+ * (osm_half_t = the 16 bits of an IEEE binary16): every `float*` that addresses NHWC activations / their
+ * gradients becomes `osm_half_t*`, `ld*` count halfs (multiples of 4), statistics / gamma / beta / FiLM /
+ * bias / split-K partials stay fp32, arithmetic and accumulation are fp32.  osm_conv2d_nhwc_h takes wfmt 1
+ * weight images (osm_pack_conv_weight_bf16s(..., wfmt = 1)) and multiplies fp16 x fp16 into fp32 on
+ * v_mfma_f32_32x32x16_f16; its descriptor has the layout of osm_conv_desc.  Everything without a `_h` twin
+ * (embeddings, attention core, sampler step) is fp32 in both modes; osm_half_to_f32 / osm_f32_to_half bridge. */
+typedef unsigned short osm_half_t;
+typedef struct osm_conv_desc_h {
+  const osm_half_t* x;
+  const void* w;        /* wfmt 1 image */
+  const float* bias;
+  const osm_half_t* res;
+  osm_half_t* y;
+  float* splitk_ws;
+  int B, H, W, Cin, Cout;
+  int ksize, splitk, accumulate;
+  long long ldx, ldy, ldr;
+  int wfmt;             /* 1 */
+  const float* gn_table;
+  int gn_silu;
+} osm_conv_desc_h;
+int osm_conv2d_nhwc_h(const osm_conv_desc_h* d, void* stream);
+int osm_gn_stats_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps,
+                   float* part, float* stats, void* stream);
+int osm_gn_apply_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G,
+                   const float* stats, const float* gamma, const float* beta, const float* film,
+                   long long ldfilm, int silu, void* stream);
+int osm_gn_fwd_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G, float eps,
+                 float* part, float* stats, const float* gamma, const float* beta, const float* film,
+                 long long ldfilm, int silu, void* stream);
+int osm_gn_prep_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
+                  const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
+                  void* stream);
+int osm_gn_bwd_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
+                 const osm_half_t* addend, long long ldadd, int B, int HW, int C, int G,
+                 const float* stats, const float* gamma, const float* beta, const float* film,
+                 long long ldfilm, int silu, float* part, float* gstats, void* stream);
+int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
+                  float scale, void* stream);
+int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
+                     float scale, void* stream);
+int osm_nchw_to_nhwc_h(const float* x, osm_half_t* y, long long ldy, int B, int C, int HW, void* stream);   /* fp32 NCHW -> half NHWC */
+int osm_nhwc_to_nchw_h(const osm_half_t* x, long long ldx, float* y, int B, int C, int HW, void* stream);   /* half NHWC -> fp32 NCHW */
+int osm_copy2d_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, long long M, int C,
+                 int accumulate, void* stream);
+/* [M][C] strided conversions (C, ld multiples of 4) between the two storage types */
+int osm_half_to_f32(const osm_half_t* x, long long ldx, float* y, long long ldy, long long M, int C, void* stream);
+int osm_f32_to_half(const float* x, long long ldx, osm_half_t* y, long long ldy, long long M, int C, void* stream);
 
 #ifdef __cplusplus
 }

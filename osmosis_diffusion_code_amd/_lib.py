@@ -100,6 +100,12 @@ _SIGS = {
     "osm_ancestral_step": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "osm_version": [],
 }
+# fp16-storage family (activations as IEEE half, `_h` suffix): same argument lists
+for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_pool2x2",
+           "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
+    _SIGS[_n + "_h"] = _SIGS[_n]
+_SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]
+_SIGS["osm_f32_to_half"] = [_P, _LL, _P, _LL, _LL, _I, _P]
 EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems"])
 
 _lib = None
@@ -230,6 +236,7 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if not t.is_cuda:
         raise OsmosisHipError("osmosis_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
                               "(there is no CPU fallback on the product path)")
-    if t.dtype not in (torch.float32, torch.int32, torch.int16):   # int16 = packed bf16 weight planes
-        raise OsmosisHipError(f"osmosis_hip kernels are fp32; got {t.dtype}")
+    # int16 = packed bf16 / fp16 weight planes; float16 = activations of the fp16-storage family
+    if t.dtype not in (torch.float32, torch.int32, torch.int16, torch.float16):
+        raise OsmosisHipError(f"osmosis_hip kernels take fp32 (or fp16-family half) tensors; got {t.dtype}")
     return t.data_ptr()

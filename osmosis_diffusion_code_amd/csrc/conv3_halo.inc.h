@@ -33,7 +33,7 @@ constexpr int B_RING = 3;                        // weight-fragment register set
 constexpr int B_DIST = 2;                        // steps between a weight fragment's load and its use
 
 template <int NP, bool GNF, int PW = 16>
-__global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* __restrict__ Aglob,
+__global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
   using GEO = HaloGeom<PW>;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
 
   // ---- halo staging coordinates: slot s = tid + 256 j -> halo pixel (tid >> 3) + 32 j, float4 group tid & 7
   const int cg = tid & 7;
-  const long long rowB = (long long)p.lda * 4;
+  const long long rowB = (long long)p.lda * ACT_B;
   const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
   unsigned voff[NJ], woff[NJ], vmask = 0;
 #pragma unroll
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
 #define OSM_H_LOAD_A(cc_)                                                                  \
   {                                                                                        \
     const bool cok_ = (cc_) * BK + 4 * cg < p.K;                                           \
-    const unsigned d_ = (unsigned)((cc_) * (BK * 4) + 16 * cg);                            \
+    const unsigned d_ = (unsigned)((cc_) * (BK * ACT_B) + 4 * ACT_B * cg);                 \
     okm = cok_ ? vmask : 0u;                                                               \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
-      ra[j] = *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)));     \
+      ra[j] = osm::ld4(reinterpret_cast<const act_t*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)))); \
     if (GNF) {                                                                             \
       const float* gt_ = gtab + (cok_ ? (cc_) * BK + 4 * cg : 0);                          \
       gm = *reinterpret_cast<const float4*>(gt_);                                          \
@@ -143,16 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
     constexpr int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
       _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                    \
-        f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + q2 * H_PLANE +               \
+        f_[t][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE +                  \
                                                        (2 * h_ + t) * RB_STRIDE + off_);             \
   }
 #define OSM_H_MMA(f_, slot_, h_)                                                           \
   _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
     _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb) {                          \
-      acc[2 * (h_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[0][pa], as_frag(bq[slot_][pb]), \
-                                                              acc[2 * (h_)], 0, 0, 0);     \
-      acc[2 * (h_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[1][pa], as_frag(bq[slot_][pb]), \
-                                                                  acc[2 * (h_) + 1], 0, 0, 0); \
+      acc[2 * (h_)] = mma16<NP>(f_[0][pa], bq[slot_][pb], acc[2 * (h_)]);                  \
+      acc[2 * (h_) + 1] = mma16<NP>(f_[1][pa], bq[slot_][pb], acc[2 * (h_) + 1]);          \
     }
 
   if (kc1 > kc0) {
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
       const int cn = min(c + 1, kc1 - 1);
       OSM_H_LOAD_A(cn);                      // next slab's halo: in flight during the MFMA stream
       __syncthreads();
-      bf16x8_t fx[2][NP], fy[2][NP];
+      uint4 fx[2][NP], fy[2][NP];
       OSM_H_READ(fx, 0)
       if constexpr (PW == 16) {
 #define OSM_H_STEP(s_)                                                                     \
@@ -222,8 +220,6 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool partial = p.splitk > 1;
-  float* Cb = partial ? p.ws + ((long long)ks * p.M) * p.N : p.C;
-  const float* Rb = (p.res && !partial) ? p.res : nullptr;
   const long long ldc = partial ? (long long)p.N : p.ldc;
   const int n = n0 + 32 * wave + lr;
   if (n >= p.N) return;
@@ -232,8 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
   //                                            PW = 8 : (4 tm + (e >> 2), (e & 3) + 4 lk)
   const int xl = x0 + 4 * lk;
   const long long pix0 = (long long)img * p.H * p.W + (long long)y0 * p.W + xl;
-  float* __restrict__ cp = Cb + pix0 * ldc + n;
-  const float* __restrict__ rp = Rb ? Rb + pix0 * p.ldr + n : nullptr;
+  float* __restrict__ wp = p.ws + ((long long)ks * p.M) * p.N + pix0 * ldc + n;   // fp32 partials (split-K only)
+  act_t* __restrict__ cp = p.C + pix0 * ldc + n;
+  const act_t* __restrict__ rp = (p.res && !partial) ? p.res + pix0 * p.ldr + n : nullptr;
   const long long crow = (long long)p.W * ldc, rrow = (long long)p.W * p.ldr;
 #pragma unroll
   for (int tm = 0; tm < RB; ++tm) {
@@ -242,14 +239,16 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const float* _
       const int dy = PW == 16 ? tm + 4 * (e >> 3) : 4 * tm + (e >> 2);
       const int dx = PW == 16 ? (e & 3) + 8 * ((e >> 2) & 1) : (e & 3);
       if (y0 + dy >= p.H || xl + dx >= p.W) continue;
-      float* c = cp + dy * crow + dx * ldc;
       float v = acc[tm][e];
-      if (!partial) {
+      if (partial) {
+        wp[dy * crow + dx * ldc] = v;
+      } else {
+        act_t* c = cp + dy * crow + dx * ldc;
         v = v * p.alpha + bv;
-        if (rp) v += rp[dy * rrow + dx * p.ldr];
-        if (p.accumulate) v += *c;
+        if (rp) v += osm::ld1(rp + dy * rrow + dx * p.ldr);
+        if (p.accumulate) v += osm::ld1(c);
+        osm::st1(c, v);
       }
-      *c = v;
     }
   }
 }

@@ -7,8 +7,8 @@ namespace {
 // ---------------------------------------------------------------- 2x2 sum-pool (avg-pool / upsample-bwd)
 // reference: Downsample(use_conv=False) = AvgPool2d(2,2)  (unet.py:213-215)
 template <int VEC>
-__global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ x, long long ldx,
-                                                       float* __restrict__ y, long long ldy, int B, int H,
+__global__ __launch_bounds__(256) void pool2x2_kernel(const act_t* __restrict__ x, long long ldx,
+                                                       act_t* __restrict__ y, long long ldy, int B, int H,
                                                        int W, int C, float scale) {
   const int Ho = H / 2, Wo = W / 2, vpr = C / VEC;
   const long long total = (long long)B * Ho * Wo * vpr;
@@ -24,20 +24,20 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ 
     const long long out = ((long long)(b * Ho + ho) * Wo + wo);
     const int c = v * VEC;
     if (VEC == 4) {
-      const float4 a0 = *reinterpret_cast<const float4*>(x + in0 * ldx + c);
-      const float4 a1 = *reinterpret_cast<const float4*>(x + (in0 + 1) * ldx + c);
-      const float4 a2 = *reinterpret_cast<const float4*>(x + (in0 + W) * ldx + c);
-      const float4 a3 = *reinterpret_cast<const float4*>(x + (in0 + W + 1) * ldx + c);
+      const float4 a0 = osm::ld4(x + in0 * ldx + c);
+      const float4 a1 = osm::ld4(x + (in0 + 1) * ldx + c);
+      const float4 a2 = osm::ld4(x + (in0 + W) * ldx + c);
+      const float4 a3 = osm::ld4(x + (in0 + W + 1) * ldx + c);
       float4 o;
       o.x = ((a0.x + a1.x) + (a2.x + a3.x)) * scale;
       o.y = ((a0.y + a1.y) + (a2.y + a3.y)) * scale;
       o.z = ((a0.z + a1.z) + (a2.z + a3.z)) * scale;
       o.w = ((a0.w + a1.w) + (a2.w + a3.w)) * scale;
-      *reinterpret_cast<float4*>(y + out * ldy + c) = o;
+      osm::st4(y + out * ldy + c, o);
     } else {
-      const float s = (x[in0 * ldx + c] + x[(in0 + 1) * ldx + c]) +
-                      (x[(in0 + W) * ldx + c] + x[(in0 + W + 1) * ldx + c]);
-      y[out * ldy + c] = s * scale;
+      const float s = (osm::ld1(x + in0 * ldx + c) + osm::ld1(x + (in0 + 1) * ldx + c)) +
+                      (osm::ld1(x + (in0 + W) * ldx + c) + osm::ld1(x + (in0 + W + 1) * ldx + c));
+      osm::st1(y + out * ldy + c, s * scale);
     }
   }
 }
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------- nearest 2x upsample (/ avg-pool-bwd)
 // reference: Upsample(use_conv=False) = F.interpolate(scale_factor=2, mode="nearest") (unet.py:186)
 template <int VEC>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, long long ldx,
-                                                          float* __restrict__ y, long long ldy, int B, int H,
+__global__ __launch_bounds__(256) void upsample2x_kernel(const act_t* __restrict__ x, long long ldx,
+                                                          act_t* __restrict__ y, long long ldy, int B, int H,
                                                           int W, int C, float scale) {
   const int Ho = 2 * H, Wo = 2 * W, vpr = C / VEC;
   const long long total = (long long)B * Ho * Wo * vpr;
@@ -62,17 +62,17 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const long long out = ((long long)(b * Ho + ho) * Wo + wo);
     const int c = v * VEC;
     if (VEC == 4) {
-      float4 a = *reinterpret_cast<const float4*>(x + in * ldx + c);
+      float4 a = osm::ld4(x + in * ldx + c);
       a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
-      *reinterpret_cast<float4*>(y + out * ldy + c) = a;
+      osm::st4(y + out * ldy + c, a);
     } else {
-      y[out * ldy + c] = x[in * ldx + c] * scale;
+      osm::st1(y + out * ldy + c, osm::ld1(x + in * ldx + c) * scale);
     }
   }
 }
 
 // ---------------------------------------------------------------- layout
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, act_t* __restrict__ y,
                                                             long long ldy, int B, int C, int HW) {
   const long long total = (long long)B * HW * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const long long row = i / C;  // b*HW + p
     const int p = (int)(row % HW);
     const int b = (int)(row / HW);
-    y[row * ldy + c] = x[((long long)b * C + c) * HW + p];
+    osm::st1(y + row * ldy + c, x[((long long)b * C + c) * HW + p]);
   }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, long long ldx,
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const act_t* __restrict__ x, long long ldx,
                                                             float* __restrict__ y, int B, int C, int HW) {
   const long long total = (long long)B * HW * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     const long long bc = i / HW;
     const int c = (int)(bc % C);
     const int b = (int)(bc / C);
-    y[i] = x[((long long)b * HW + p) * ldx + c];
+    y[i] = osm::ld1(x + ((long long)b * HW + p) * ldx + c);
   }
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, long long ldx,
-                                                      float* __restrict__ y, long long ldy, long long M, int C,
+__global__ __launch_bounds__(256) void copy2d_kernel(const act_t* __restrict__ x, long long ldx,
+                                                      act_t* __restrict__ y, long long ldy, long long M, int C,
                                                       int accumulate) {
   const int vpr = C / VEC;
   const long long total = M * vpr;
@@ -109,17 +109,17 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x
     const long long row = i / vpr;
     const int c = (int)(i - row * vpr) * VEC;
     if (VEC == 4) {
-      float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
-      float4* d = reinterpret_cast<float4*>(y + row * ldy + c);
+      float4 a = osm::ld4(x + row * ldx + c);
+      act_t* d = y + row * ldy + c;
       if (accumulate) {
-        const float4 o = *d;
+        const float4 o = osm::ld4(d);
         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
       }
-      *d = a;
+      osm::st4(d, a);
     } else {
-      float a = x[row * ldx + c];
-      if (accumulate) a += y[row * ldy + c];
-      y[row * ldy + c] = a;
+      float a = osm::ld1(x + row * ldx + c);
+      if (accumulate) a += osm::ld1(y + row * ldy + c);
+      osm::st1(y + row * ldy + c, a);
     }
   }
 }
@@ -296,13 +296,34 @@ inline int grid_for(long long total) {
   return (int)b;
 }
 
+// (float family only below this kernel) 2-D strided conversion between the two activation storage types
+#ifdef OSM_ACT_F16
+template <bool TO_HALF>
+__global__ __launch_bounds__(256) void convert2d_kernel(const void* __restrict__ x, long long ldx, void* __restrict__ y,
+                                                         long long ldy, long long M, int C) {
+  const int vpr = C / 4;
+  const long long total = M * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / vpr;
+    const int c = (int)(i - row * vpr) * 4;
+    if (TO_HALF)
+      osm::st4(reinterpret_cast<_Float16*>(y) + row * ldy + c, osm::ld4(reinterpret_cast<const float*>(x) + row * ldx + c));
+    else
+      osm::st4(reinterpret_cast<float*>(y) + row * ldy + c, osm::ld4(reinterpret_cast<const _Float16*>(x) + row * ldx + c));
+  }
+}
+#endif
+
 }  // namespace
 
-extern "C" int osm_pool2x2(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
-                           float scale, void* stream) {
+extern "C" int OSM_FN(osm_pool2x2)(const abi_act_t* x_, long long ldx, abi_act_t* y_, long long ldy, int B, int H, int W,
+                                   int C, float scale, void* stream) {
+  const act_t* x = OSM_CACT(x_);
+  act_t* y = OSM_ACT(y_);
   OSM_REQUIRE(x && y, "osm_pool2x2: null pointer");
   OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "osm_pool2x2: H, W must be even");
-  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned_act4(x) && osm::aligned_act4(y);
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / (v4 ? 4 : 1));
   if (v4)
     hipLaunchKernelGGL((pool2x2_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
@@ -311,11 +332,13 @@ extern "C" int osm_pool2x2(const float* x, long long ldx, float* y, long long ld
   return osm::check_launch("pool2x2_kernel");
 }
 
-extern "C" int osm_upsample2x(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W,
-                              int C, float scale, void* stream) {
+extern "C" int OSM_FN(osm_upsample2x)(const abi_act_t* x_, long long ldx, abi_act_t* y_, long long ldy, int B, int H,
+                                      int W, int C, float scale, void* stream) {
+  const act_t* x = OSM_CACT(x_);
+  act_t* y = OSM_ACT(y_);
   OSM_REQUIRE(x && y, "osm_upsample2x: null pointer");
   OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "osm_upsample2x: bad shape");
-  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned_act4(x) && osm::aligned_act4(y);
   const long long total = (long long)B * (2 * H) * (2 * W) * (C / (v4 ? 4 : 1));
   if (v4)
     hipLaunchKernelGGL((upsample2x_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
@@ -324,24 +347,30 @@ extern "C" int osm_upsample2x(const float* x, long long ldx, float* y, long long
   return osm::check_launch("upsample2x_kernel");
 }
 
-extern "C" int osm_nchw_to_nhwc(const float* x, float* y, long long ldy, int B, int C, int HW, void* stream) {
+extern "C" int OSM_FN(osm_nchw_to_nhwc)(const float* x, abi_act_t* y_, long long ldy, int B, int C, int HW,
+                                        void* stream) {
+  act_t* y = OSM_ACT(y_);
   OSM_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && ldy >= C, "osm_nchw_to_nhwc: bad argument");
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0,
                      (hipStream_t)stream, x, y, ldy, B, C, HW);
   return osm::check_launch("nchw_to_nhwc_kernel");
 }
 
-extern "C" int osm_nhwc_to_nchw(const float* x, long long ldx, float* y, int B, int C, int HW, void* stream) {
+extern "C" int OSM_FN(osm_nhwc_to_nchw)(const abi_act_t* x_, long long ldx, float* y, int B, int C, int HW,
+                                        void* stream) {
+  const act_t* x = OSM_CACT(x_);
   OSM_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && ldx >= C, "osm_nhwc_to_nchw: bad argument");
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, y, B, C, HW);
   return osm::check_launch("nhwc_to_nchw_kernel");
 }
 
-extern "C" int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long M, int C,
-                          int accumulate, void* stream) {
+extern "C" int OSM_FN(osm_copy2d)(const abi_act_t* x_, long long ldx, abi_act_t* y_, long long ldy, long long M, int C,
+                                  int accumulate, void* stream) {
+  const act_t* x = OSM_CACT(x_);
+  act_t* y = OSM_ACT(y_);
   OSM_REQUIRE(x && y && M > 0 && C > 0, "osm_copy2d: bad argument");
-  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) && osm::aligned16(y);
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned_act4(x) && osm::aligned_act4(y);
   const long long total = M * (C / (v4 ? 4 : 1));
   if (v4)
     hipLaunchKernelGGL((copy2d_kernel<4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, accumulate);
@@ -349,6 +378,25 @@ extern "C" int osm_copy2d(const float* x, long long ldx, float* y, long long ldy
     hipLaunchKernelGGL((copy2d_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, accumulate);
   return osm::check_launch("copy2d_kernel");
 }
+
+#ifdef OSM_ACT_F16
+extern "C" int osm_half_to_f32(const osm_half_t* x, long long ldx, float* y, long long ldy, long long M, int C,
+                               void* stream) {
+  OSM_REQUIRE(x && y && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(y) &&
+              osm::aligned_act4(x), "osm_half_to_f32: bad argument (C, ld multiples of 4; aligned pointers)");
+  hipLaunchKernelGGL((convert2d_kernel<false>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const void*)x, ldx, (void*)y, ldy, M, C);
+  return osm::check_launch("convert2d_kernel");
+}
+extern "C" int osm_f32_to_half(const float* x, long long ldx, osm_half_t* y, long long ldy, long long M, int C,
+                               void* stream) {
+  OSM_REQUIRE(x && y && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && osm::aligned16(x) &&
+              osm::aligned_act4(y), "osm_f32_to_half: bad argument (C, ld multiples of 4; aligned pointers)");
+  hipLaunchKernelGGL((convert2d_kernel<true>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const void*)x, ldx, (void*)y, ldy, M, C);
+  return osm::check_launch("convert2d_kernel");
+}
+#else
 
 extern "C" int osm_softmax_rows(const float* S, float* P, float* PT, int nmat, int T, void* stream) {
   OSM_REQUIRE(S && P && nmat > 0 && T > 0, "osm_softmax_rows: bad argument");
@@ -399,5 +447,6 @@ extern "C" int osm_linear(const float* x, const float* W, const float* b, float*
   return osm::check_launch("linear_kernel");
 }
 
-extern "C" int osm_version(void) { return (0 << 16) | (1 << 8) | 0; }
+extern "C" int osm_version(void) { return (0 << 16) | (2 << 8) | 0; }
 extern "C" const char* osm_last_error(void) { return osm::err_buf(); }
+#endif   // !OSM_ACT_F16

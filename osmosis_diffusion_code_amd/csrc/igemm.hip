@@ -31,16 +31,16 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_STRIDE = 36;      // floats per staged row (32 + 4 pad)
-constexpr int LDS_KN_STRIDE = 132;  // floats per k-row of a [k][n] staged B tile
+[[maybe_unused]] constexpr int LDS_STRIDE = 36;      // floats per staged row (32 + 4 pad)
+[[maybe_unused]] constexpr int LDS_KN_STRIDE = 132;  // floats per k-row of a [k][n] staged B tile
 
 struct IGemmParams {
-  const float* A;
-  const float* Bm;
+  const act_t* A;      // activations: fp32, or half in the OSM_ACT_F16 family
+  const float* Bm;     // weights (fp32 image, or a split-bf16 / fp16 fragment image behind the same pointer)
   const float* bias;
-  const float* res;
-  float* C;
-  float* ws;
+  const act_t* res;
+  act_t* C;
+  float* ws;           // split-K partials are fp32 in both families
   int M, N, K;
   int H, W;
   int splitk;
@@ -63,6 +63,7 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+#ifndef OSM_ACT_F16
 // NARROW (N <= 64, e.g. attention P V with 64-wide heads): the four waves split the 128 rows (32 each) and
 // every wave covers the 64 live columns, instead of 2 x 2 waves of 64 x 64 where half would multiply zeros.
 template <int TAPS, bool B_KN, bool NARROW = false>
@@ -285,6 +286,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
   }
 }
 
+#endif   // !OSM_ACT_F16
+
 // C = alpha * sum_s ws[s] + bias + res (+ C)      (fixed summation order: deterministic)
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
@@ -311,20 +314,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
     }
     const int b1 = z % p.nb1, b2 = z / p.nb1;
     const long long coff = b1 * p.sC1 + b2 * p.sC2;
-    float* c = p.C + coff + (long long)m * p.ldc + n;
-    const float* rs = p.res ? p.res + coff + (long long)m * p.ldr + n : nullptr;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float v = s[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
-      if (rs) v += rs[e];
-      if (p.accumulate) v += c[e];
-      s[e] = v;
+    act_t* c = p.C + coff + (long long)m * p.ldc + n;
+    const act_t* rs = p.res ? p.res + coff + (long long)m * p.ldr + n : nullptr;
+    float rv[VEC], cv[VEC];
+    if constexpr (VEC == 4) {
+      const float4 r4 = rs ? osm::ld4(rs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 c4 = p.accumulate ? osm::ld4(c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+      cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+    } else {
+      rv[0] = rs ? osm::ld1(rs) : 0.f;
+      cv[0] = p.accumulate ? osm::ld1(c) : 0.f;
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(c) = make_float4(s[0], s[1], s[2], s[3]);
-    else c[0] = s[0];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = (s[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f)) + rv[e] + cv[e];
+    if constexpr (VEC == 4) osm::st4(c, make_float4(s[0], s[1], s[2], s[3]));
+    else osm::st1(c, s[0]);
   }
 }
 
+#ifndef OSM_ACT_F16
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                    float* __restrict__ wd, int Cout, int Cin, int k) {
   const long long total = (long long)Cout * Cin * k * k;
@@ -339,6 +348,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     if (wd) wd[((long long)((k - 1 - kh) * k + (k - 1 - kw)) * Cin + ci) * Cout + co] = v;
   }
 }
+
+#endif   // !OSM_ACT_F16
 
 #include "igemm_bf16s.inc.h"
 #include "conv3_halo.inc.h"
@@ -359,6 +370,11 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > p.nchunks) p.splitk = p.nchunks;
   dim3 grid(p.mtiles * p.ntiles, p.splitk, p.nbatch);
+#ifdef OSM_ACT_F16
+  if (wfmt != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "the fp16 family takes wfmt 1 (fp16 fragment image) only, got %d", wfmt);
+#else
+  if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
+#endif
   if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
     // halo-tile kernel: M-tiles are 8 x 16 (W >= 16) or 8 x 8 pixel patches, K is consumed in 32-channel slabs of all 9 taps
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
@@ -368,20 +384,28 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
-    if (wfmt != 2 && wfmt != 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+    if (wfmt < 1 || wfmt > 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
 #define OSM_HALO_LAUNCH(NP_, GN_, PW_) \
     hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_>), g2, dim3(256), 0, st, p.A, Bp, p)
-    if (wfmt == 3) {
-      if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(3, true, 16); else OSM_HALO_LAUNCH(3, false, 16); }
-      else      { if (p.gn_table) OSM_HALO_LAUNCH(3, true, 8);  else OSM_HALO_LAUNCH(3, false, 8); }
-    } else {
-      if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(2, true, 16); else OSM_HALO_LAUNCH(2, false, 16); }
-      else      { if (p.gn_table) OSM_HALO_LAUNCH(2, true, 8);  else OSM_HALO_LAUNCH(2, false, 8); }
-    }
+#define OSM_HALO_PICK(NP_)                                                                                \
+    if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16); else OSM_HALO_LAUNCH(NP_, false, 16); } \
+    else      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8);  else OSM_HALO_LAUNCH(NP_, false, 8); }
+#ifdef OSM_ACT_F16
+    OSM_HALO_PICK(1)
+#else
+    if (wfmt == 3) { OSM_HALO_PICK(3) } else { OSM_HALO_PICK(2) }
+#endif
+#undef OSM_HALO_PICK
 #undef OSM_HALO_LAUNCH
   } else if (wfmt != 0) {
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
+#ifdef OSM_ACT_F16
+    if (taps == 9)
+      hipLaunchKernelGGL((igemm_bf16s_kernel<9, 1>), g2, dim3(256), 0, st, p.A, Bp, p);
+    else
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 1>), g2, dim3(256), 0, st, p.A, Bp, p);
+#else
     if (wfmt == 3 && taps == 9)
       hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 3)
@@ -392,7 +416,10 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
       hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2>), g2, dim3(256), 0, st, p.A, Bp, p);
     else
       return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
-  } else if (taps == 9) {
+#endif
+  }
+#ifndef OSM_ACT_F16
+  else if (taps == 9) {
     if (b_kn) return osm::fail(OSM_ERR_UNSUPPORTED, "3x3 conv needs [n][k] weights");
     hipLaunchKernelGGL((igemm_f32_kernel<9, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   } else if (b_kn && p.N <= 64) {
@@ -404,11 +431,12 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
   } else {
     hipLaunchKernelGGL((igemm_f32_kernel<1, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   }
-  int rc = osm::check_launch("igemm_f32_kernel");
+#endif
+  int rc = osm::check_launch("igemm kernel");
   if (rc) return rc;
   if (p.splitk > 1) {
-    const bool v4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && osm::aligned16(p.C) &&
-                    osm::aligned16(p.ws) && (!p.res || osm::aligned16(p.res)) && p.sC1 % 4 == 0 && p.sC2 % 4 == 0;
+    const bool v4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && osm::aligned_act4(p.C) &&
+                    osm::aligned16(p.ws) && (!p.res || osm::aligned_act4(p.res)) && p.sC1 % 4 == 0 && p.sC2 % 4 == 0;
     const long long total = (long long)p.nbatch * p.M * p.N / (v4 ? 4 : 1);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -421,6 +449,7 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 
 }  // namespace
 
+#ifndef OSM_ACT_F16
 extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
   const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (nbatch > 0 ? nbatch : 1);
   const int nchunks = taps * ((K + BK - 1) / BK);
@@ -437,17 +466,24 @@ extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
   return (int)(s < 1 ? 1 : s);
 }
 
+#endif   // !OSM_ACT_F16
+
+#ifdef OSM_ACT_F16
+extern "C" int osm_conv2d_nhwc_h(const osm_conv_desc_h* d, void* stream) {
+#else
 extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
+#endif
   OSM_REQUIRE(d && d->x && d->w && d->y, "osm_conv2d_nhwc: null pointer");
   OSM_REQUIRE(d->ksize == 1 || d->ksize == 3, "osm_conv2d_nhwc: ksize must be 1 or 3 (got %d)", d->ksize);
   OSM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "osm_conv2d_nhwc: bad shape");
   OSM_REQUIRE(d->Cin % 4 == 0 && d->ldx % 4 == 0, "osm_conv2d_nhwc: Cin and ldx must be multiples of 4");
   OSM_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout, "osm_conv2d_nhwc: ld smaller than channels");
-  OSM_REQUIRE(osm::aligned16(d->x) && osm::aligned16(d->w), "osm_conv2d_nhwc: x/w must be 16-byte aligned");
+  OSM_REQUIRE(osm::aligned_act4(d->x) && osm::aligned16(d->w), "osm_conv2d_nhwc: x (4 elements) / w (16 bytes) misaligned");
   OSM_REQUIRE(d->splitk <= 1 || d->splitk_ws, "osm_conv2d_nhwc: splitk>1 needs a workspace");
   OSM_REQUIRE(!d->res || d->ldr >= d->Cout, "osm_conv2d_nhwc: ldr smaller than Cout");
   IGemmParams p{};
-  p.A = d->x; p.Bm = d->w; p.bias = d->bias; p.res = d->res; p.C = d->y; p.ws = d->splitk_ws;
+  p.A = OSM_CACT(d->x); p.Bm = reinterpret_cast<const float*>(d->w); p.bias = d->bias; p.res = OSM_CACT(d->res);
+  p.C = OSM_ACT(d->y); p.ws = d->splitk_ws;
   p.M = d->B * d->H * d->W; p.N = d->Cout; p.K = d->Cin; p.H = d->H; p.W = d->W;
   p.splitk = d->splitk; p.accumulate = d->accumulate; p.alpha = 1.f;
   p.lda = d->ldx; p.ldb = d->Cin; p.ldc = d->ldy; p.ldr = d->ldr;
@@ -461,13 +497,14 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
     p.gn_silu = d->gn_silu;
   }
   if (d->wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
-    OSM_REQUIRE(d->wfmt == 2 || d->wfmt == 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
+    OSM_REQUIRE(d->wfmt >= 1 && d->wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");
     p.nt32 = (d->Cout + 31) / 32;
     p.ksteps = 2 * ((d->Cin + 31) / 32);
   }
   return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream, d->wfmt);
 }
 
+#ifndef OSM_ACT_F16
 extern "C" int osm_gemm(const osm_gemm_desc* d, void* stream) {
   OSM_REQUIRE(d && d->A && d->Bm && d->C, "osm_gemm: null pointer");
   OSM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->nb1 > 0 && d->nb2 > 0, "osm_gemm: bad shape");
@@ -501,6 +538,7 @@ extern "C" int osm_pack_conv_weight(const float* w, float* wf, float* wd, int Co
 
 extern "C" long long osm_packed_weight_elems(int Cout, int Cin, int k, int wfmt, int dgrad) {
   if (wfmt == 0) return (long long)k * k * Cout * Cin;                         // floats
+  // wfmt 1 (one fp16 plane), 2, 3 (bf16 planes): 16-bit elements
   const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
   return (long long)wfmt * k * k * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // bf16 (uint16) elements
 }
@@ -509,7 +547,7 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
                                           int wfmt, void* stream) {
   OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_bf16s: null pointer");
   OSM_REQUIRE(k == 1 || k == 3, "osm_pack_conv_weight_bf16s: ksize must be 1 or 3");
-  OSM_REQUIRE(wfmt == 2 || wfmt == 3, "osm_pack_conv_weight_bf16s: wfmt must be 2 or 3");
+  OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_pack_conv_weight_bf16s: wfmt must be 1 (fp16), 2 or 3 (bf16 planes)");
   for (int dg = 0; dg < 2; ++dg) {
     unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
     if (!out) continue;
@@ -523,4 +561,4 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
   }
   return OSM_OK;
 }
-
+#endif   // !OSM_ACT_F16

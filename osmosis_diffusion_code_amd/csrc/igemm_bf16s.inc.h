@@ -28,6 +28,8 @@
 //       instructions of the staging work fit in the 48 gaps of a chunk.)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr int ACT_B = (int)sizeof(act_t);   // bytes per stored activation (4, or 2 in the OSM_ACT_F16 family)
 
 constexpr int S_ROWB = 80;              // bytes per staged A row (32 bf16 + 16 B pad)
 constexpr int S_PLANE = 128 * S_ROWB;   // bytes per 128-row plane
@@ -47,6 +49,11 @@ __device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 
 // 4 fp32 -> NP planes of 4 bf16 (2 packed dwords per plane); 22 VALU ops for NP = 3.
 template <int NP>
 __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
+  if constexpr (NP == 1) {   // fp16 arithmetic (the reference's use_fp16): ONE half plane, RNE
+    const osm::floatx4_t f = {x.x, x.y, x.z, x.w};
+    pl[0] = __builtin_bit_cast(uint2, __builtin_convertvector(f, osm::half4_t));
+    return;
+  }
   unsigned a = cvt_pk_bf16(x.x, x.y), b = cvt_pk_bf16(x.z, x.w);
   pl[0] = make_uint2(a, b);
   float r0 = x.x - bf_lo(a), r1 = x.y - bf_hi(a), r2 = x.z - bf_lo(b), r3 = x.w - bf_hi(b);
@@ -60,9 +67,17 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
 }
 
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+// one 32x32x16 MFMA on 16-byte fragments: bf16 planes (NP = 2, 3) or fp16 (NP = 1)
+template <int NP>
+__device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (NP == 1)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 template <int TAPS, int NP>
-__global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __restrict__ Aglob,
+__global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Bglob,
                                                               IGemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * S_PLANE];   // two A stages
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const float* __restrict__ A = Aglob;
+  const act_t* __restrict__ A = Aglob;
   const unsigned short* __restrict__ Bm = Bglob;
 
   const int ks = blockIdx.y;
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
   // Masked lanes (halo / ragged edge / channel tail) read their own centre pixel (always valid memory)
   // and are zeroed after the load -- ~9 VALU per load instead of ~30 of 64-bit pointer arithmetic.
   const int cg = tid & 7, r0 = tid >> 3;
-  const long long rowB = (long long)p.lda * 4;                         // bytes per pixel row
+  const long long rowB = (long long)p.lda * ACT_B;                     // bytes per pixel row
   const long long biasB = (TAPS == 9) ? (long long)(p.W + 1) * rowB : 0;
   const char* __restrict__ sbaseA = reinterpret_cast<const char*>(A) + (long long)m0 * rowB - biasB;
   unsigned vcen[4], vsafe[4], amask[4];
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
     }
     amask[i] = mk;
     vsafe[i] = (unsigned)(biasB + (m < p.M ? (long long)(r0 + 32 * i) * rowB : 0));
-    vcen[i] = vsafe[i] + 16u * cg;
+    vcen[i] = vsafe[i] + (unsigned)(4 * ACT_B) * cg;
   }
 
   // ---- B fragment addressing: image [plane][tap][k16-step][n/32][lane][8]; wave-uniform base + lane offset
@@ -136,13 +151,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
   unsigned okE = 0, okO = 0;                  // validity bits of the staged A registers
   uint4 bE00, bE01, bE02, bE10, bE11, bE12;   // [k16-step][plane] B fragments, even chunks
   uint4 bO00, bO01, bO02, bO10, bO11, bO12;   // odd chunks
-  bE02 = bE12 = bO02 = bO12 = make_uint4(0u, 0u, 0u, 0u);
+  bE02 = bE12 = bO02 = bO12 = bE01 = bE11 = bO01 = bO11 = make_uint4(0u, 0u, 0u, 0u);
 
 #define OSM_S_LOAD_A(ra_, ok_, kc_)                                                                  \
   {                                                                                                  \
     const int cc_ = (kc_) / TAPS;                                                                    \
     const int tap_ = (kc_) - cc_ * TAPS;                                                             \
-    int sdelta_ = cc_ * (BK * 4);                                                                    \
+    int sdelta_ = cc_ * (BK * ACT_B);                                                                \
     if (TAPS == 9) sdelta_ += (int)(((tap_ / 3 - 1) * p.W + (tap_ % 3 - 1)) * rowB);                 \
     const bool cok_ = cc_ * BK + 4 * cg < p.K;                                                       \
     ok_ = 0;                                                                                         \
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
       const bool o_ = cok_ && ((amask[i] >> tap_) & 1u);                                             \
       ok_ |= (o_ ? 1u : 0u) << i;                                                                    \
       const unsigned vo_ = o_ ? vcen[i] + (unsigned)sdelta_ : vsafe[i];                              \
-      ra_[i] = *reinterpret_cast<const float4*>(sbaseA + vo_);                                       \
+      ra_[i] = osm::ld4(reinterpret_cast<const act_t*>(sbaseA + vo_));                               \
     }                                                                                                \
   }
 #define OSM_S_LOAD_B(b_, kc_)                                                                        \
@@ -162,8 +177,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
     const long long pl_ = b_ok ? b_plane : 0;                                                        \
     b_##00 = *reinterpret_cast<const uint4*>(sb_ + b_lane);                                          \
     b_##10 = *reinterpret_cast<const uint4*>(sb_ + st_ + b_lane);                                    \
-    b_##01 = *reinterpret_cast<const uint4*>(sb_ + pl_ + b_lane);                                    \
-    b_##11 = *reinterpret_cast<const uint4*>(sb_ + pl_ + st_ + b_lane);                              \
+    if (NP >= 2) {                                                                                   \
+      b_##01 = *reinterpret_cast<const uint4*>(sb_ + pl_ + b_lane);                                  \
+      b_##11 = *reinterpret_cast<const uint4*>(sb_ + pl_ + st_ + b_lane);                            \
+    }                                                                                                \
     if (NP == 3) {                                                                                   \
       b_##02 = *reinterpret_cast<const uint4*>(sb_ + 2 * pl_ + b_lane);                              \
       b_##12 = *reinterpret_cast<const uint4*>(sb_ + 2 * pl_ + st_ + b_lane);                        \
@@ -173,20 +190,18 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
 #define OSM_S_READ(f_, buf_, st_, half_)                                                             \
   _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                      \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                                \
-      f_[t][q2] = *reinterpret_cast<const bf16x8_t*>(a_rd + (buf_) * (NP * S_PLANE) + q2 * S_PLANE + \
+      f_[t][q2] = *reinterpret_cast<const uint4*>(a_rd + (buf_) * (NP * S_PLANE) + q2 * S_PLANE + \
                                                      (64 * (half_) + 32 * t) * S_ROWB + 32 * (st_));
 #define OSM_S_MMA(f_, b_, st_, half_)                                                                \
   {                                                                                                  \
-    bf16x8_t bf[NP];                                                                                 \
-    bf[0] = as_frag((st_) ? b_##10 : b_##00);                                                        \
-    bf[1] = as_frag((st_) ? b_##11 : b_##01);                                                        \
-    if (NP == 3) bf[NP - 1] = as_frag((st_) ? b_##12 : b_##02);                                      \
+    uint4 bf[3];                                                                                     \
+    bf[0] = (st_) ? b_##10 : b_##00;                                                                 \
+    bf[1] = (st_) ? b_##11 : b_##01;                                                                 \
+    bf[2] = (st_) ? b_##12 : b_##02;                                                                 \
     _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                           \
       _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb) {                                  \
-        acc[2 * (half_)] =                                                                           \
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[0][pa], bf[pb], acc[2 * (half_)], 0, 0, 0);   \
-        acc[2 * (half_) + 1] =                                                                       \
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_[1][pa], bf[pb], acc[2 * (half_) + 1], 0, 0, 0); \
+        acc[2 * (half_)] = mma16<NP>(f_[0][pa], bf[pb], acc[2 * (half_)]);                           \
+        acc[2 * (half_) + 1] = mma16<NP>(f_[1][pa], bf[pb], acc[2 * (half_) + 1]);                   \
       }                                                                                              \
   }
 // split one staged float4 (rows r0 + 32 i) into NP planes of A stage `buf_`
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
 #define OSM_S_CHUNK(ra_, ok_, bc_, bn_, it_)                                                              \
   {                                                                                                  \
     const int rb_ = (it_) & 1, wb_ = rb_ ^ 1;                                                        \
-    bf16x8_t fx[2][NP], fy[2][NP];                                                                   \
+    uint4 fx[2][NP], fy[2][NP];                                                                      \
     OSM_S_LOAD_B(bn_, min(kc0 + (it_) + 1, kc1 - 1));                                                \
     OSM_S_READ(fx, rb_, 0, 0)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -258,9 +273,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool partial = p.splitk > 1;
-  float* Cb = partial ? p.ws + ((long long)ks * p.M) * p.N : p.C;
-  const float* Rb = (p.res && !partial) ? p.res : nullptr;
-  const long long ldc = partial ? (long long)p.N : p.ldc;
+  float* Wb = p.ws + ((long long)ks * p.M) * p.N;       // fp32 partials [ks][M][N]
   const int n = n0 + 32 * wave + lr;
   if (n >= p.N) return;
   const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
@@ -271,12 +284,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
       const int m = m0 + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * lk;
       if (m >= p.M) continue;
       float v = acc[tm][e];
-      if (!partial) {
+      if (partial) {
+        Wb[(long long)m * p.N + n] = v;
+      } else {
         v = v * p.alpha + bv;
-        if (Rb) v += Rb[(long long)m * p.ldr + n];
-        if (p.accumulate) v += Cb[(long long)m * ldc + n];
+        if (p.res) v += osm::ld1(p.res + (long long)m * p.ldr + n);
+        if (p.accumulate) v += osm::ld1(p.C + (long long)m * p.ldc + n);
+        osm::st1(p.C + (long long)m * p.ldc + n, v);
       }
-      Cb[(long long)m * ldc + n] = v;
     }
   }
 }
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const float* __rest
 //   [plane][tap][k16-step s][n/32 j][lane l][e],  n = 32 j + (l & 31),  k = 16 s + 8 (l >> 5) + e
 // forward: n = Cout, k = Cin ; data-gradient: n = Cin, k = Cout, taps flipped.  Out-of-range (n, k) are zero;
 // the step count is even (2 per 32-wide chunk) so a chunk never reads past the image.
+#ifndef OSM_ACT_F16
 __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout,
                                          int Cin, int k, int np, int dgrad) {
   const int N = dgrad ? Cin : Cout;
@@ -315,6 +331,10 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned s
       }
       v = w[(((long long)co * Cin + ci) * k + kh) * k + kw];
     }
+    if (np == 1) {      // wfmt 1: ONE plane of IEEE half (RNE) for the fp16-arithmetic family
+      out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+      continue;
+    }
     float rr = v;
     for (int qq = 0; qq < np; ++qq) {
       const __bf16 b = (__bf16)rr;
@@ -323,3 +343,4 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned s
     }
   }
 }
+#endif   // !OSM_ACT_F16

@@ -22,15 +22,15 @@ __host__ __device__ inline int gn_ppc(int HW) {
 constexpr int NJMAX = 4;  // channel vectors per thread (C <= 4096)
 
 struct GNArgs {
-  const float* x;
-  const float* dy;
+  const act_t* x;
+  const act_t* dy;
   const float* stats;   // [B][G][2] mean, rstd
   const float* gstats;  // [B][G][2] m1, m2 (backward)
   const float* gamma;
   const float* beta;
   const float* film;    // [B][2C] or null
-  const float* addend;
-  float* out;
+  const act_t* addend;
+  act_t* out;
   float* part;
   float* fin;           // finalized statistics written by the one-launch kernel / the fused apply prologue
   double n;             // elements per group
@@ -90,15 +90,15 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
         const long long row = (long long)b * a.HW + p;
         float xv[VEC], dv[VEC];
         if (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+          const float4 t = osm::ld4(a.x + row * a.ldx + c);
           xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
           if (MODE == 1) {
-            const float4 u = *reinterpret_cast<const float4*>(a.dy + row * a.lddy + c);
+            const float4 u = osm::ld4(a.dy + row * a.lddy + c);
             dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
           }
         } else {
-          xv[0] = a.x[row * a.ldx + c];
-          if (MODE == 1) dv[0] = a.dy[row * a.lddy + c];
+          xv[0] = osm::ld1(a.x + row * a.ldx + c);
+          if (MODE == 1) dv[0] = osm::ld1(a.dy + row * a.lddy + c);
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -295,31 +295,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
       sc[e] = film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
       sh[e] = film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
     }
-    const float* xp = a.x + ((long long)b * a.HW + p0 + tr) * a.ldx + c;
-    const float* dp = MODE == 1 ? a.dy + ((long long)b * a.HW + p0 + tr) * a.lddy + c : nullptr;
-    const float* ap = (MODE == 1 && a.addend) ? a.addend + ((long long)b * a.HW + p0 + tr) * a.ldadd + c : nullptr;
-    float* op = a.out + ((long long)b * a.HW + p0 + tr) * a.ldo + c;
+    const act_t* xp = a.x + ((long long)b * a.HW + p0 + tr) * a.ldx + c;
+    const act_t* dp = MODE == 1 ? a.dy + ((long long)b * a.HW + p0 + tr) * a.lddy + c : nullptr;
+    const act_t* ap = (MODE == 1 && a.addend) ? a.addend + ((long long)b * a.HW + p0 + tr) * a.ldadd + c : nullptr;
+    act_t* op = a.out + ((long long)b * a.HW + p0 + tr) * a.ldo + c;
     const long long sx = (long long)rowT * a.ldx, sd = (long long)rowT * a.lddy, sa = (long long)rowT * a.ldadd,
                     so = (long long)rowT * a.ldo;
 #pragma unroll 4
     for (int p = p0 + tr; p < p1; p += rowT) {
       float xv[VEC], dv[VEC], ov[VEC], av[VEC];
       if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(xp);
+        const float4 t = osm::ld4(xp);
         xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
         if (MODE == 1) {
-          const float4 u = *reinterpret_cast<const float4*>(dp);
+          const float4 u = osm::ld4(dp);
           dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
           if (ap) {
-            const float4 w = *reinterpret_cast<const float4*>(ap);
+            const float4 w = osm::ld4(ap);
             av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
           }
         }
       } else {
-        xv[0] = *xp;
+        xv[0] = osm::ld1(xp);
         if (MODE == 1) {
-          dv[0] = *dp;
-          if (ap) av[0] = *ap;
+          dv[0] = osm::ld1(dp);
+          if (ap) av[0] = osm::ld1(ap);
         }
       }
 #pragma unroll
@@ -338,9 +338,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
         }
       }
       if (VEC == 4) {
-        *reinterpret_cast<float4*>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        osm::st4(op, make_float4(ov[0], ov[1], ov[2], ov[3]));
       } else {
-        *op = ov[0];
+        osm::st1(op, ov[0]);
       }
       xp += sx;
       op += so;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
   float s1 = 0.f, s2 = 0.f;
   if (live) {
     for (int p = tp; p < a.HW; p += ppi) {
-      const float4 t = *reinterpret_cast<const float4*>(a.x + (row0 + p) * a.ldx + c);
+      const float4 t = osm::ld4(a.x + (row0 + p) * a.ldx + c);
       const float xv[4] = {t.x, t.y, t.z, t.w};
       if (MODE == 0) {
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
           s2 += xv[e] * xv[e];
         }
       } else {
-        const float4 u = *reinterpret_cast<const float4*>(a.dy + (row0 + p) * a.lddy + c);
+        const float4 u = osm::ld4(a.dy + (row0 + p) * a.lddy + c);
         const float dv[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
     rstd = q1;
   }
   for (int p = tp; p < a.HW; p += ppi) {
-    const float4 t = *reinterpret_cast<const float4*>(a.x + (row0 + p) * a.ldx + c);
+    const float4 t = osm::ld4(a.x + (row0 + p) * a.ldx + c);
     const float xv[4] = {t.x, t.y, t.z, t.w};
     float ov[4];
     if (MODE == 0) {
@@ -458,11 +458,11 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
         ov[e] = a.silu ? osm::silu_f(z) : z;
       }
     } else {
-      const float4 u = *reinterpret_cast<const float4*>(a.dy + (row0 + p) * a.lddy + c);
+      const float4 u = osm::ld4(a.dy + (row0 + p) * a.lddy + c);
       const float dv[4] = {u.x, u.y, u.z, u.w};
       float av[4] = {0.f, 0.f, 0.f, 0.f};
       if (a.addend) {
-        const float4 w = *reinterpret_cast<const float4*>(a.addend + (row0 + p) * a.ldadd + c);
+        const float4 w = osm::ld4(a.addend + (row0 + p) * a.ldadd + c);
         av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
       }
 #pragma unroll
@@ -475,17 +475,17 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
         ov[e] = rstd * (dxh - q0 - xh * q1) + av[e];
       }
     }
-    *reinterpret_cast<float4*>(a.out + (row0 + p) * a.ldo + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    osm::st4(a.out + (row0 + p) * a.ldo + c, make_float4(ov[0], ov[1], ov[2], ov[3]));
   }
 }
 
 constexpr int GN_SMALL_HW = 256;   // measured: 32 x 32 tensors are faster on the chunked three-launch path
 
 bool use_vec4(const GNArgs& a) {
-  return a.gs % 4 == 0 && a.ldx % 4 == 0 && osm::aligned16(a.x) &&
-         (!a.dy || (a.lddy % 4 == 0 && osm::aligned16(a.dy))) &&
-         (!a.out || (a.ldo % 4 == 0 && osm::aligned16(a.out))) &&
-         (!a.addend || (a.ldadd % 4 == 0 && osm::aligned16(a.addend)));
+  return a.gs % 4 == 0 && a.ldx % 4 == 0 && osm::aligned_act4(a.x) &&
+         (!a.dy || (a.lddy % 4 == 0 && osm::aligned_act4(a.dy))) &&
+         (!a.out || (a.ldo % 4 == 0 && osm::aligned_act4(a.out))) &&
+         (!a.addend || (a.ldadd % 4 == 0 && osm::aligned_act4(a.addend)));
 }
 
 int check_common(const GNArgs& a, const char* who) {
@@ -549,25 +549,28 @@ int run_small(GNArgs& a, float* finalized, hipStream_t st) {
 
 }  // namespace
 
+#ifndef OSM_ACT_F16
 extern "C" int osm_gn_nchunk(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
+#endif
+static int gn_nchunk_of(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
 
-extern "C" int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C, int G, float eps,
+extern "C" int OSM_FN(osm_gn_stats)(const abi_act_t* x, long long ldx, int B, int HW, int C, int G, float eps,
                             float* part, float* stats, void* stream) {
   OSM_REQUIRE(x && part && stats, "osm_gn_stats: null pointer");
   GNArgs a{};
-  a.x = x; a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
+  a.x = OSM_CACT(x); a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
   int rc = check_common(a, "osm_gn_stats");
   if (rc) return rc;
   return run_reduce<0>(a, stats, (hipStream_t)stream);
 }
 
-extern "C" int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part,
+extern "C" int OSM_FN(osm_gn_prep)(const abi_act_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part,
                            float* stats, const float* gamma, const float* beta, const float* film,
                            long long ldfilm, float* table, void* stream) {
   OSM_REQUIRE(x && part && stats && gamma && beta && table, "osm_gn_prep: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_prep: ldfilm smaller than 2*C");
   GNArgs a{};
-  a.x = x; a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
+  a.x = OSM_CACT(x); a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
   int rc = check_common(a, "osm_gn_prep");
   if (rc) return rc;
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, false);
@@ -578,51 +581,51 @@ extern "C" int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, 
   return osm::check_launch("gn_finalize_table_kernel");
 }
 
-extern "C" int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C,
+extern "C" int OSM_FN(osm_gn_apply)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C,
                             int G, const float* stats, const float* gamma, const float* beta,
                             const float* film, long long ldfilm, int silu, void* stream) {
   OSM_REQUIRE(x && y && stats && gamma && beta, "osm_gn_apply: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_apply: ldfilm smaller than 2*C");
   GNArgs a{};
-  a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G;
+  a.x = OSM_CACT(x); a.ldx = ldx; a.out = OSM_ACT(y); a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G;
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_apply");
   if (rc) return rc;
   return run_apply<0>(a, (hipStream_t)stream);
 }
 
-extern "C" int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx,
-                          long long lddx, const float* addend, long long ldadd, int B, int HW, int C, int G,
+extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy, abi_act_t* dx,
+                          long long lddx, const abi_act_t* addend, long long ldadd, int B, int HW, int C, int G,
                           const float* stats, const float* gamma, const float* beta, const float* film,
                           long long ldfilm, int silu, float* part, float* gstats, void* stream) {
   OSM_REQUIRE(x && dy && dx && stats && gamma && beta && part && gstats, "osm_gn_bwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd: ldfilm smaller than 2*C");
   GNArgs a{};
-  a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.addend = addend; a.ldadd = ldadd;
+  a.x = OSM_CACT(x); a.ldx = ldx; a.dy = OSM_CACT(dy); a.lddy = lddy; a.out = OSM_ACT(dx); a.ldo = lddx; a.addend = OSM_CACT(addend); a.ldadd = ldadd;
   a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
   a.film = film; a.ldf = ldfilm; a.silu = silu; a.part = part;
   int rc = check_common(a, "osm_gn_bwd");
   if (rc) return rc;
   if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
-  a.fuse = osm_gn_nchunk(HW) <= GN_FUSE_CHUNKS;
+  a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = gstats;
   rc = run_reduce<1>(a, gstats, (hipStream_t)stream, !a.fuse);
   if (rc) return rc;
   return run_apply<1>(a, (hipStream_t)stream);
 }
 
-extern "C" int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G,
+extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C, int G,
                           float eps, float* part, float* stats, const float* gamma, const float* beta,
                           const float* film, long long ldfilm, int silu, void* stream) {
   OSM_REQUIRE(x && y && part && stats && gamma && beta, "osm_gn_fwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_fwd: ldfilm smaller than 2*C");
   GNArgs a{};
-  a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
+  a.x = OSM_CACT(x); a.ldx = ldx; a.out = OSM_ACT(y); a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_fwd");
   if (rc) return rc;
   if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
-  a.fuse = osm_gn_nchunk(HW) <= GN_FUSE_CHUNKS;
+  a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = stats;
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, !a.fuse);
   if (rc) return rc;

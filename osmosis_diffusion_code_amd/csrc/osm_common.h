@@ -5,7 +5,47 @@
 #include <cstdio>
 #include "../../include/osmosis_hip.h"
 
+// ---------------------------------------------------------------- activation storage type of this build family
+// Every source that touches NHWC activations is compiled twice: as is (activations fp32, entry points `osm_*`) and
+// with -DOSM_ACT_F16 (activations IEEE half in HBM, fp32 arithmetic / accumulation everywhere, entry points
+// `osm_*_h`) -- the reference's `use_fp16` storage (unet.py:544,733; fp16_util.py:13-20) with GroupNorm32's fp32
+// arithmetic (nn.py:17-19).  Both families live in libosmosis_hip.so.
+#ifdef OSM_ACT_F16
+typedef _Float16 act_t;
+typedef osm_half_t abi_act_t;      // how the C ABI spells the element type (IEEE binary16 bits)
+#define OSM_FN(name) name##_h
+#define OSM_ACT_IS_F16 1
+#else
+typedef float act_t;
+typedef float abi_act_t;
+#define OSM_FN(name) name
+#define OSM_ACT_IS_F16 0
+#endif
+#define OSM_ACT(p) reinterpret_cast<act_t*>(p)
+#define OSM_CACT(p) reinterpret_cast<const act_t*>(p)
+
 namespace osm {
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+// 4 consecutive activations <-> fp32 registers (16-byte access for fp32 storage, 8-byte for half storage)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+  const floatx4_t f = __builtin_convertvector(*reinterpret_cast<const half4_t*>(p), floatx4_t);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(_Float16* p, float4 v) {
+  const floatx4_t f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<half4_t*>(p) = __builtin_convertvector(f, half4_t);   // RNE
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+// alignment of a 4-element activation vector access
+inline bool aligned_act4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(act_t) - 1)) == 0; }
 
 inline char* err_buf() {
   static thread_local char buf[512] = {0};

@@ -83,6 +83,7 @@ class UNetWeights:
         self.ted = 4 * self.mc
         self.cin, self.cout = model.in_channels, model.out_channels
         self.nlev = len(model.channel_mult)
+        self.arch = describe_architecture(model)
 
         def wrap(m):
             from .guided_diffusion.unet import AttentionParams, ResBlockParams
@@ -117,13 +118,33 @@ class UNetWeights:
             m.ew = m.eb = None
 
 
-def activation_bytes_per_image(w: UNetWeights, H: int, W: int, itemsize: int = 4) -> int:
+def describe_architecture(model) -> dict:
+    """Shapes-only description of a UNetModel (no device work): per block sequence, ('res', cin, cout, up, down) /
+    ('attn', ch, heads) entries; what `activation_bytes_per_image` walks."""
+    from .guided_diffusion.unet import AttentionParams, ResBlockParams
+
+    def seq(s):
+        out = []
+        for _, m in sorted(((int(k), v) for k, v in s._modules.items()), key=lambda kv: kv[0]):
+            if isinstance(m, ResBlockParams):
+                out.append(("res", m.cin, m.cout, m.up, m.down))
+            elif isinstance(m, AttentionParams):
+                out.append(("attn", m.ch, m.heads))
+            else:
+                out.append(("conv", m.weight.shape[1], m.weight.shape[0]))
+        return out
+
+    return dict(inp=[seq(s) for s in model.input_blocks], mid=seq(model.middle_block),
+                outb=[seq(s) for s in model.output_blocks], cin=model.in_channels, cout=model.out_channels)
+
+
+def activation_bytes_per_image(arch: dict, H: int, W: int, itemsize: int = 4) -> int:
     """HBM bytes one image keeps resident in an engine (forward activations kept for the data-gradient pass,
     the gradient buffers of the recorded backward plan, attention probabilities, scratch): a dry walk over the
     same allocation logic as `UNetEngine._forward_impl / _backward_impl`.  Used to size the number of images
-    processed per pass (`UNetModel.images_in_flight`): ~8 GB per 256 x 256 image for the 552.8 M-parameter net."""
+    processed per pass (`UNetModel.images_in_flight`)."""
     fixed = 0          # persistent buffers, elements of the activation type
-    f32 = 0            # fp32 elements (attention logits / probabilities)
+    f32 = 0            # fp32 elements (attention logits / probabilities; qkv in the half family)
     scratch = {"a": 0, "b": 0, "c": 0, "s": 0}
 
     def scr(slot, n):
@@ -134,44 +155,50 @@ def activation_bytes_per_image(w: UNetWeights, H: int, W: int, itemsize: int = 4
         c = cin
         for i, l in enumerate(layers):
             last = i == len(layers) - 1
-            if isinstance(l, _Res):
-                ho = (hw[0] * 2, hw[1] * 2) if l.up else ((hw[0] // 2, hw[1] // 2) if l.down else hw)
+            if l[0] == "res":
+                _, lcin, lcout, up, down = l
+                ho = (hw[0] * 2, hw[1] * 2) if up else ((hw[0] // 2, hw[1] // 2) if down else hw)
                 M, Mo = hw[0] * hw[1], ho[0] * ho[1]
-                fixed += Mo * l.cout                       # h1
+                fixed += Mo * lcout                        # h1
                 if not (last and last_has_dst):
-                    fixed += Mo * l.cout                   # block output
-                fixed += M * l.cin if i > 0 else 0         # backward: d/d(input) of a non-first layer
-                scr("a", max(M * l.cin, Mo * l.cout))
-                scr("b", max(Mo * l.cin, Mo * l.cout, M * l.cin))
-                scr("c", max(Mo * l.cin, M * l.cin))
-                hw, c = ho, l.cout
+                    fixed += Mo * lcout                    # block output
+                fixed += M * lcin if i > 0 else 0          # backward: d/d(input) of a non-first layer
+                scr("a", max(M * lcin, Mo * lcout))
+                scr("b", max(Mo * lcin, Mo * lcout, M * lcin))
+                scr("c", max(Mo * lcin, M * lcin))
+                hw, c = ho, lcout
             else:
+                _, ch, heads = l
                 T = hw[0] * hw[1]
-                fixed += T * 3 * l.ch                      # qkv
+                if itemsize == 4:
+                    fixed += T * 3 * ch                    # qkv
+                else:
+                    f32 += T * 3 * ch                      # half family: the attention core keeps qkv in fp32
                 if T > 64:
-                    f32 += 2 * l.heads * T * T             # P, P^T
-                    scr("s", 3 * l.heads * T * T)          # S / dP, dS, dS^T
+                    f32 += 2 * heads * T * T               # P, P^T
+                    scr("s", 3 * heads * T * T)            # S / dP, dS, dS^T
                 if not (last and last_has_dst):
-                    fixed += T * l.ch
-                fixed += T * l.ch if i > 0 else 0
-                scr("a", T * l.ch)
-                scr("b", T * 3 * l.ch)
+                    fixed += T * ch
+                fixed += T * ch if i > 0 else 0
+                scr("a", T * ch)
+                scr("b", T * 3 * ch)
+                f32 += 0 if itemsize == 4 else 0
         return hw, c
 
-    stem = w.inp[0][0]
-    chans, hws = [stem.cout], [(H, W)]
-    hw, c = (H, W), stem.cout
-    fixed += H * W * (w.cin + w.cout) * 3                  # x / out / gradients in NHWC
-    for layers in w.inp[1:]:
+    stem_cout = arch["inp"][0][0][2]
+    chans, hws = [stem_cout], [(H, W)]
+    hw, c = (H, W), stem_cout
+    fixed += H * W * (arch["cin"] + arch["cout"]) * 3      # x / out / gradients in NHWC
+    for layers in arch["inp"][1:]:
         hw, c = seq_cost(layers, hw, c, True)
         chans.append(c)
         hws.append(hw)
-    hw, c = seq_cost(w.mid, hw, c, True)
-    n_in = len(w.inp)
-    for i, layers in enumerate(w.outb):
+    hw, c = seq_cost(arch["mid"], hw, c, True)
+    n_in = len(arch["inp"])
+    for i, layers in enumerate(arch["outb"]):
         j = n_in - 1 - i
         fixed += 2 * hws[j][0] * hws[j][1] * (c + chans[j])   # concat buffer + its gradient
-        hw, c = seq_cost(layers, hws[j], c + chans[j], i + 1 < len(w.outb))
+        hw, c = seq_cost(layers, hws[j], c + chans[j], i + 1 < len(arch["outb"]))
     fixed += 2 * H * W * c
     scr("a", H * W * c)
     splitk = 4 * 1024 * 1024                               # split-K partials (bounded by the ~1 workgroup / CU target)
@@ -184,6 +211,9 @@ class UNetEngine:
         self.B, self.H, self.W, self.dev = B, H, W, dev
         self.weights = weights
         self.conv_mode = weights.conv_mode
+        # storage type of every NHWC activation / gradient buffer: IEEE half in the "f16" arithmetic (the
+        # reference's use_fp16), fp32 otherwise.  Sampler-side tensors (x_in, out, d_out, dx) are always fp32 NCHW.
+        self.adt = torch.float16 if weights.conv_mode == "f16" else torch.float32
         self.mc, self.ted, self.cin, self.cout = weights.mc, weights.ted, weights.cin, weights.cout
         nlev = weights.nlev
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
@@ -217,19 +247,21 @@ class UNetEngine:
         self.gn_part = torch.empty(B * ops.gn_nchunk(H * W) * G * 2, **f32)
 
     # ------------------------------------------------------------------ buffers
-    def _buf(self, rows, cols) -> Mat:
-        return Mat.of(torch.empty(rows, cols, device=self.dev, dtype=torch.float32))
+    def _buf(self, rows, cols, dtype=None) -> Mat:
+        return Mat.of(torch.empty(rows, cols, device=self.dev, dtype=dtype or self.adt))
 
     def _small(self, n) -> torch.Tensor:
         return torch.empty(n, device=self.dev, dtype=torch.float32)
 
-    def _scr(self, slot: str, rows: int, cols: int) -> Mat:
+    def _scr(self, slot: str, rows: int, cols: int, dtype=None) -> Mat:
         """Scratch matrix (contents live only until the next use of the same slot)."""
         need = rows * cols
-        t = self._scratch.get(slot)
+        dtype = dtype or self.adt
+        key = slot if dtype == self.adt else slot + "/32"
+        t = self._scratch.get(key)
         if t is None or t.numel() < need:
-            t = torch.empty(max(need, 1), device=self.dev, dtype=torch.float32)
-            self._scratch[slot] = t
+            t = torch.empty(max(need, 1), device=self.dev, dtype=dtype)
+            self._scratch[key] = t
         return Mat.of(t[:need].view(rows, cols))
 
     def _scr_flat(self, slot: str, n: int) -> torch.Tensor:
@@ -385,11 +417,18 @@ class UNetEngine:
         st = self._small(B * G * 2)
         xn = self._scr("a", M, C)
         ops.gn_fwd(x, xn, B, T, G, self.gn_part, st, blk.norm.g, blk.norm.b, silu=False)
-        qkv = self._buf(M, 3 * C)
-        self._conv(xn, blk.qkv, qkv, hw)
+        half = self.adt != torch.float32
+        if half:     # the attention core is fp32 in both modes (the reference soft-maxes in fp32, unet.py:431)
+            qkv_h = self._scr("b", M, 3 * C)
+            self._conv(xn, blk.qkv, qkv_h, hw)
+            qkv = self._buf(M, 3 * C, torch.float32)
+            ops.convert(qkv_h, qkv)
+        else:
+            qkv = self._buf(M, 3 * C)
+            self._conv(xn, blk.qkv, qkv, hw)
         nmat = B * nh
         alpha = 1.0 / math.sqrt(ch)     # (q*ch^-1/4)·(k*ch^-1/4)
-        a = self._scr("b", M, C)
+        a = self._scr("c", M, C, torch.float32)
         # fused core: measured faster at T = 64 (3 launches instead of 14); at T = 256 its fp32 FMA work sits on
         # only 64 workgroups and the unfused GEMM pipeline wins (OSM_ATTN_FUSED=all / 0 to force either way)
         mode = os.environ.get("OSM_ATTN_FUSED", "64")
@@ -406,6 +445,10 @@ class UNetEngine:
             ops.softmax_rows(S, P, PT, nmat, T)
             self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                        sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
+        if half:
+            a_h = self._scr("a", M, C)
+            ops.convert(a, a_h)
+            a = a_h
         self._conv(a, blk.proj, dst, hw, res=x)
         self._saved[id(blk)] = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused)
         return hw
@@ -421,9 +464,14 @@ class UNetEngine:
         nmat = B * nh
         qkv, P, PT = s["qkv"], s["P"], s["PT"]
         alpha = 1.0 / math.sqrt(ch)
+        half = self.adt != torch.float32
         da = self._scr("a", M, C)
         self._conv(dy, blk.proj, da, hw, dgrad=True)
-        dqkv = self._scr("b", M, 3 * C)
+        if half:
+            da32 = self._scr("c", M, C, torch.float32)
+            ops.convert(da, da32)
+            da = da32
+        dqkv = self._scr("b", M, 3 * C, torch.float32)
         if s["fused"]:
             ws = self._scr_flat("s0", 2 * nmat * T * T)
             ops.attn_small_bwd(qkv, da, dqkv, ws, B, T, nh, ch, (qo, ko, vo), hs, alpha)
@@ -442,6 +490,10 @@ class UNetEngine:
                        sA=(T * T, nh * T * T), sB=sQ, sC=sQ, b_off=qo, c_off=ko)
             self._gemm(PT, T, da.t, C, dqkv.t, 3 * C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                        sA=(T * T, nh * T * T), sB=(ch, T * C), sC=sQ, c_off=vo)
+        if half:
+            dqkv_h = self._scr("b", M, 3 * C)
+            ops.convert(dqkv, dqkv_h)
+            dqkv = dqkv_h
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
         if accumulate:

@@ -86,8 +86,6 @@ class UNetModel(nn.Module):
             raise NotImplementedError("HIP UNet covers resblock_updown=True (all shipped configs)")
         if not use_scale_shift_norm:
             raise NotImplementedError("HIP UNet covers use_scale_shift_norm=True (all shipped configs)")
-        if use_fp16:
-            raise NotImplementedError("use_fp16 has no working reference (SURVEY.md F3); the HIP path is fp32")
         if dropout:
             raise NotImplementedError("dropout is inference-irrelevant and not implemented")
         if num_heads_upsample == -1:
@@ -103,7 +101,7 @@ class UNetModel(nn.Module):
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
         self.use_new_attention_order = use_new_attention_order
-        self.dtype = torch.float32
+        self.dtype = torch.float16 if use_fp16 else torch.float32
 
         mc = model_channels
         ted = mc * 4
@@ -155,7 +153,11 @@ class UNetModel(nn.Module):
         self._weights: Dict[Tuple, Tuple] = {}
         # arithmetic of the conv / 1x1 contractions: "f32" exact-fp32 MFMA (parity mode), "bf16x6"
         # (fp32 split into 3 bf16 terms, 6 MFMAs: fp32-class accuracy), "bf16x3" (2 terms, ~2^-16)
-        self.conv_mode = os.environ.get("OSM_CONV_MODE", "bf16x6")
+        # "f16" = the reference's use_fp16 (unet.py:544,697-703,733): activations and conv weights in IEEE half, fp32
+        # accumulation, GroupNorm / softmax / embeddings in fp32; parameters stay fp32 in the module (the half weight
+        # images are made at pack time, like convert_module_to_f16 does in place)
+        self._fp32_conv_mode = os.environ.get("OSM_CONV_MODE", "bf16x6")
+        self.conv_mode = "f16" if use_fp16 else self._fp32_conv_mode
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self, seed: int = 0):
@@ -174,10 +176,17 @@ class UNetModel(nn.Module):
                     p.copy_(torch.randn(p.shape, generator=g) * (0.5 / fan_in ** 0.5))
 
     def convert_to_fp16(self):
-        raise NotImplementedError("the HIP path is fp32 (reference use_fp16 is broken as shipped, SURVEY.md F3)")
+        """unet.py:697-703: run the torso in fp16 storage / arithmetic.  (The reference forgets to call this when
+        `use_fp16: True`; here `use_fp16=True` implies it.)"""
+        if self.conv_mode != "f16":
+            self._fp32_conv_mode = self.conv_mode
+        self.conv_mode = "f16"
+        self.dtype = torch.float16
 
     def convert_to_fp32(self):
-        return None
+        """unet.py:705-711."""
+        self.conv_mode = self._fp32_conv_mode
+        self.dtype = torch.float32
 
     def _params_version(self):
         return tuple(p._version for p in self.parameters())
@@ -219,7 +228,7 @@ class UNetModel(nn.Module):
         stays under `OSM_ACT_BUDGET_GB` (default: 80 % of the free memory).  Images are independent chains
         (SURVEY.md F1/F2), so a batch processed in chunks is the same computation."""
         w = self.packed_weights()
-        per = activation_bytes_per_image(w, H, W, 4)
+        per = activation_bytes_per_image(w.arch, H, W, 2 if self.conv_mode == "f16" else 4)
         env = os.environ.get("OSM_ACT_BUDGET_GB")
         if env:
             budget = float(env) * 2 ** 30

@@ -39,6 +39,22 @@ def _s():
     return current_stream_ptr()
 
 
+def _fam(t: torch.Tensor) -> str:
+    """Entry-point family of an activation tensor: fp32 storage -> osm_*, IEEE-half storage -> osm_*_h."""
+    if t.dtype == torch.float16:
+        return "_h"
+    if t.dtype != torch.float32:
+        raise _lib.OsmosisHipError(f"activations must be float32 or float16, got {t.dtype}")
+    return ""
+
+
+def _same_family(*ts):
+    fams = {_fam(t) for t in ts if t is not None}
+    if len(fams) != 1:
+        raise _lib.OsmosisHipError("activation tensors of one call must share a storage type")
+    return fams.pop()
+
+
 def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat, B: int, H: int, W: int,
            ksize: int, res: Optional[Mat] = None, accumulate: bool = False,
            splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0,
@@ -53,17 +69,21 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.ldx, d.ldy, d.ldr = x.ld, y.ld, (res.ld if res is not None else 0)
     d.wfmt = wfmt
     d.gn_table, d.gn_silu = ptr(gn_table), int(gn_silu)
-    call("osm_conv2d_nhwc", C.byref(d), _s(),
+    fam = _same_family(x.t, y.t, res.t if res is not None else None)
+    if (fam == "_h") != (wfmt == 1):
+        raise _lib.OsmosisHipError("fp16 activations go with the fp16 weight image (wfmt 1), fp32 with 0 / 2 / 3")
+    call("osm_conv2d_nhwc" + fam, C.byref(d), _s(),
          keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table))
 
 
 # conv arithmetic modes: weight-image format code of the C ABI
-WFMT = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+# "f16": activations AND weights in IEEE half, fp32 accumulation (the reference's use_fp16): fp16-storage family
+WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True, wfmt: int = 0):
     """OIHW (or [O][I][1] conv1d / [O][I] linear) -> (fwd image, dgrad image).
-    wfmt 0: fp32 [k*k][O][I] / [k*k][I][O];  2 / 3: split-bf16 planes (int16 tensors)."""
+    wfmt 0: fp32 [k*k][O][I] / [k*k][I][O];  2 / 3: split-bf16 planes, 1: one fp16 plane (int16 tensors)."""
     w = w_oihw.contiguous()
     O, I = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() >= 3 else 1
@@ -138,7 +158,7 @@ def gn_nchunk(HW: int) -> int:
 
 
 def gn_stats(x: Mat, B: int, HW: int, G: int, part: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
-    call("osm_gn_stats", x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), _s(), keep=(x.t, part, stats))
+    call("osm_gn_stats" + _fam(x.t), x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), _s(), keep=(x.t, part, stats))
 
 
 def _film(film):
@@ -150,39 +170,39 @@ def _film(film):
 
 def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=None, silu=True):
     fp, ldf = _film(film)
-    call("osm_gn_apply", x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
+    call("osm_gn_apply" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
          int(silu), _s(), keep=(x.t, y.t, stats, gamma, beta, film))
 
 
 def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, film=None, silu=True, eps: float = 1e-5):
     """statistics (written to `stats`) + normalise/FiLM/SiLU; a single launch for HW <= 1024."""
     fp, ldf = _film(film)
-    call("osm_gn_fwd", x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
+    call("osm_gn_fwd" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
          fp, ldf, int(silu), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film))
 
 
 def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5):
     """statistics (-> `stats`) + per-channel table [B][4][C] that conv2d(gn_table=...) applies while staging."""
     fp, ldf = _film(film)
-    call("osm_gn_prep", x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
+    call("osm_gn_prep" + _fam(x.t), x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
          ptr(table), _s(), keep=(x.t, part, stats, gamma, beta, film, table))
 
 
 def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
            film=None, silu=True, addend: Optional[Mat] = None):
     fp, ldf = _film(film)
-    call("osm_gn_bwd", x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld,
+    call("osm_gn_bwd" + _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None), x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld,
          addend.p if addend is not None else None, addend.ld if addend is not None else 0,
          B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(part), ptr(gstats), _s(),
          keep=(x.t, dy.t, dx.t, addend.t if addend else None, stats, gamma, beta, film, part, gstats))
 
 
 def pool2x2(x: Mat, y: Mat, B, H, W, scale=0.25):
-    call("osm_pool2x2", x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
+    call("osm_pool2x2" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
 
 
 def upsample2x(x: Mat, y: Mat, B, H, W, scale=1.0):
-    call("osm_upsample2x", x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
+    call("osm_upsample2x" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
 
 
 def softmax_rows(S, P, PT, nmat, T):
@@ -203,15 +223,25 @@ def linear(x, W, b, y, B, K, N, silu_in=False, silu_out=False):
 
 
 def nchw_to_nhwc(x, y: Mat, B, Cc, HW):
-    call("osm_nchw_to_nhwc", ptr(x), y.p, y.ld, B, Cc, HW, _s(), keep=(x, y.t))
+    call("osm_nchw_to_nhwc" + _fam(y.t), ptr(x), y.p, y.ld, B, Cc, HW, _s(), keep=(x, y.t))
 
 
 def nhwc_to_nchw(x: Mat, y, B, Cc, HW):
-    call("osm_nhwc_to_nchw", x.p, x.ld, ptr(y), B, Cc, HW, _s(), keep=(x.t, y))
+    call("osm_nhwc_to_nchw" + _fam(x.t), x.p, x.ld, ptr(y), B, Cc, HW, _s(), keep=(x.t, y))
 
 
 def copy2d(x: Mat, y: Mat, accumulate=False):
-    call("osm_copy2d", x.p, x.ld, y.p, y.ld, x.rows, x.cols, int(accumulate), _s(), keep=(x.t, y.t))
+    call("osm_copy2d" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, x.rows, x.cols, int(accumulate), _s(),
+         keep=(x.t, y.t))
+
+
+def convert(x: Mat, y: Mat):
+    """y = x across the two activation storage types (half -> fp32 or fp32 -> half), [rows][cols] strided."""
+    fx, fy = _fam(x.t), _fam(y.t)
+    if fx == fy:
+        raise _lib.OsmosisHipError("convert() is for half <-> fp32; use copy2d within one storage type")
+    call("osm_half_to_f32" if fx == "_h" else "osm_f32_to_half", x.p, x.ld, y.p, y.ld, x.rows, x.cols, _s(),
+         keep=(x.t, y.t))
 
 
 # ----------------------------------------------------------------------------- sampler step

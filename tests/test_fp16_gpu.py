@@ -1,0 +1,274 @@
+"""fp16-storage family (`use_fp16: True`, entry points `osm_*_h`): activations and conv weights in IEEE half,
+fp32 accumulation, GroupNorm / softmax / embeddings / sampler step in fp32.
+
+The reference's own fp16 mode does not run as shipped (nobody calls `convert_to_fp16()`), so the oracle
+for it is the fp32 reference path plus a STATED tolerance:
+  * op level: the kernels must equal an fp64 evaluation of the SAME half-rounded operands up to the final rounding
+    of the result to half (2^-11 relative) and fp32 accumulation noise -- i.e. the arithmetic itself is exact-class;
+  * model level: UNet output / input-gradient within 2e-2 of the tensor's max-abs of the fp32 oracle;
+  * sampler level: 10 guided steps within 3e-2 max-abs of the fp32 trace on x_{t-1} / pred_xstart
+(half has 11 significand bits: ~5e-4 per stored tensor, ~60 stored tensors deep)."""
+import contextlib
+import io
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import baseline_configs as BC
+from oracle import unet_ref as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from osmosis_diffusion_code_amd import ops as o
+    return o
+
+
+def to_nhwc_h(x):
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV, torch.float16)
+
+
+def from_nhwc(m, B, H, W):
+    return m.float().cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+HALF_ULP = 2.0 ** -11
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,splitk,gn", [
+    (1, 32, 64, 16, 16, 3, 1, False), (2, 4, 32, 8, 8, 3, 1, False), (1, 64, 8, 16, 16, 3, 1, False),
+    (1, 96, 160, 12, 20, 3, 1, False), (1, 256, 128, 8, 8, 3, 4, False), (2, 64, 64, 8, 8, 1, 1, False),
+    (1, 288, 32, 4, 4, 3, 9, False), (1, 128, 256, 32, 32, 3, 1, True), (1, 64, 64, 8, 8, 3, 2, True),
+])
+def test_conv_h_fwd_and_dgrad(ops, B, Cin, Cout, H, W, k, splitk, gn):
+    """fp16 x fp16 -> fp32 convolution (halo-tile kernel, tap-chunked kernel, 1x1, split-K, fused GroupNorm input
+    transform) against fp64 on the half-rounded operands."""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).half().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    wh = w.half().float()
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g).half().float()
+    wf, wd = ops.pack_conv_weight(w.to(DEV), wfmt=ops.WFMT["f16"])
+    xin = x
+    table = None
+    if gn:
+        mean, rstd = torch.randn(B, Cin, generator=g) * 0.1, 1 + 0.1 * torch.rand(B, Cin, generator=g)
+        ga, be = 1 + 0.1 * torch.randn(B, Cin, generator=g), 0.1 * torch.randn(B, Cin, generator=g)
+        table = torch.stack([mean, rstd, ga, be], 1).contiguous().to(DEV)          # [B][4][Cin]
+        z = ((x - mean[:, :, None, None]) * rstd[:, :, None, None]) * ga[:, :, None, None] + be[:, :, None, None]
+        xin = (z * torch.sigmoid(z)).half().float()          # the kernel rounds the transformed input to half
+    ref = (F.conv2d(xin.double(), wh.double(), bias.double(), padding=k // 2) + res.double()).float()
+    y = torch.full((B * H * W, Cout), float("nan"), device=DEV, dtype=torch.float16)
+    ws = torch.empty(splitk * B * H * W * Cout, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(to_nhwc_h(x)), wf, bias.to(DEV), ops.Mat.of(y), B, H, W, k, res=ops.Mat.of(to_nhwc_h(res)),
+               splitk=splitk, splitk_ws=ws, wfmt=ops.WFMT["f16"], gn_table=table)
+    out = from_nhwc(y, B, H, W)
+    # gn: sigmoid via v_exp/v_rcp (1 ulp each) can flip the half rounding of an input element: a few 2^-11 |x w| terms
+    tol = (1.5 if not gn else 6.0) * HALF_ULP
+    assert relerr(out, ref) < tol, relerr(out, ref)
+    if gn:
+        return
+    dy = torch.randn(B, Cout, H, W, generator=g).half().float()
+    xr = x.double().clone().requires_grad_(True)
+    (dref,) = torch.autograd.grad(F.conv2d(xr, wh.double(), None, padding=k // 2), xr, dy.double())
+    dx = torch.full((B * H * W, Cin), float("nan"), device=DEV, dtype=torch.float16)
+    ws2 = torch.empty(splitk * B * H * W * Cin, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(to_nhwc_h(dy)), wd, None, ops.Mat.of(dx), B, H, W, k, splitk=splitk, splitk_ws=ws2,
+               wfmt=ops.WFMT["f16"])
+    assert relerr(from_nhwc(dx, B, H, W), dref.float()) < 1.5 * HALF_ULP
+
+
+def test_conv_h_rejects_mixed_families(ops):
+    from osmosis_diffusion_code_amd._lib import OsmosisHipError
+    w = torch.randn(32, 32, 3, 3)
+    wf16, _ = ops.pack_conv_weight(w.to(DEV), wfmt=ops.WFMT["f16"])
+    wf6, _ = ops.pack_conv_weight(w.to(DEV), wfmt=ops.WFMT["bf16x6"])
+    xh = torch.zeros(64, 32, device=DEV, dtype=torch.float16)
+    xf = torch.zeros(64, 32, device=DEV)
+    with pytest.raises(OsmosisHipError):
+        ops.conv2d(ops.Mat.of(xh), wf6, None, ops.Mat.of(torch.empty_like(xh)), 1, 8, 8, 3, wfmt=3)
+    with pytest.raises(OsmosisHipError):
+        ops.conv2d(ops.Mat.of(xf), wf16, None, ops.Mat.of(torch.empty_like(xf)), 1, 8, 8, 3, wfmt=1)
+    with pytest.raises(OsmosisHipError):
+        ops.conv2d(ops.Mat.of(xh), wf16, None, ops.Mat.of(torch.empty_like(xf)), 1, 8, 8, 3, wfmt=1)
+
+
+@pytest.mark.parametrize("B,C,H,W,film", [(2, 64, 8, 8, True), (1, 256, 32, 32, False), (1, 128, 16, 16, True),
+                                           (1, 256, 64, 64, True)])
+def test_group_norm_h_fwd_bwd(ops, B, C, H, W, film):
+    """GroupNorm32 semantics on half storage (nn.py:17-19: fp32 arithmetic, result cast back): forward and
+    input-gradient vs torch fp32 on the same half inputs; tolerance = the final rounding to half."""
+    G = 32
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).half().float()
+    ga, be = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    fl = 0.2 * torch.randn(B, 2 * C, generator=g) if film else None
+    dy = torch.randn(B, C, H, W, generator=g).half().float()
+    add = torch.randn(B, C, H, W, generator=g).half().float()
+    xr = x.clone().requires_grad_(True)
+    z = F.group_norm(xr, G, ga, be, 1e-5)
+    if film:
+        z = z * (1 + fl[:, :C, None, None]) + fl[:, C:, None, None]
+    yref = F.silu(z)
+    (dxref,) = torch.autograd.grad(yref, xr, dy)
+    dxref = dxref + add
+    HW = H * W
+    xm = ops.Mat.of(to_nhwc_h(x))
+    y = torch.empty(B * HW, C, device=DEV, dtype=torch.float16)
+    part = torch.empty(B * ops.gn_nchunk(HW) * G * 2, device=DEV)
+    st = torch.empty(B * G * 2, device=DEV)
+    fd = fl.to(DEV) if film else None
+    ops.gn_fwd(xm, ops.Mat.of(y), B, HW, G, part, st, ga.to(DEV), be.to(DEV), film=fd, silu=True)
+    assert relerr(from_nhwc(y, B, H, W), yref.detach()) < 1.5 * HALF_ULP
+    dx = torch.empty(B * HW, C, device=DEV, dtype=torch.float16)
+    gst = torch.empty(B * G * 2, device=DEV)
+    ops.gn_bwd(xm, ops.Mat.of(to_nhwc_h(dy)), ops.Mat.of(dx), B, HW, G, st, ga.to(DEV), be.to(DEV), part, gst,
+               film=fd, silu=True, addend=ops.Mat.of(to_nhwc_h(add)))
+    assert relerr(from_nhwc(dx, B, H, W), dxref) < 2 * HALF_ULP
+
+
+def test_resample_layout_convert_h(ops):
+    g = torch.Generator().manual_seed(1)
+    B, C, H, W = 2, 24, 6, 10
+    x = torch.randn(B, C, H, W, generator=g).half().float()
+    xm = ops.Mat.of(to_nhwc_h(x))
+    p = torch.empty(B * (H // 2) * (W // 2), C, device=DEV, dtype=torch.float16)
+    ops.pool2x2(xm, ops.Mat.of(p), B, H, W, 0.25)
+    assert relerr(from_nhwc(p, B, H // 2, W // 2), F.avg_pool2d(x, 2)) < HALF_ULP
+    u = torch.empty(B * 4 * H * W, C, device=DEV, dtype=torch.float16)
+    ops.upsample2x(xm, ops.Mat.of(u), B, H, W, 1.0)
+    assert torch.equal(from_nhwc(u, B, 2 * H, 2 * W), F.interpolate(x, scale_factor=2, mode="nearest"))
+    n = torch.empty(B * H * W, C, device=DEV, dtype=torch.float16)
+    ops.nchw_to_nhwc(x.to(DEV), ops.Mat.of(n), B, C, H * W)
+    assert torch.equal(from_nhwc(n, B, H, W), x)
+    back = torch.empty(B, C, H, W, device=DEV)
+    ops.nhwc_to_nchw(ops.Mat.of(n), back, B, C, H * W)
+    assert torch.equal(back.cpu(), x)
+    f = torch.empty(B * H * W, C, device=DEV)
+    ops.convert(ops.Mat.of(n), ops.Mat.of(f))
+    assert torch.equal(f.cpu(), n.float().cpu())
+    h2 = torch.empty_like(n)
+    ops.convert(ops.Mat.of(f), ops.Mat.of(h2))
+    assert torch.equal(h2, n)
+    acc = n.clone()
+    ops.copy2d(ops.Mat.of(n), ops.Mat.of(acc), accumulate=True)
+    assert torch.equal(acc.float().cpu(), (2 * n.float()).half().float().cpu())
+
+
+def _tiny_models():
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    cfg = U.UNetConfig.from_create_model_kwargs(**BC.TINY_UNET)
+    sd = U.seeded_state_dict(cfg, 1234)
+    m16 = unet.create_model(**dict(BC.TINY_UNET, use_fp16=True))
+    m16.load_state_dict(sd, strict=True)
+    return m16.to(DEV).eval(), cfg, sd
+
+
+def test_tiny_unet_fp16_vs_fp32_oracle():
+    """`create_model(use_fp16=True)`: forward and input gradient of the tiny UNet vs the fp32 oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m16, cfg, sd = _tiny_models()
+    assert m16.conv_mode == "f16" and m16.dtype == torch.float16
+    g = torch.Generator().manual_seed(0)
+    x = 0.7 * torch.randn(2, 4, 32, 32, generator=g)
+    t = torch.tensor([37.0, 5.0])
+    w = torch.randn(2, 8, 32, 32, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = U.unet_forward(sd, cfg, xr, t)
+    (dxr,) = torch.autograd.grad((yr * w).sum(), xr)
+    xd = x.to(DEV).requires_grad_(True)
+    y = m16(xd, t.to(DEV))
+    assert y.dtype == torch.float32
+    (dx,) = torch.autograd.grad((y * w.to(DEV)).sum(), xd)
+    ey, ed = relerr(y.detach().cpu(), yr.detach()), relerr(dx.cpu(), dxr)
+    print(f"tiny UNet fp16 vs fp32 oracle: forward {ey:.2e}  input-gradient {ed:.2e} (relative to max-abs)")
+    assert ey < 2e-2 and ed < 2e-2
+    eng = next(iter(m16._engines.values()))
+    assert eng.adt == torch.float16
+    m16.convert_to_fp32()
+    assert m16.conv_mode != "f16"
+    y32 = m16(x.to(DEV), t.to(DEV))
+    assert relerr(y32.cpu(), yr.detach()) < 1e-4
+
+
+def test_guided_loop_fp16_vs_reference_trace():
+    """10 guided steps (revised underwater operator) in fp16 mode vs the per-step trace captured from the real fp32
+    reference (tests/golden/loop_underwater_physical_revised.npz): the F3 oracle with a stated fp16 tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    m16, cfg, sd = _tiny_models()
+    gold = dict(np.load(os.path.join(GOLD, "loop_underwater_physical_revised.npz")))
+    opc = dict(BC.SAMPLE["measurement"]["operator"])
+    name = opc.pop("name")
+    op = M.get_operator(name, device=DEV, batch_size=1, **opc)
+    cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **BC.SAMPLE["conditioning"]["params"],
+                                      **BC.PATTERN, **BC.SAMPLE["aux_loss"])
+    sampler = gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                     model_mean_type="epsilon", model_var_type="learned_range",
+                                     dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
+    noise = torch.from_numpy(gold["noise"]).to(DEV)
+    trace = []
+    img, variables, loss, x0 = sampler.p_sample_loop(
+        model=m16, x_start=torch.from_numpy(gold["x_T"]).to(DEV), measurement=torch.from_numpy(gold["y"]).to(DEV),
+        measurement_cond_fn=cond.conditioning, record=False, save_root=None, pretrain_model="osmosis",
+        rgb_guidance=False, sample_pattern=BC.PATTERN, noise_fn=lambda k, shape: noise[k], trace=trace)
+    e_in = max(float((trace[k]["x_in"].cpu() - torch.from_numpy(gold["trace.x_in"][k])).abs().max()) for k in range(10))
+    e_x0 = max(float((trace[k]["x0"].cpu() - torch.from_numpy(gold["trace.x0"][k])).abs().max()) for k in range(10))
+    e_fin = float((img.cpu() - torch.from_numpy(gold["final_img"])).abs().max())
+    print(f"fp16 guided loop vs fp32 reference trace: x_t {e_in:.2e}  pred_xstart {e_x0:.2e}  final x_0 {e_fin:.2e}  "
+          f"final loss {float(loss[0]):.4f} vs {float(gold['final_loss'][0]):.4f}")
+    assert e_in < 3e-2 and e_x0 < 3e-2 and e_fin < 3e-2
+    assert abs(float(loss[0]) - float(gold["final_loss"][0])) < 2e-2 * abs(float(gold["final_loss"][0]))
+
+
+def test_config5_haze_batch32_fp16_full_size():
+    """BASELINE config 5 as quoted: B = 32, haze_physical, degamma_input, 250-step respacing, use_fp16.  Half storage
+    keeps ~4 GB per image, so the 32 images go through ONE engine pass (no chunking); image 0 stays within the fp16
+    tolerance of the fp32 (bf16x6) run of the same image."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import test_configs_gpu as TC
+    from osmosis_diffusion_code_amd import sampling
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    cfg = BC.HAZE
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = unet.create_model(**cfg["unet_model"])
+    model.reset_parameters(1234)
+    model = model.to(DEV).eval()
+    assert model.conv_mode == "f16"
+    sampler = gd.create_sampler(**cfg["diffusion"])
+    gt, y = TC.synthetic_scene(32, seed=21, phi_ab=(1.0, 1.0, 1.0), phi_inf=(0.14, 0.29, 0.49), depth_type="gamma")
+    yl = sampling.degamma(2 * torch.pow(0.5 * (y + 1), 1 / 2.2) - 1)
+    x_start = TC.noised_start(gt, sampler, 2)
+    noise = torch.randn(3, 32, 4, 256, 256, generator=torch.Generator().manual_seed(2))
+    img, variables, loss, x0 = TC.run_chain(model, cfg, x_start, yl, 3, noise)
+    eng = next(iter(model._engines.values()))
+    assert eng.B == 32 and eng.adt == torch.float16
+    assert torch.isfinite(img).all() and torch.isfinite(x0).all() and np.isfinite(loss).all()
+    model.convert_to_fp32()
+    r_img, r_vars, r_loss, r_x0 = TC.run_chain(model, cfg, x_start[:1], yl[:1], 3, noise[:, :1])
+    e_img, e_x0 = float((img[0] - r_img[0]).abs().max()), float((x0[0] - r_x0[0]).abs().max())
+    print(f"config 5 fp16 (B=32) vs fp32 (B=1), image 0 after 3 steps: x_(t-1) {e_img:.2e}  pred_xstart {e_x0:.2e}  "
+          f"loss {loss[0]:.4f} vs {r_loss[0]:.4f}")
+    assert e_img < 3e-2 and e_x0 < 3e-2
