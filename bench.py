@@ -135,6 +135,11 @@ def roofline(model, args):
             fl = 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * d.ksize * d.ksize
             shape = (d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.splitk)
             per_shape.setdefault(shape, [0.0, 0, fl])
+            # layers with <= 256 pixel rows (8x8, 16x16 at batch 1) run the small-M weight-streaming kernel (3x3 and 1x1)
+            small_m = (args.conv_mode != "f32" and d.B * d.H * d.W <= int(os.environ.get("OSM_SKINNY_MAXM", "256"))
+                       and d.Cin % 32 == 0 and not d.gn_table)
+            if small_m:
+                return ("conv_small_m", fl, shape)
             if d.ksize != 3:
                 return ("conv1x1", fl, shape)
             # split-bf16 modes: layers with W >= 16 run the halo-tile kernel (the dominant one), the 8x8
@@ -190,7 +195,7 @@ def roofline(model, args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
             pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
-                    "bf16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]
+                    "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1"}[args.conv_mode]
             hit = [k for k in json.load(open(path))["kernels"]
                    if k["kernel"].replace(" ", "").startswith(pref)
                    and (args.conv_mode == "f32" or k["kernel"].replace(" ", "").endswith(",16>"))]   # 8 x 16 patches
@@ -200,8 +205,10 @@ def roofline(model, args):
         except Exception:
             pass
     convs3 = {k: v for k, v in per_shape.items()
-              if len(k) == 7 and k[5] == 3 and (args.conv_mode == "f32" or (k[2] >= 16 and k[1] >= 8))}
-    alg_bytes = sum(4.0 * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
+              if len(k) == 7 and k[5] == 3 and (args.conv_mode == "f32" or (k[2] >= 16 and k[1] >= 8 and
+                                                 k[0] * k[1] * k[2] > int(os.environ.get("OSM_SKINNY_MAXM", "256"))))}
+    esz = 2.0 if args.conv_mode == "f16" else 4.0
+    alg_bytes = sum(esz * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
                     for k, v in convs3.items()) / max(1, sum(v[1] for v in convs3.values()))
     kname, peak, note = {
         "f32": ("igemm_f32_kernel<9,false>", FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
@@ -211,6 +218,9 @@ def roofline(model, args):
         "bf16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
                    "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative): "
                    "peak = 2500 / 3; achieved counts ALGORITHMIC flops"),
+        "f16": ("conv3_halo_bf16s_kernel<1>", BF16_MFMA_PEAK_TFLOPS,
+                "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one v_mfma_f32_32x32x16_f16 "
+                "per product; peak = dense fp16 MFMA peak 2500 TFLOP/s"),
     }[args.conv_mode]
     return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -288,7 +298,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU (reference config: 1)")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps for cpu_baseline (0 = skip)")
-    ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "bf16x3"],
+    ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "bf16x3", "f16"],
                     help="conv arithmetic: exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
@@ -329,7 +339,7 @@ def main():
         "metric": "denoise-steps/sec (256x256 RGBD, 1000-step DDPM+guidance)",
         "value": round(units / dt, 4), "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.conv_mode == "f16" else "f32", "data": "synthetic",
         "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
                                "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime (t <= 0.3T)",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,

@@ -96,6 +96,10 @@ int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, 
 int osm_gemm(const osm_gemm_desc* d, void* stream);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
+/* the split-K factor osm_conv2d_nhwc(_h) should be given for a layer (pass it as desc.splitk with a workspace of
+ * splitk*B*H*W*Cout floats): layers with few pixel rows (<= 256: the 8x8 / 16x16 levels at batch 1) run a
+ * weight-streaming kernel that splits K over the 4 waves of a workgroup first, so they need fewer partials. */
+int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int has_gn_table);
 
 /* ------------------------------------------------------------------ fused attention core (low resolutions)
  * QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467) for T in {64, 256} tokens and
@@ -119,6 +123,15 @@ typedef struct osm_attn_desc {
   long long lddqkv;
   float* ws;
 } osm_attn_desc;
+/* Flash-style core on the matrix cores for T a multiple of 256 (the 16x16 / 32x32 blocks) and 64-wide heads:
+ * logits / probabilities stay in registers, fp32 operands are split into 3 bf16 planes (6 MFMAs per product, fp32-class),
+ * softmax in fp32.  Forward writes `out` and lse[B*heads][T] (max + log-sum of the scaled logits of each query row);
+ * backward takes that lse and the forward output (for delta = rowsum(d(out) * out), scratch `delta` [B*heads][T]),
+ * recomputes P and writes dq | dk | dv into dqkv. */
+int osm_attn_flash_supported(int T, int ch);
+int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stream);
+int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long long ldout, const float* lse, float* delta,
+                       void* stream);
 int osm_attn_small_supported(int T, int ch);
 int osm_attn_small_fwd(const osm_attn_desc* d, void* stream);
 int osm_attn_small_bwd(const osm_attn_desc* d, void* stream);

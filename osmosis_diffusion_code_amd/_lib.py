@@ -71,7 +71,11 @@ _SIGS = {
     "osm_gemm": [C.POINTER(GemmDesc), _P],
     "osm_pack_conv_weight_bf16s": [_P, _P, _P, _I, _I, _I, _I, _P],
     "osm_splitk_hint": [_I, _I, _I, _I, _I],
+    "osm_conv_splitk": [_I, _I, _I, _I, _I, _I, _I, _I],
     "osm_attn_small_supported": [_I, _I],
+    "osm_attn_flash_supported": [_I, _I],
+    "osm_attn_flash_fwd": [C.POINTER(AttnDesc), _P, _P],
+    "osm_attn_flash_bwd": [C.POINTER(AttnDesc), _P, _LL, _P, _P, _P],
     "osm_attn_small_fwd": [C.POINTER(AttnDesc), _P],
     "osm_attn_small_bwd": [C.POINTER(AttnDesc), _P],
     "osm_gn_nchunk": [_I],

@@ -1,0 +1,404 @@
+// Flash-style attention core on the matrix cores for the 16x16 and 32x32 AttentionBlocks (T = 256, 1024 tokens,
+// 64-wide heads).  Reference: QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467):
+//     w = softmax(einsum(q * s, k * s)) (in fp32, :431),  a = einsum(w, v),  s = ch^-1/4
+// and its autograd (the reference checkpoints the block, unet.py:376 / nn.py:142-170: P is recomputed in backward;
+// so is it here, from the saved log-sum-exp).
+//
+// Round 1 ran this as GEMM -> softmax -> transpose -> GEMM through HBM (5 + 9 launches, logits and probabilities
+// written and re-read: 1.8 ms per step).  Here S and P never leave the registers of the wave that made them:
+//   * arithmetic: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product (mfma_split.h, the same
+//     fp32-class arithmetic as the convolutions); softmax in fp32 on the VALU;
+//   * a workgroup = (32 query rows | 32 key rows, head, image); its four waves split the OTHER sequence axis four ways
+//     (flash-decoding style), so that B = 1 still yields 256 (T = 1024) / 128 (T = 256) workgroups, and combine
+//     through LDS (running max / sum for the forward, plain sums for the gradients);
+//   * logits are produced TRANSPOSED (keys x queries for the forward / dq pass): in the 32x32 MFMA C layout a lane then
+//     holds 16 keys of ONE query, so the row max / sum of the softmax are in-lane reductions plus one cross-half
+//     shuffle, and the same registers ARE the B-operand fragment of the following P V product (the 16 key slots of a
+//     k16-step are a permutation of 16 consecutive keys; the V gather uses the same permutation) -- no LDS
+//     round trip, no cross-lane traffic between the two GEMMs;
+//   * operands come straight from the qkv matrix in L2 (<= 6 MB): row-pattern fragments are two 16-byte loads,
+//     gather-pattern fragments (the operand that is contracted over its ROW index) eight 4-byte loads of
+//     128-byte-coalesced rows.
+#include "osm_common.h"
+#include "mfma_split.h"
+
+namespace {
+
+constexpr int NP = 3;      // bf16x6
+constexpr int DH = 64;     // head width
+
+struct FlashArgs {
+  const float* qkv;
+  long long ldqkv;
+  int q_off, k_off, v_off, hs;
+  float* out;            // forward: [B*T][ldout], head h at columns h * 64
+  long long ldout;
+  float* lse;            // [B*heads][T]: max + log(sum) of the scaled logits of a query row
+  const float* o;        // backward: the forward output (for delta = rowsum(dO * O))
+  long long ldo;
+  const float* dout;     // [B*T][lddout]
+  long long lddout;
+  float* delta;          // [B*heads][T]
+  float* dqkv;           // [B*T][lddqkv], same column layout as qkv
+  long long lddqkv;
+  int B, T, heads;
+  float scale;
+};
+
+// X[row][col + 16 s + 8 h + e], e = 0..7  ->  NP fragments (A operand: rows x k; or B operand: k x columns)
+__device__ __forceinline__ void frag_row(const float* __restrict__ X, long long ld, long long row, int col, int s, int h,
+                                         float scale, uint4 (&f)[NP]) {
+  const float* p = X + row * ld + col + 16 * s + 8 * h;
+  float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+  b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+  split_frag8<NP>(a, b, f);
+}
+// X[row0 + 16 s + (e & 3) + 8 (e >> 2) + 4 h][col], e = 0..7: the operand contracted over its row index, in the
+// slot order in which a C-layout accumulator hands over the other operand
+__device__ __forceinline__ void frag_gather(const float* __restrict__ X, long long ld, long long row0, int col, int s,
+                                            int h, uint4 (&f)[NP]) {
+  const float* p = X + (row0 + 16 * s + 4 * h) * ld + col;
+  const float4 a = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+  const float4 b = make_float4(p[8 * ld], p[9 * ld], p[10 * ld], p[11 * ld]);
+  split_frag8<NP>(a, b, f);
+}
+// accumulator registers [8 s .. 8 s + 7] -> fragment of step s
+__device__ __forceinline__ void frag_acc(const f32x16& c, int s, uint4 (&f)[NP]) {
+  if (s == 0)
+    split_frag8<NP>(make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7]), f);
+  else
+    split_frag8<NP>(make_float4(c[8], c[9], c[10], c[11]), make_float4(c[12], c[13], c[14], c[15]), f);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.f;
+  return z;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (T / 32, heads, B).  Wave w: keys [w T/4, (w+1) T/4), 64 at a time.
+__global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
+  __shared__ float os[4][DH][33];
+  __shared__ float ms[4][32];
+  __shared__ float ls[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const long long ld = a.ldqkv;
+
+  uint4 qf[4][NP];   // B operand of S^T = K (scale Q)^T: k = d, column = this lane's query
+#pragma unroll
+  for (int s = 0; s < 4; ++s) frag_row(Q, ld, rb + q0 + lr, 0, s, h, a.scale, qf[s]);
+
+  f32x16 o0 = zero16(), o1 = zero16();   // O^T: rows d (0..31 | 32..63), column = query
+  float m = -INFINITY, l = 0.f;
+  const int kw = a.T >> 2;
+  for (int kb = wave * kw; kb < (wave + 1) * kw; kb += 64) {
+    f32x16 s0 = zero16(), s1 = zero16();   // S^T of keys kb .. kb+31 | kb+32 .. kb+63
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 k0[NP], k1[NP];
+      frag_row(K, ld, rb + kb + lr, 0, s, h, 1.f, k0);
+      frag_row(K, ld, rb + kb + 32 + lr, 0, s, h, 1.f, k1);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          s0 = mma16<NP>(k0[pa], qf[s][pb], s0);
+          s1 = mma16<NP>(k1[pa], qf[s][pb], s1);
+        }
+    }
+    // online softmax of this lane's query over its 32 keys (the other 32 sit in lane ^ 32)
+    float mx = s0[0];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s0[e] = __expf(s0[e] - mn);
+      s1[e] = __expf(s1[e] - mn);
+      ps += s0[e] + s1[e];
+    }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      o0[e] *= alpha;
+      o1[e] *= alpha;
+    }
+    // O^T += V^T P^T : A = V^T (rows d, key slots), B = P^T straight from the S^T registers
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint4 pf[NP], v0[NP], v1[NP];
+      frag_acc(t < 2 ? s0 : s1, t & 1, pf);
+      frag_gather(V, ld, rb + kb + 32 * (t >> 1), lr, t & 1, h, v0);
+      frag_gather(V, ld, rb + kb + 32 * (t >> 1), 32 + lr, t & 1, h, v1);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          o0 = mma16<NP>(v0[pa], pf[pb], o0);
+          o1 = mma16<NP>(v1[pa], pf[pb], o1);
+        }
+    }
+  }
+  // ---- combine the four key ranges.  O^T C layout: column = query lr, row d = 32 mb + (e&3) + 8 (e>>2) + 4 h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = o0[e];
+    os[wave][32 + d][lr] = o1[e];
+  }
+  if (h == 0) ms[wave][lr] = m;
+  ls[wave][lane] = l;
+  __syncthreads();
+  const int d = tid & 63, qg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = qg * 8 + i;
+    const float M = fmaxf(fmaxf(ms[0][q], ms[1][q]), fmaxf(ms[2][q], ms[3][q]));
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = __expf(ms[w][q] - M);
+      L += (ls[w][q] + ls[w][q + 32]) * sc;
+      o += os[w][d][q] * sc;
+    }
+    a.out[(rb + q0 + q) * a.ldout + hd * DH + d] = o / L;
+    if (d == 0) a.lse[((long long)blockIdx.z * a.heads + hd) * a.T + q0 + q] = M + logf(L);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// delta[q] = sum_d dO[q][d] O[q][d]        one wave per (row, head): grid (B*T*heads / 4)
+__global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= (long long)a.B * a.T * a.heads) return;
+  const int hd = (int)(i % a.heads);
+  const long long row = i / a.heads;        // b * T + t
+  float v = a.dout[row * a.lddout + hd * DH + lane] * a.o[row * a.ldo + hd * DH + lane];
+  v = osm::wave_sum(v);
+  if (lane == 0) a.delta[((row / a.T) * a.heads + hd) * a.T + row % a.T] = v;
+}
+
+// dq: grid (T / 32, heads, B): workgroup = 32 queries, waves split the keys.
+//   S^T = K (scale Q)^T, P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);
+//   dq^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
+__global__ __launch_bounds__(256, 1) void flash_bwd_q_kernel(FlashArgs a) {
+  __shared__ float os[4][DH][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const float* __restrict__ dO = a.dout + hd * DH;
+  const long long ld = a.ldqkv;
+  const long long stat = ((long long)blockIdx.z * a.heads + hd) * a.T + q0 + lr;
+  const float lse = a.lse[stat], dl = a.delta[stat];
+
+  uint4 qf[4][NP], gf[4][NP];   // B operands (k = d, column = query): scale * Q and dO
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    frag_row(Q, ld, rb + q0 + lr, 0, s, h, a.scale, qf[s]);
+    frag_row(dO, a.lddout, rb + q0 + lr, 0, s, h, 1.f, gf[s]);
+  }
+  f32x16 g0 = zero16(), g1 = zero16();   // dq^T rows d (0..31 | 32..63), column = query
+  const int kw = a.T >> 2;
+  for (int kb = wave * kw; kb < (wave + 1) * kw; kb += 32) {
+    f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 kf[NP], vf[NP];
+      frag_row(K, ld, rb + kb + lr, 0, s, h, 1.f, kf);
+      frag_row(V, ld, rb + kb + lr, 0, s, h, 1.f, vf);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          st = mma16<NP>(kf[pa], qf[s][pb], st);
+          dp = mma16<NP>(vf[pa], gf[s][pb], dp);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = __expf(st[e] - lse) * (dp[e] - dl);   // dS^T
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 sf[NP], k0[NP], k1[NP];
+      frag_acc(st, t, sf);
+      frag_gather(K, ld, rb + kb, lr, t, h, k0);
+      frag_gather(K, ld, rb + kb, 32 + lr, t, h, k1);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          g0 = mma16<NP>(k0[pa], sf[pb], g0);
+          g1 = mma16<NP>(k1[pa], sf[pb], g1);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = g0[e];
+    os[wave][32 + d][lr] = g1[e];
+  }
+  __syncthreads();
+  const int d = tid & 63, qg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = qg * 8 + i;
+    const float v = (os[0][d][q] + os[1][d][q]) + (os[2][d][q] + os[3][d][q]);
+    a.dqkv[(rb + q0 + q) * a.lddqkv + a.q_off + hd * a.hs + d] = v * a.scale;
+  }
+}
+
+// dk, dv: grid (T / 32, heads, B): workgroup = 32 keys, waves split the queries.
+//   S = (scale Q) K^T (queries x keys: column = this lane's key), P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q]);
+//   dv^T[d][key] = sum_q dO^T[d][q] P[q][key];   dk^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+__global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs a) {
+  __shared__ float os[4][2 * DH][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int k0r = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const float* __restrict__ dO = a.dout + hd * DH;
+  const long long ld = a.ldqkv;
+  const float* __restrict__ lsep = a.lse + ((long long)blockIdx.z * a.heads + hd) * a.T;
+  const float* __restrict__ dlp = a.delta + ((long long)blockIdx.z * a.heads + hd) * a.T;
+
+  uint4 kf[4][NP], vf[4][NP];   // B operands (k = d, column = key)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    frag_row(K, ld, rb + k0r + lr, 0, s, h, 1.f, kf[s]);
+    frag_row(V, ld, rb + k0r + lr, 0, s, h, 1.f, vf[s]);
+  }
+  f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+  const int qw = a.T >> 2;
+  for (int qb = wave * qw; qb < (wave + 1) * qw; qb += 32) {
+    f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 qf[NP], gf[NP];
+      frag_row(Q, ld, rb + qb + lr, 0, s, h, a.scale, qf);
+      frag_row(dO, a.lddout, rb + qb + lr, 0, s, h, 1.f, gf);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          sc = mma16<NP>(qf[pa], kf[s][pb], sc);
+          dp = mma16<NP>(gf[pa], vf[s][pb], dp);
+        }
+    }
+    // rows of the C layout are queries: q = qb + (e&3) + 8 (e>>2) + 4 h
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb + 8 * j + 4 * h);
+      const float4 d4 = *reinterpret_cast<const float4*>(dlp + qb + 8 * j + 4 * h);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pr = __expf(sc[4 * j + i] - lv[i]);
+        sc[4 * j + i] = pr;                          // P
+        dp[4 * j + i] = pr * (dp[4 * j + i] - dv[i]);   // dS
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 pf[NP], sf[NP], g0[NP], g1[NP], q0f[NP], q1f[NP];
+      frag_acc(sc, t, pf);
+      frag_acc(dp, t, sf);
+      frag_gather(dO, a.lddout, rb + qb, lr, t, h, g0);
+      frag_gather(dO, a.lddout, rb + qb, 32 + lr, t, h, g1);
+      frag_gather(Q, ld, rb + qb, lr, t, h, q0f);
+      frag_gather(Q, ld, rb + qb, 32 + lr, t, h, q1f);
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+          dv0 = mma16<NP>(g0[pa], pf[pb], dv0);
+          dv1 = mma16<NP>(g1[pa], pf[pb], dv1);
+          dk0 = mma16<NP>(q0f[pa], sf[pb], dk0);
+          dk1 = mma16<NP>(q1f[pa], sf[pb], dk1);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = dv0[e];
+    os[wave][32 + d][lr] = dv1[e];
+    os[wave][64 + d][lr] = dk0[e];
+    os[wave][96 + d][lr] = dk1[e];
+  }
+  __syncthreads();
+  const int d = tid & 63, kg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = kg * 8 + i;
+    const float dvv = (os[0][d][k] + os[1][d][k]) + (os[2][d][k] + os[3][d][k]);
+    const float dkv = (os[0][64 + d][k] + os[1][64 + d][k]) + (os[2][64 + d][k] + os[3][64 + d][k]);
+    float* row = a.dqkv + (rb + k0r + k) * a.lddqkv + hd * a.hs;
+    row[a.v_off + d] = dvv;
+    row[a.k_off + d] = dkv * a.scale;
+  }
+}
+
+int check(const osm_attn_desc* d, const char* who) {
+  OSM_REQUIRE(d && d->qkv, "%s: null pointer", who);
+  OSM_REQUIRE(d->ch == DH && d->T >= 256 && d->T % 256 == 0, "%s: needs 64-wide heads and T a multiple of 256 (got ch %d, T %d)",
+              who, d->ch, d->T);
+  OSM_REQUIRE(d->B > 0 && d->heads > 0, "%s: bad shape", who);
+  OSM_REQUIRE(d->ldqkv % 4 == 0 && d->q_off % 4 == 0 && d->k_off % 4 == 0 && d->v_off % 4 == 0 && d->head_stride % 4 == 0 &&
+              osm::aligned16(d->qkv), "%s: qkv columns must be 16-byte aligned", who);
+  return OSM_OK;
+}
+
+FlashArgs to_args(const osm_attn_desc* d) {
+  FlashArgs a{};
+  a.qkv = d->qkv; a.ldqkv = d->ldqkv; a.q_off = d->q_off; a.k_off = d->k_off; a.v_off = d->v_off; a.hs = d->head_stride;
+  a.out = d->out; a.ldout = d->ldout; a.dout = d->dout; a.lddout = d->lddout; a.dqkv = d->dqkv; a.lddqkv = d->lddqkv;
+  a.B = d->B; a.T = d->T; a.heads = d->heads; a.scale = d->scale;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int osm_attn_flash_supported(int T, int ch) { return ch == DH && T >= 256 && T % 256 == 0; }
+
+extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stream) {
+  int rc = check(d, "osm_attn_flash_fwd");
+  if (rc) return rc;
+  OSM_REQUIRE(d->out && lse, "osm_attn_flash_fwd: null pointer");
+  FlashArgs a = to_args(d);
+  a.lse = lse;
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3(d->T / 32, d->heads, d->B), dim3(256), 0, (hipStream_t)stream, a);
+  return osm::check_launch("flash_fwd_kernel");
+}
+
+extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long long ldout, const float* lse, float* delta,
+                                  void* stream) {
+  int rc = check(d, "osm_attn_flash_bwd");
+  if (rc) return rc;
+  OSM_REQUIRE(d->dout && d->dqkv && out && lse && delta, "osm_attn_flash_bwd: null pointer");
+  OSM_REQUIRE(d->lddout % 4 == 0 && osm::aligned16(d->dout), "osm_attn_flash_bwd: dout must be 16-byte aligned");
+  FlashArgs a = to_args(d);
+  a.o = out; a.ldo = ldout; a.lse = const_cast<float*>(lse); a.delta = delta;
+  const long long rows = (long long)d->B * d->T * d->heads;
+  hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 g(d->T / 32, d->heads, d->B);
+  hipLaunchKernelGGL(flash_bwd_q_kernel, g, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_bwd_kv_kernel, g, dim3(256), 0, (hipStream_t)stream, a);
+  return osm::check_launch("flash_bwd kernels");
+}

@@ -24,11 +24,11 @@
 //   * Small-M layers (8x8..32x32) are weight-bandwidth bound: split-K over grid.y with fp32
 //     partials and a deterministic reduce.
 #include "osm_common.h"
+#include "mfma_split.h"
 #include <cstdlib>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 [[maybe_unused]] constexpr int LDS_STRIDE = 36;      // floats per staged row (32 + 4 pad)
@@ -59,9 +59,6 @@ struct IGemmParams {
   int gn_silu;
 };
 
-__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
 
 #ifndef OSM_ACT_F16
 // NARROW (N <= 64, e.g. attention P V with 64-wide heads): the four waves split the 128 rows (32 each) and
@@ -353,6 +350,34 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 #include "igemm_bf16s.inc.h"
 #include "conv3_halo.inc.h"
+#include "skinny.inc.h"
+
+// ---- small-M path (skinny.inc.h): eligibility and its split of K
+// OSM_SKINNY_MAXM: largest M (pixel rows) served by the small-M kernel (default 256: the 8x8 and 16x16 levels at
+// batch 1); 0 switches it off (A/B measurements).
+int skinny_max_m() {
+  static const int v = [] {
+    const char* e = std::getenv("OSM_SKINNY_MAXM");
+    return e ? atoi(e) : 256;
+  }();
+  return v;
+}
+bool skinny_ok(int M, int K, int wfmt, bool gn_table) {
+  return wfmt != 0 && !gn_table && K % 32 == 0 && M <= skinny_max_m();
+}
+int skinny_rb(int M) { return M <= 64 ? 2 : (M <= 128 ? 4 : 8); }
+// grid.y of the small-M kernel (K is cut 4 * grid.y ways: 4 waves per workgroup): ~4 waves per CU, >= 4 k16-steps each
+int skinny_gridy(int M, int N, int K, int taps) {
+  const int rb = skinny_rb(M);
+  const int tiles = ((N + 31) / 32) * ((M + rb * 32 - 1) / (rb * 32));
+  const int nsteps = taps * 2 * ((K + 31) / 32);
+  int nsplit = (1024 + tiles - 1) / tiles;
+  if (nsplit > nsteps / 4) nsplit = nsteps / 4;
+  int gy = (nsplit + 3) / 4;
+  if (gy < 1) gy = 1;
+  if (gy > 16) gy = 16;
+  return gy;
+}
 
 // OSM_CONV_HALO=0 selects the tap-chunked kernel for 3x3 layers too (A/B measurements only)
 bool halo_enabled() {
@@ -375,7 +400,25 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 #else
   if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
 #endif
-  if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
+  if (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) && p.nbatch == 1) {
+    // small-M kernel: weight streaming, K split over the 4 waves of a workgroup (and over grid.y = p.splitk)
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
+    const int rb = skinny_rb(p.M);
+    const int nsteps = taps * p.ksteps;
+    if (p.splitk * 4 > nsteps) p.splitk = nsteps / 4 > 0 ? nsteps / 4 : 1;
+    const dim3 g3(p.nt32, p.splitk, (p.M + rb * 32 - 1) / (rb * 32));
+#define OSM_SK_LAUNCH(NP_, RB_, T_) hipLaunchKernelGGL((skinny_kernel<NP_, RB_, T_>), g3, dim3(256), 0, st, p.A, Bp, p)
+#define OSM_SK_PICK(NP_)                                                                                   \
+    if (taps == 9) { if (rb == 2) OSM_SK_LAUNCH(NP_, 2, 9); else if (rb == 4) OSM_SK_LAUNCH(NP_, 4, 9); else OSM_SK_LAUNCH(NP_, 8, 9); } \
+    else           { if (rb == 2) OSM_SK_LAUNCH(NP_, 2, 1); else if (rb == 4) OSM_SK_LAUNCH(NP_, 4, 1); else OSM_SK_LAUNCH(NP_, 8, 1); }
+#ifdef OSM_ACT_F16
+    OSM_SK_PICK(1)
+#else
+    if (wfmt == 3) { OSM_SK_PICK(3) } else { OSM_SK_PICK(2) }
+#endif
+#undef OSM_SK_PICK
+#undef OSM_SK_LAUNCH
+  } else if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
     // halo-tile kernel: M-tiles are 8 x 16 (W >= 16) or 8 x 8 pixel patches, K is consumed in 32-channel slabs of all 9 taps
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const bool wide = p.W >= 16;
@@ -466,6 +509,12 @@ extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
   return (int)(s < 1 ? 1 : s);
 }
 
+// split-K factor osm_conv2d_nhwc(_h) wants for a layer (callers size the fp32 workspace splitk * M * Cout from it)
+extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int has_gn_table) {
+  const int M = B * H * W;
+  if (skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return skinny_gridy(M, Cout, Cin, ksize * ksize);
+  return osm_splitk_hint(M, Cout, Cin, ksize * ksize, 1);
+}
 #endif   // !OSM_ACT_F16
 
 #ifdef OSM_ACT_F16

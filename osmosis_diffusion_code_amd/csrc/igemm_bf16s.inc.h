@@ -27,54 +27,13 @@
 //       waves: 48 % MFMA busy.  An MFMA leaves ~5 issue slots per 32-cycle gap; the ~140 VALU + 40 memory
 //       instructions of the staging work fit in the 48 gaps of a chunk.)
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// (split helpers, fragment types and mma16<NP>: mfma_split.h)
 constexpr int ACT_B = (int)sizeof(act_t);   // bytes per stored activation (4, or 2 in the OSM_ACT_F16 family)
-
 constexpr int S_ROWB = 80;              // bytes per staged A row (32 bf16 + 16 B pad)
 constexpr int S_PLANE = 128 * S_ROWB;   // bytes per 128-row plane
 
 // 32 B of zeros every masked staging load is redirected to (halo / ragged edge / channel tail).
 __device__ uint4 g_zero_page[2];   // zero-initialised device global (never written)
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // RNE, v_cvt_pk_bf16_f32
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const f2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-// 4 fp32 -> NP planes of 4 bf16 (2 packed dwords per plane); 22 VALU ops for NP = 3.
-template <int NP>
-__device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
-  if constexpr (NP == 1) {   // fp16 arithmetic (the reference's use_fp16): ONE half plane, RNE
-    const osm::floatx4_t f = {x.x, x.y, x.z, x.w};
-    pl[0] = __builtin_bit_cast(uint2, __builtin_convertvector(f, osm::half4_t));
-    return;
-  }
-  unsigned a = cvt_pk_bf16(x.x, x.y), b = cvt_pk_bf16(x.z, x.w);
-  pl[0] = make_uint2(a, b);
-  float r0 = x.x - bf_lo(a), r1 = x.y - bf_hi(a), r2 = x.z - bf_lo(b), r3 = x.w - bf_hi(b);
-  a = cvt_pk_bf16(r0, r1);
-  b = cvt_pk_bf16(r2, r3);
-  pl[1] = make_uint2(a, b);
-  if (NP == 3) {
-    r0 -= bf_lo(a); r1 -= bf_hi(a); r2 -= bf_lo(b); r3 -= bf_hi(b);
-    pl[NP - 1] = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
-  }
-}
-
-__device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
-// one 32x32x16 MFMA on 16-byte fragments: bf16 planes (NP = 2, 3) or fp16 (NP = 1)
-template <int NP>
-__device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
-  if constexpr (NP == 1)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
 
 template <int TAPS, int NP>
 __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __restrict__ Aglob,

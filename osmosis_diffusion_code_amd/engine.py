@@ -278,7 +278,7 @@ class UNetEngine:
         cin = cv.cout if dgrad else cv.cin
         cout = cv.cin if dgrad else cv.cout
         assert x.cols == cin and y.cols == cout and x.rows == M and y.rows == M, (x.cols, cin, y.cols, cout)
-        sk = ops.splitk_hint(M, cout, cin, cv.k * cv.k, 1)
+        sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, cv.wfmt, gn_table is not None)
         ws = None
         if sk > 1:
             ws = self._scr_flat("splitk", sk * M * cout)
@@ -433,8 +433,14 @@ class UNetEngine:
         # only 64 workgroups and the unfused GEMM pipeline wins (OSM_ATTN_FUSED=all / 0 to force either way)
         mode = os.environ.get("OSM_ATTN_FUSED", "64")
         fused = ops.attn_small_supported(T, ch) and (mode == "all" or (mode != "0" and T <= 64))
-        P = PT = None
-        if fused:      # 8x8 / 16x16: logits stay on the CU, one launch, nothing kept for the backward
+        # 16x16 / 32x32 with 64-wide heads: flash-style core on the matrix cores (OSM_ATTN_FLASH=0: the GEMM pipeline)
+        flash = (not fused) and os.environ.get("OSM_ATTN_FLASH", "1") != "0" and ops.attn_flash_supported(T, ch)
+        P = PT = lse = None
+        if flash:      # logits / probabilities stay in registers; the output and its log-sum-exp are kept for the backward
+            a = self._buf(M, C, torch.float32)
+            lse = self._small(nmat * T)
+            ops.attn_flash_fwd(qkv, a, lse, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+        elif fused:    # 8x8: logits stay on the CU, one launch, nothing kept for the backward
             ops.attn_small_fwd(qkv, a, B, T, nh, ch, (qo, ko, vo), hs, alpha)
         else:
             S = self._scr_flat("s0", nmat * T * T)
@@ -445,12 +451,14 @@ class UNetEngine:
             ops.softmax_rows(S, P, PT, nmat, T)
             self._gemm(P, T, qkv.t, 3 * C, a.t, C, T, ch, T, b_kn=True, nb1=nh, nb2=B,
                        sA=(T * T, nh * T * T), sB=(hs, T * 3 * C), sC=(ch, T * C), b_off=vo)
+        a32 = a
         if half:
             a_h = self._scr("a", M, C)
             ops.convert(a, a_h)
             a = a_h
         self._conv(a, blk.proj, dst, hw, res=x)
-        self._saved[id(blk)] = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused)
+        self._saved[id(blk)] = dict(x=x, st=st, qkv=qkv, P=P, PT=PT, hw=hw, fused=fused, flash=flash, lse=lse,
+                                    a=a32 if flash else None)
         return hw
 
     def _attn_bwd(self, blk: _Attn, dy: Mat, dx_dst: Mat, accumulate: bool):
@@ -472,7 +480,10 @@ class UNetEngine:
             ops.convert(da, da32)
             da = da32
         dqkv = self._scr("b", M, 3 * C, torch.float32)
-        if s["fused"]:
+        if s["flash"]:
+            delta = self._scr_flat("s0", nmat * T)
+            ops.attn_flash_bwd(qkv, s["a"], da, dqkv, s["lse"], delta, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+        elif s["fused"]:
             ws = self._scr_flat("s0", 2 * nmat * T * T)
             ops.attn_small_bwd(qkv, da, dqkv, ws, B, T, nh, ch, (qo, ko, vo), hs, alpha)
         else:

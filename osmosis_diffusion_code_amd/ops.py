@@ -149,8 +149,32 @@ def attn_small_bwd(qkv: Mat, dout: Mat, dqkv: Mat, ws: torch.Tensor, B, T, heads
     call("osm_attn_small_bwd", C.byref(d), _s(), keep=(d, qkv.t, dout.t, dqkv.t, ws))
 
 
+def attn_flash_supported(T: int, ch: int) -> bool:
+    return bool(query("osm_attn_flash_supported", T, ch))
+
+
+def attn_flash_fwd(qkv: Mat, out: Mat, lse: torch.Tensor, B, T, heads, ch, offsets, head_stride, scale):
+    """out = softmax(scale q k^T) v per (image, head) on the matrix cores; lse [B*heads*T] is kept for the backward."""
+    d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
+    d.out, d.ldout = out.p, out.ld
+    call("osm_attn_flash_fwd", C.byref(d), ptr(lse), _s(), keep=(d, qkv.t, out.t, lse))
+
+
+def attn_flash_bwd(qkv: Mat, out: Mat, dout: Mat, dqkv: Mat, lse, delta, B, T, heads, ch, offsets, head_stride, scale):
+    """dq | dk | dv (qkv column layout) from d(out), the forward output and its lse; delta: [B*heads*T] scratch."""
+    d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
+    d.dout, d.lddout = dout.p, dout.ld
+    d.dqkv, d.lddqkv = dqkv.p, dqkv.ld
+    call("osm_attn_flash_bwd", C.byref(d), out.p, out.ld, ptr(lse), ptr(delta), _s(),
+         keep=(d, qkv.t, out.t, dout.t, dqkv.t, lse, delta))
+
+
 def splitk_hint(M, N, K, taps, nbatch=1) -> int:
     return query("osm_splitk_hint", M, N, K, taps, nbatch)
+
+
+def conv_splitk(B, H, W, Cin, Cout, ksize, wfmt, has_gn_table=False) -> int:
+    return query("osm_conv_splitk", B, H, W, Cin, Cout, ksize, wfmt, int(bool(has_gn_table)))
 
 
 def gn_nchunk(HW: int) -> int:

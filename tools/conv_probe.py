@@ -29,12 +29,13 @@ def main():
         B, H, W, Cin, Cout, k = (int(v) for v in s.split(","))
         M = B * H * W
         g = torch.Generator(device=dev).manual_seed(0)
-        x = torch.randn(M, Cin, device=dev, generator=g)
+        adt = torch.float16 if a.mode == "f16" else torch.float32
+        x = torch.randn(M, Cin, device=dev, generator=g).to(adt)
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, device=dev, generator=g)
-        y = torch.empty(M, Cout, device=dev)
+        y = torch.empty(M, Cout, device=dev, dtype=adt)
         wf, _ = ops.pack_conv_weight(w, wfmt=wfmt)
-        sk = ops.splitk_hint(M, Cout, Cin, k * k, 1)
+        sk = ops.conv_splitk(B, H, W, Cin, Cout, k, wfmt)
         ws = torch.empty(sk * M * Cout, device=dev) if sk > 1 else None
         run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt)  # noqa: E731
         for _ in range(3):
@@ -50,8 +51,8 @@ def main():
         fl = 2.0 * M * Cin * Cout * k * k
         msg = f"{a.mode:7s} {s:28s} splitk={sk:2d}  {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s"
         if a.check:
-            ref = torch.nn.functional.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
-            err = float((y.view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
+            ref = torch.nn.functional.conv2d(x.float().view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
+            err = float((y.float().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
             msg += f"  relerr {err:.2e}"
         print(msg, flush=True)
 
