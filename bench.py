@@ -130,6 +130,8 @@ def roofline(model, args):
     eng = model.engine(B, S, S)
 
     def select(name, a):
+        if name.endswith("_h"):          # fp16-storage family: same operations
+            name = name[:-2]
         if name == "osm_conv2d_nhwc":
             d = a[0]._obj
             fl = 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * d.ksize * d.ksize
@@ -152,6 +154,13 @@ def roofline(model, args):
             shape = ("osm_gemm", d.M, d.N, d.K, d.nb1 * d.nb2, int(d.b_kn))
             per_shape.setdefault(shape, [0.0, 0, fl])
             return ("attn_gemm", fl, shape)
+        if name in ("osm_attn_flash_fwd", "osm_attn_flash_bwd", "osm_attn_small_fwd", "osm_attn_small_bwd"):
+            d = a[0]._obj
+            # algorithmic flops of the core: forward 2 GEMMs (QK^T, PV), backward 5 (S, dP, dq, dk, dv) of 2 T^2 ch each
+            fl = 2.0 * d.B * d.heads * d.T * d.T * d.ch * (2 if name.endswith("fwd") else 5)
+            shape = (name, d.B, d.T, d.heads, d.ch)
+            per_shape.setdefault(shape, [0.0, 0, fl])
+            return ("attention_core", fl, shape)
         if name in ("osm_softmax_rows", "osm_softmax_rows_bwd"):
             i0 = 3 if name == "osm_softmax_rows" else 4
             shape = (name, int(a[i0]), int(a[i0 + 1]))
@@ -222,6 +231,17 @@ def roofline(model, args):
                 "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one v_mfma_f32_32x32x16_f16 "
                 "per product; peak = dense fp16 MFMA peak 2500 TFLOP/s"),
     }[args.conv_mode]
+    att = {k: out[k] for k in ("attention_core", "attn_gemm", "softmax") if k in out}
+    if att:
+        ams = sum(v["ms_per_step"] for v in att.values())
+        agf = sum(v["gflop_per_step"] for v in att.values())
+        peak_att = BF16_MFMA_PEAK_TFLOPS / 6.0
+        out["_attention"] = {
+            "what": "attention cores (QK^T, softmax, PV and their gradients; T = 64 / 256 / 1024, 64-wide heads)",
+            "ms_per_step": round(ams, 3), "achieved_tflops": round(agf / max(ams, 1e-9), 2),
+            "peak_tflops": round(peak_att, 1), "mfma_util": round(agf / max(ams, 1e-9) / peak_att, 4),
+            "note": "algorithmic flops / HIP-event time of the launches / (dense bf16 MFMA peak / 6: bf16x6 arithmetic); "
+                    "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound"}
     return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
@@ -350,6 +370,10 @@ def main():
     if rank == 0:
         rl, breakdown = roofline(model, args)
         line["roofline"] = rl
+        att = breakdown.pop("_attention", None)
+        if att:
+            line["attention"] = att
+            line["attention_mfma_util"] = att["mfma_util"]
         line["kernel_breakdown_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in breakdown.items()}
         line["achieved_tflops_whole_step"] = round(
             sum(v["gflop_per_step"] for v in breakdown.values()) / (1e3 * dt / args.steps), 2)

@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    # the CPU oracle (torch / oneDNN) is several times SLOWER with one thread per hardware thread on the 256-thread GPU
+    # hosts than with ~16 (bench.py's thread sweep): cap the default for every test
+    import os
+
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))

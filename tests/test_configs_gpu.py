@@ -197,7 +197,7 @@ def test_full_size_guided_step_vs_oracle(full_model):
             record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
             sample_pattern=cfg["sample_pattern"], index_range=(idx, idx), noise_fn=lambda k, shape: nd[k], trace=trace)
         # ---- oracle: the body of the reference loop for this idx (oracle/diffusion_ref.py::p_sample_loop)
-        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))   # oneDNN is fastest at ~16 threads on the 256-thread hosts (bench sweep)
         tb = D.make_tables(1000, "linear", 1000)
         rop = D.PhysOperator(name, batch_size=1, depth_type=opc["depth_type"], value=opc["value"], phi_a=opc["phi_a"],
                              phi_b=opc["phi_b"], phi_inf=opc["phi_inf"])

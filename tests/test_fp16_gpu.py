@@ -5,8 +5,10 @@ The reference's own fp16 mode does not run as shipped (nobody call
 for it is the fp32 reference path plus a STATED tolerance:
   * op level: the kernels must equal an fp64 evaluation of the SAME half-rounded operands up to the final rounding
     of the result to half (2^-11 relative) and fp32 accumulation noise -- i.e. the arithmetic itself is exact-class;
-  * model level: UNet output / input-gradient within 2e-2 of the tensor's max-abs of the fp32 oracle;
-  * sampler level: 10 guided steps within 3e-2 max-abs of the fp32 trace on x_{t-1} / pred_xstart
+  * model level: UNet output / input-gradient within 1e-2 of the tensor's max-abs of the fp32 oracle
+    (measured on MI355X: 2.2e-3 / 5.5e-3);
+  * sampler level: 10 guided steps within 5e-3 max-abs of the fp32 reference trace on x_t / pred_xstart (measured
+    ~1e-3); 3 full-size steps of config 5 within 2e-3 of the fp32 run (measured 1.7e-4)
 (half has 11 significand bits: ~5e-4 per stored tensor, ~60 stored tensors deep)."""
 import contextlib
 import io
@@ -199,7 +201,7 @@ def test_tiny_unet_fp16_vs_fp32_oracle():
     (dx,) = torch.autograd.grad((y * w.to(DEV)).sum(), xd)
     ey, ed = relerr(y.detach().cpu(), yr.detach()), relerr(dx.cpu(), dxr)
     print(f"tiny UNet fp16 vs fp32 oracle: forward {ey:.2e}  input-gradient {ed:.2e} (relative to max-abs)")
-    assert ey < 2e-2 and ed < 2e-2
+    assert ey < 1e-2 and ed < 1e-2
     eng = next(iter(m16._engines.values()))
     assert eng.adt == torch.float16
     m16.convert_to_fp32()
@@ -237,7 +239,7 @@ def test_guided_loop_fp16_vs_reference_trace():
     e_fin = float((img.cpu() - torch.from_numpy(gold["final_img"])).abs().max())
     print(f"fp16 guided loop vs fp32 reference trace: x_t {e_in:.2e}  pred_xstart {e_x0:.2e}  final x_0 {e_fin:.2e}  "
           f"final loss {float(loss[0]):.4f} vs {float(gold['final_loss'][0]):.4f}")
-    assert e_in < 3e-2 and e_x0 < 3e-2 and e_fin < 3e-2
+    assert e_in < 5e-3 and e_x0 < 5e-3 and e_fin < 5e-3
     assert abs(float(loss[0]) - float(gold["final_loss"][0])) < 2e-2 * abs(float(gold["final_loss"][0]))
 
 
@@ -271,4 +273,4 @@ def test_config5_haze_batch32_fp16_full_size():
     e_img, e_x0 = float((img[0] - r_img[0]).abs().max()), float((x0[0] - r_x0[0]).abs().max())
     print(f"config 5 fp16 (B=32) vs fp32 (B=1), image 0 after 3 steps: x_(t-1) {e_img:.2e}  pred_xstart {e_x0:.2e}  "
           f"loss {loss[0]:.4f} vs {r_loss[0]:.4f}")
-    assert e_img < 3e-2 and e_x0 < 3e-2
+    assert e_img < 2e-3 and e_x0 < 2e-3

@@ -86,7 +86,7 @@ def test_full_size_unet_256_vs_oracle(create_model):
     x = 0.7 * torch.randn(1, 4, 256, 256, generator=g)
     t = torch.tensor([37.0])
     w = torch.randn(1, 8, 256, 256, generator=g)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))   # oneDNN is fastest at ~16 threads on the 256-thread hosts (bench sweep)
     xr = x.clone().requires_grad_(True)
     yr = U.unet_forward(sd, cfg, xr, t)
     (dxr,) = torch.autograd.grad((yr * w).sum(), xr)
