@@ -61,6 +61,17 @@ typedef struct osm_conv_desc {
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
                           osm_gn_prep; NULL = plain convolution */
   int gn_silu;           /* act = SiLU when != 0 */
+  /* optional side output: per-column sums of the result, so that the GroupNorm that reads (or back-propagates
+   * through) it needs no reduction pass of its own.  colsum: [B][chunks][2][Cout] floats, chunks =
+   * osm_conv_stat_chunks(...) (0 = this layer's kernel cannot emit them).  stat_mode 1: (sum y, sum y^2);
+   * stat_mode 2: y is d/d(act(xh g + b)), xh = (x - mean) rstd with x = stat_x [B*H*W][ld_sx] and the per-channel
+   * rows mean | rstd | g | b in stat_table [B][4][Cout] (the table of osm_gn_prep / osm_gn_finalize_cols): sums of
+   * dxh = y act'(z) g and dxh xh -- the two reductions of the GroupNorm backward.  Feed to osm_gn_finalize_cols. */
+  float* colsum;
+  int stat_mode, stat_silu;
+  const float* stat_x;
+  long long ld_sx;
+  const float* stat_table;
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
 
@@ -100,6 +111,8 @@ int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
  * splitk*B*H*W*Cout floats): layers with few pixel rows (<= 256: the 8x8 / 16x16 levels at batch 1) run a
  * weight-streaming kernel that splits K over the 4 waves of a workgroup first, so they need fewer partials. */
 int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int has_gn_table);
+/* chunks per image of osm_conv_desc.colsum for a layer run with `splitk` (0: no column sums from that layer) */
+int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int splitk, int has_gn_table);
 
 /* ------------------------------------------------------------------ fused attention core (low resolutions)
  * QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467) for T in {64, 256} tokens and
@@ -155,6 +168,17 @@ int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, in
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
                 const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
                 void* stream);
+/* Statistics from column sums emitted by the producing convolution (osm_conv_desc.colsum, [B][nchunk][2][C]):
+ * mode 0: stats[B][G][2] = (mean, rstd) of the tensor (+ the per-channel table [B][4][C] when table != NULL, as
+ * osm_gn_prep);  mode 1: stats = (sum dxh / n, sum dxh xh / n), the two means of the GroupNorm backward (gstats). */
+int osm_gn_finalize_cols(const float* colsum, int nchunk, int B, int HW, int C, int G, float eps, int mode,
+                         float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm,
+                         float* table, void* stream);
+/* the apply pass of osm_gn_bwd alone, with gstats given (osm_gn_finalize_cols mode 1) */
+int osm_gn_bwd_apply(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
+                     const float* addend, long long ldadd, int B, int HW, int C, int G,
+                     const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
+                     long long ldfilm, int silu, void* stream);
 /* dx = dGN(dy) (+ addend).  part: workspace as above. */
 int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                const float* addend, long long ldadd, int B, int HW, int C, int G,
@@ -268,6 +292,11 @@ typedef struct osm_conv_desc_h {
   int wfmt;             /* 1 */
   const float* gn_table;
   int gn_silu;
+  float* colsum;
+  int stat_mode, stat_silu;
+  const osm_half_t* stat_x;
+  long long ld_sx;
+  const float* stat_table;
 } osm_conv_desc_h;
 int osm_conv2d_nhwc_h(const osm_conv_desc_h* d, void* stream);
 int osm_gn_stats_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps,
@@ -285,6 +314,10 @@ int osm_gn_bwd_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long 
                  const osm_half_t* addend, long long ldadd, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,
                  long long ldfilm, int silu, float* part, float* gstats, void* stream);
+int osm_gn_bwd_apply_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
+                       const osm_half_t* addend, long long ldadd, int B, int HW, int C, int G,
+                       const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
+                       long long ldfilm, int silu, void* stream);
 int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,

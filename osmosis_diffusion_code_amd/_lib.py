@@ -31,7 +31,9 @@ class ConvDesc(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("ksize", C.c_int), ("splitk", C.c_int), ("accumulate", C.c_int),
                 ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong), ("wfmt", C.c_int),
-                ("gn_table", C.c_void_p), ("gn_silu", C.c_int)]
+                ("gn_table", C.c_void_p), ("gn_silu", C.c_int),
+                ("colsum", C.c_void_p), ("stat_mode", C.c_int), ("stat_silu", C.c_int), ("stat_x", C.c_void_p),
+                ("ld_sx", C.c_longlong), ("stat_table", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -72,6 +74,9 @@ _SIGS = {
     "osm_pack_conv_weight_bf16s": [_P, _P, _P, _I, _I, _I, _I, _P],
     "osm_splitk_hint": [_I, _I, _I, _I, _I],
     "osm_conv_splitk": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "osm_conv_stat_chunks": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "osm_gn_finalize_cols": [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _LL, _P, _P],
+    "osm_gn_bwd_apply": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _P, _LL, _I, _P],
     "osm_attn_small_supported": [_I, _I],
     "osm_attn_flash_supported": [_I, _I],
     "osm_attn_flash_fwd": [C.POINTER(AttnDesc), _P, _P],
@@ -105,7 +110,7 @@ _SIGS = {
     "osm_version": [],
 }
 # fp16-storage family (activations as IEEE half, `_h` suffix): same argument lists
-for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_pool2x2",
+for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_gn_bwd_apply", "osm_pool2x2",
            "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
     _SIGS[_n + "_h"] = _SIGS[_n]
 _SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]

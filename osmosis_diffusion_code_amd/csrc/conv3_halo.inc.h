@@ -29,13 +29,15 @@ template <int PW> struct HaloGeom {
   static constexpr int PLANE = ROWS * S_ROWB;       // bytes per plane
   static constexpr int RB = PW / 4;                 // MFMA row blocks (32 rows each)
 };
-constexpr int B_RING = 3;                        // weight-fragment register sets (divides the 18 steps of a slab)
-constexpr int B_DIST = 2;                        // steps between a weight fragment's load and its use
+// BR = weight-fragment register sets (a divisor of the 18 steps of a slab); a fragment is loaded BR - 1 steps before
+// its use.  3 on the MFMA-bound layers; deeper rings (6 / 9) keep more of the weight stream in flight for the
+// weight-bandwidth-bound low-resolution layers (few rows per weight byte: the loads, not the MFMAs, set the pace).
 
-template <int NP, bool GNF, int PW = 16>
+template <int NP, bool GNF, int PW = 16, int BR = 3>
 __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
+  constexpr int B_RING = BR, B_DIST = BR - 1;
   using GEO = HaloGeom<PW>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
                 RB = GEO::RB;
@@ -232,6 +234,17 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
   act_t* __restrict__ cp = p.C + pix0 * ldc + n;
   const act_t* __restrict__ rp = (p.res && !partial) ? p.res + pix0 * p.ldr + n : nullptr;
   const long long crow = (long long)p.W * ldc, rrow = (long long)p.W * p.ldr;
+  // optional column sums of the final values (IGemmParams::colsum); the split-K case is served by the combine kernel
+  const bool stats = p.colsum != nullptr && !partial;
+  float s1 = 0.f, s2 = 0.f;
+  StatCol scol = {};
+  const act_t* __restrict__ sxp = nullptr;
+  const long long srow = (long long)p.W * p.ld_sx;
+  if (stats && p.stat_mode == 2) {
+    const float* tb = p.stat_table + (long long)img * 4 * p.N + n;
+    scol = StatCol{tb[0], tb[p.N], tb[2 * p.N], tb[3 * p.N]};
+    sxp = p.stat_x + pix0 * p.ld_sx + n;
+  }
 #pragma unroll
   for (int tm = 0; tm < RB; ++tm) {
 #pragma unroll
@@ -248,7 +261,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
         if (rp) v += osm::ld1(rp + dy * rrow + dx * p.ldr);
         if (p.accumulate) v += osm::ld1(c);
         osm::st1(c, v);
+        if (stats)
+          stat_add(p.stat_mode, p.stat_silu, scol, (float)(act_t)v,
+                   p.stat_mode == 2 ? osm::ld1(sxp + dy * srow + dx * p.ld_sx) : 0.f, s1, s2);
       }
+    }
+  }
+  if (stats) {   // fold the two half-waves (same column, other rows); one (sum, sum) pair per column and patch
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lk == 0) {
+      float* o = p.colsum + ((long long)img * p.stat_chunks + (ty * tpx + tx)) * 2 * p.N + n;
+      o[0] = s1;
+      o[p.N] = s2;
     }
   }
 }

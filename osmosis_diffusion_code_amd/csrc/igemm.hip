@@ -57,7 +57,33 @@ struct IGemmParams {
   int nbatch;
   const float* gn_table;   // halo kernel: fused GroupNorm(+FiLM)(+SiLU) of the input, [B][4][K]
   int gn_silu;
+  // optional per-column sums of the OUTPUT tensor, written by the epilogue that holds the final values (halo kernel, or
+  // the split-K reduce): colsum[image][chunk][2][N].  stat_mode 1: (sum y, sum y^2) -> the statistics of the GroupNorm
+  // that reads y next;  2: y is the gradient w.r.t. a GroupNorm output act(xh g + b), xh = (x - mean) rstd, and the sums
+  // are (sum dxh, sum dxh xh), dxh = y act'(z) g -> the two reductions of that GroupNorm's backward (x = stat_x).
+  float* colsum;
+  int stat_mode, stat_silu, stat_chunks;
+  const act_t* stat_x;
+  long long ld_sx;
+  const float* stat_table;   // mode 2: [B][4][N] mean | rstd | g | b (the table the forward convolution applied)
 };
+
+// the contribution of one final output element v (already rounded to the storage type) to the two column sums
+struct StatCol {
+  float mean, rstd, g, b;
+};
+__device__ __forceinline__ void stat_add(int mode, int silu, const StatCol& c, float v, float xv, float& s1, float& s2) {
+  if (mode == 1) {
+    s1 += v;
+    s2 += v * v;
+  } else {
+    const float xh = (xv - c.mean) * c.rstd;
+    const float z = xh * c.g + c.b;
+    const float dxh = v * (silu ? osm::dsilu_f(z) : 1.0f) * c.g;
+    s1 += dxh;
+    s2 += dxh * xh;
+  }
+}
 
 
 #ifndef OSM_ACT_F16
@@ -285,6 +311,41 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const float* __restri
 
 #endif   // !OSM_ACT_F16
 
+// Deep splits of small outputs (the 8x8 / 16x16 layers: 16-32 partials of <= 1 MB each): one thread per float4 would leave
+// 64-256 workgroups each walking 32 dependent-latency loads.  Here a workgroup owns 64 float4 and its four waves take the
+// partials k = w, w + 4, ...; the four sums are folded through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(IGemmParams p) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const long long slice = (long long)p.M * p.N;
+  const long long i = (long long)blockIdx.x * 64 + lane;       // float4 index
+  const bool live = i < slice / 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* w = p.ws + i * 4;
+#pragma unroll 4
+    for (int k = kg; k < p.splitk; k += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(w + k * slice);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+  }
+  red[kg][lane] = s;
+  __syncthreads();
+  if (kg != 0 || !live) return;
+  const float4 a = red[0][lane], b = red[1][lane], c2 = red[2][lane], d = red[3][lane];
+  float v[4] = {(a.x + b.x) + (c2.x + d.x), (a.y + b.y) + (c2.y + d.y), (a.z + b.z) + (c2.z + d.z), (a.w + b.w) + (c2.w + d.w)};
+  const int nv = p.N / 4;
+  const int n = (int)(i % nv) * 4;
+  const long long m = i / nv;
+  act_t* c = p.C + m * p.ldc + n;
+  const float4 r4 = p.res ? osm::ld4(p.res + m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 c4 = p.accumulate ? osm::ld4(c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f)) + rv[e] + cv[e];
+  osm::st4(c, make_float4(v[0], v[1], v[2], v[3]));
+}
+
 // C = alpha * sum_s ws[s] + bias + res (+ C)      (fixed summation order: deterministic)
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
@@ -330,6 +391,61 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
   }
 }
 
+// The same combine for 3x3 / 1x1 convolutions that also want the column sums of their result (IGemmParams::colsum):
+// a workgroup owns 8 rows x 128 columns (thread = 4 columns of one row), folds its 8 rows through LDS in a fixed order
+// and writes chunk (= 8-row block) partials colsum[m / 8][2][N].  Needs N % 4 == 0 and 16-byte aligned rows.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IGemmParams p) {
+  __shared__ float red[8][2][128];
+  const int t = threadIdx.x, cg = t & 31, r = t >> 5;
+  const int n = blockIdx.y * 128 + cg * 4;
+  const long long m = (long long)blockIdx.x * 8 + r;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.N && m < p.M) {
+    const long long slice = (long long)p.M * p.N;
+    const float* w = p.ws + m * p.N + n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.splitk; ++k) {
+      const float4 q = *reinterpret_cast<const float4*>(w + k * slice);
+      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+    }
+    act_t* c = p.C + m * p.ldc + n;
+    const float4 r4 = p.res ? osm::ld4(p.res + m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 c4 = p.accumulate ? osm::ld4(c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f)) + rv[e] + cv[e];
+    osm::st4(c, make_float4(v[0], v[1], v[2], v[3]));
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    StatCol sc[4] = {};
+    if (p.stat_mode == 2) {
+      const float4 x4 = osm::ld4(p.stat_x + m * p.ld_sx + n);
+      xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+      const float* tb = p.stat_table + (m / ((long long)p.H * p.W)) * 4 * p.N + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = StatCol{tb[e], tb[p.N + e], tb[2 * p.N + e], tb[3 * p.N + e]};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stat_add(p.stat_mode, p.stat_silu, sc[e], (float)(act_t)v[e], xv[e], s1[e], s2[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[r][0][cg * 4 + e] = s1[e];
+    red[r][1][cg * 4 + e] = s2[e];
+  }
+  __syncthreads();
+  if (t < 128 && blockIdx.y * 128 + t < p.N) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a1 += red[q][0][t];
+      a2 += red[q][1][t];
+    }
+    float* o = p.colsum + (long long)blockIdx.x * 2 * p.N + blockIdx.y * 128 + t;
+    o[0] = a1;
+    o[p.N] = a2;
+  }
+}
+
 #ifndef OSM_ACT_F16
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                    float* __restrict__ wd, int Cout, int Cin, int k) {
@@ -353,12 +469,15 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 #include "skinny.inc.h"
 
 // ---- small-M path (skinny.inc.h): eligibility and its split of K
-// OSM_SKINNY_MAXM: largest M (pixel rows) served by the small-M kernel (default 256: the 8x8 and 16x16 levels at
-// batch 1); 0 switches it off (A/B measurements).
+// OSM_SKINNY_MAXM: largest M (pixel rows) served by the small-M kernel.  Default 0 = OFF: measured on MI355X (round 2,
+// profiles/r02_small_m_ab.txt) it LOSES to the tiled kernels on every 3x3 layer (8x8 1024->1024: 30 vs 24 us; 16x16:
+// 64 vs 38 us) and ties on 8x8 1x1 layers: every wave gathers its own A fragments (32-byte pieces of 32 different
+// pixel rows per load instruction, ~32 cache lines each), which saturates the CU's vector-memory path long before the
+// weight stream saturates HBM; the tiled kernels stage A once per workgroup through LDS with full-line loads.
 int skinny_max_m() {
   static const int v = [] {
     const char* e = std::getenv("OSM_SKINNY_MAXM");
-    return e ? atoi(e) : 256;
+    return e ? atoi(e) : 0;
   }();
   return v;
 }
@@ -400,6 +519,10 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 #else
   if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
 #endif
+  const bool halo_path = wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled();
+  if (p.colsum && (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) || wfmt == 0 || !(halo_path || p.splitk > 1)))
+    return osm::fail(OSM_ERR_UNSUPPORTED, "column sums are produced by the halo-tile kernel or the split-K combine only "
+                                          "(ask osm_conv_stat_chunks first)");
   if (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) && p.nbatch == 1) {
     // small-M kernel: weight streaming, K split over the 4 waves of a workgroup (and over grid.y = p.splitk)
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
@@ -426,13 +549,20 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
     p.mtiles = nimg * ((p.H + 7) / 8) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+    p.stat_chunks = p.mtiles / nimg;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
     if (wfmt < 1 || wfmt > 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
-#define OSM_HALO_LAUNCH(NP_, GN_, PW_) \
-    hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_>), g2, dim3(256), 0, st, p.A, Bp, p)
-#define OSM_HALO_PICK(NP_)                                                                                \
-    if (wide) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16); else OSM_HALO_LAUNCH(NP_, false, 16); } \
-    else      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8);  else OSM_HALO_LAUNCH(NP_, false, 8); }
+    // deeper weight-fragment rings where the weight stream sets the pace (few pixel rows per weight byte)
+    static const int ring16 = [] { const char* e = std::getenv("OSM_BRING16"); return e ? atoi(e) : 3; }();
+    static const int ring8 = [] { const char* e = std::getenv("OSM_BRING8"); return e ? atoi(e) : 3; }();
+    const bool deep16 = ring16 == 6 && p.M <= 4096, deep8 = ring8 == 9;
+#define OSM_HALO_LAUNCH(NP_, GN_, PW_, BR_) \
+    hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_, BR_>), g2, dim3(256), 0, st, p.A, Bp, p)
+#define OSM_HALO_PICK(NP_)                                                                                  \
+    if (wide && deep16) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 6); else OSM_HALO_LAUNCH(NP_, false, 16, 6); } \
+    else if (wide)      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 3); else OSM_HALO_LAUNCH(NP_, false, 16, 3); } \
+    else if (deep8)     { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 9);  else OSM_HALO_LAUNCH(NP_, false, 8, 9); }  \
+    else                { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 3);  else OSM_HALO_LAUNCH(NP_, false, 8, 3); }
 #ifdef OSM_ACT_F16
     OSM_HALO_PICK(1)
 #else
@@ -477,12 +607,23 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 #endif
   int rc = osm::check_launch("igemm kernel");
   if (rc) return rc;
+  if (p.splitk > 1 && p.colsum) {
+    if (!(p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && osm::aligned_act4(p.C) && osm::aligned16(p.ws) &&
+          (!p.res || osm::aligned_act4(p.res)) && p.M % 8 == 0 && (p.H * p.W) % 8 == 0 && p.nbatch == 1))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "column sums with split-K need N %% 4 == 0, 8-row aligned images, aligned rows");
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(p.M / 8, (p.N + 127) / 128), dim3(256), 0, st, p);
+    return osm::check_launch("splitk_reduce_stats_kernel");
+  }
   if (p.splitk > 1) {
     const bool v4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && osm::aligned_act4(p.C) &&
                     osm::aligned16(p.ws) && (!p.res || osm::aligned_act4(p.res)) && p.sC1 % 4 == 0 && p.sC2 % 4 == 0;
     const long long total = (long long)p.nbatch * p.M * p.N / (v4 ? 4 : 1);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    if (v4 && p.nbatch == 1 && p.splitk >= 8 && total <= 64 * 1024) {
+      hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, p);
+      return osm::check_launch("splitk_reduce_deep_kernel");
+    }
     if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     rc = osm::check_launch("splitk_reduce_kernel");
@@ -515,6 +656,15 @@ extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize
   if (skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return skinny_gridy(M, Cout, Cin, ksize * ksize);
   return osm_splitk_hint(M, Cout, Cin, ksize * ksize, 1);
 }
+// chunks per image of the column sums a layer can emit (osm_conv_desc.colsum), 0 = that layer's kernel cannot
+extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int splitk,
+                                    int has_gn_table) {
+  const int M = B * H * W;
+  if (wfmt == 0 || skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return 0;
+  if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
+  if (ksize == 3 && W >= 8 && H >= 8 && halo_enabled()) return ((H + 7) / 8) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
+  return 0;
+}
 #endif   // !OSM_ACT_F16
 
 #ifdef OSM_ACT_F16
@@ -544,6 +694,13 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
     OSM_REQUIRE(osm::aligned16(d->gn_table), "osm_conv2d_nhwc: gn_table must be 16-byte aligned");
     p.gn_table = d->gn_table;
     p.gn_silu = d->gn_silu;
+  }
+  if (d->colsum) {
+    OSM_REQUIRE(d->stat_mode == 1 || d->stat_mode == 2, "osm_conv2d_nhwc: stat_mode must be 1 or 2 with colsum");
+    OSM_REQUIRE(d->stat_mode == 1 || (d->stat_x && d->stat_table && d->ld_sx >= d->Cout && d->ld_sx % 4 == 0),
+                "osm_conv2d_nhwc: stat_mode 2 needs stat_x (ld >= Cout, multiple of 4) and stat_table");
+    p.colsum = d->colsum; p.stat_mode = d->stat_mode; p.stat_silu = d->stat_silu;
+    p.stat_x = OSM_CACT(d->stat_x); p.ld_sx = d->ld_sx; p.stat_table = d->stat_table;
   }
   if (d->wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
     OSM_REQUIRE(d->wfmt >= 1 && d->wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");

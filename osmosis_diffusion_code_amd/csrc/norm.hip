@@ -218,6 +218,59 @@ __global__ __launch_bounds__(256) void gn_finalize_table_kernel(const float* __r
   }
 }
 
+// Statistics from the column sums a convolution wrote next to its output ([B][nchunk][2][C], igemm.hip): one wave per
+// (image, group) adds nchunk x (C / G) x 2 values in fp64.  MODE 0: (mean, rstd) (+ table);  MODE 1: (s1 / n, s2 / n).
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ cs, float* __restrict__ out,
+                                                                float* __restrict__ table, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ film,
+                                                                long long ldf, int B, int G, int C, int nchunk, double n,
+                                                                float eps) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B * G) return;
+  const int b = i / G, g = i % G;
+  const int gs = C / G;
+  const float* base = cs + (long long)b * nchunk * 2 * C + g * gs;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < nchunk * gs; k += 64) {
+    const int ch = k / gs, e = k - ch * gs;
+    s1 += (double)base[(long long)ch * 2 * C + e];
+    s2 += (double)base[(long long)ch * 2 * C + C + e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (MODE == 1) {
+    if (lane == 0) {
+      out[i * 2] = (float)(s1 / n);
+      out[i * 2 + 1] = (float)(s2 / n);
+    }
+    return;
+  }
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (lane == 0) {
+    out[i * 2] = mean;
+    out[i * 2 + 1] = rstd;
+  }
+  if (!table) return;
+  float* t = table + (long long)b * 4 * C;
+  for (int e = lane; e < gs; e += 64) {
+    const int c = g * gs + e;
+    const float sc = film ? film[(long long)b * ldf + c] : 0.f;
+    const float sh = film ? film[(long long)b * ldf + C + c] : 0.f;
+    t[c] = mean;
+    t[C + c] = rstd;
+    t[2 * C + c] = gamma[c] * (1.0f + sc);
+    t[3 * C + c] = beta[c] * (1.0f + sc) + sh;
+  }
+}
+
 // MODE 0: y = act(GN(x)).   MODE 1: dx = dGN(dy) (+ addend)
 // Same (chunk, image) grid and (column-vector, row) thread mapping as the reduce pass: a thread owns
 // fixed channel vector(s), so gamma/beta/FiLM/statistics are loaded once and the row loop is pure
@@ -592,6 +645,44 @@ extern "C" int OSM_FN(osm_gn_apply)(const abi_act_t* x, long long ldx, abi_act_t
   int rc = check_common(a, "osm_gn_apply");
   if (rc) return rc;
   return run_apply<0>(a, (hipStream_t)stream);
+}
+
+#ifndef OSM_ACT_F16
+extern "C" int osm_gn_finalize_cols(const float* colsum, int nchunk, int B, int HW, int C, int G, float eps, int mode,
+                                    float* stats, const float* gamma, const float* beta, const float* film,
+                                    long long ldfilm, float* table, void* stream) {
+  OSM_REQUIRE(colsum && stats && nchunk > 0 && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0,
+              "osm_gn_finalize_cols: bad argument");
+  OSM_REQUIRE(mode == 0 || mode == 1, "osm_gn_finalize_cols: mode must be 0 or 1");
+  OSM_REQUIRE(!table || (mode == 0 && gamma && beta), "osm_gn_finalize_cols: the table needs mode 0, gamma and beta");
+  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_finalize_cols: ldfilm smaller than 2*C");
+  const int n = B * G;
+  const double cnt = (double)HW * (C / G);
+  if (mode == 0)
+    hipLaunchKernelGGL((gn_finalize_cols_kernel<0>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, colsum, stats,
+                       table, gamma, beta, film, ldfilm, B, G, C, nchunk, cnt, eps);
+  else
+    hipLaunchKernelGGL((gn_finalize_cols_kernel<1>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, colsum, stats,
+                       (float*)nullptr, gamma, beta, film, ldfilm, B, G, C, nchunk, cnt, eps);
+  return osm::check_launch("gn_finalize_cols_kernel");
+}
+#endif
+
+extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy,
+                                        abi_act_t* dx, long long lddx, const abi_act_t* addend, long long ldadd, int B,
+                                        int HW, int C, int G, const float* stats, const float* gstats, const float* gamma,
+                                        const float* beta, const float* film, long long ldfilm, int silu, void* stream) {
+  OSM_REQUIRE(x && dy && dx && stats && gstats && gamma && beta, "osm_gn_bwd_apply: null pointer");
+  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd_apply: ldfilm smaller than 2*C");
+  GNArgs a{};
+  a.x = OSM_CACT(x); a.ldx = ldx;
+  a.dy = OSM_CACT(dy); a.lddy = lddy; a.out = OSM_ACT(dx); a.ldo = lddx; a.addend = OSM_CACT(addend); a.ldadd = ldadd;
+  a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
+  a.film = film; a.ldf = ldfilm; a.silu = silu;
+  int rc = check_common(a, "osm_gn_bwd_apply");
+  if (rc) return rc;
+  a.fuse = 0;
+  return run_apply<1>(a, (hipStream_t)stream);
 }
 
 extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy, abi_act_t* dx,

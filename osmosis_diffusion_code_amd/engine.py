@@ -232,6 +232,8 @@ class UNetEngine:
         self._fwd_graph = self._bwd_graph = None
         # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
         self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
+        # GroupNorm reductions (forward statistics, backward sums) as column sums from the epilogue of the producing conv
+        self.fuse_stats = self.fuse_gn and os.environ.get("OSM_FUSE_STATS", "1") != "0"
 
         w = weights
         self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
@@ -272,7 +274,11 @@ class UNetEngine:
         return t[:n]
 
     def _conv(self, x: Mat, cv: _Conv, y: Mat, hw: Tuple[int, int], dgrad=False, res: Optional[Mat] = None,
-              accumulate=False, gn_table=None, gn_silu=True):
+              accumulate=False, gn_table=None, gn_silu=True, stat=None):
+        """stat: None, ("fwd",) -- also emit the per-column (sum, sum of squares) of y for the GroupNorm that reads it --
+        or ("bwd", x_gn, table) -- y is the gradient w.r.t. SiLU(GN(x_gn)): emit that GroupNorm's two backward
+        reductions.  Returns (colsum, chunks per image) when the layer's kernel produced them, else None (the caller
+        then runs the GroupNorm's own reduction pass)."""
         H, W = hw
         M = self.B * H * W
         cin = cv.cout if dgrad else cv.cin
@@ -282,23 +288,47 @@ class UNetEngine:
         ws = None
         if sk > 1:
             ws = self._scr_flat("splitk", sk * M * cout)
+        cs, nch, skw = None, 0, {}
+        if stat is not None and self.fuse_stats:
+            nch = ops.conv_stat_chunks(self.B, H, W, cin, cout, cv.k, cv.wfmt, sk, gn_table is not None)
+            if nch > 0:
+                cs = self._scr_flat("colsum", self.B * nch * 2 * cout)      # consumed by the finalize that follows
+                skw = dict(colsum=cs, stat_mode=1)
+                if stat[0] == "bwd":
+                    skw = dict(colsum=cs, stat_mode=2, stat_x=stat[1], stat_table=stat[2], stat_silu=True)
         ops.conv2d(x, cv.wd if dgrad else cv.wf, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
-                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt, gn_table=gn_table, gn_silu=gn_silu)
+                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt, gn_table=gn_table, gn_silu=gn_silu,
+                   **skw)
+        return (cs, nch) if cs is not None else None
 
-    def _gn_conv(self, x: Mat, norm: _Norm, st, cv: _Conv, y: Mat, hw, film=None, res: Optional[Mat] = None):
+    def _gn_fusable(self, cv: _Conv, hw) -> bool:
+        """GroupNorm apply inside the consuming 3x3 convolution: needs the halo-tile kernel (split-bf16 / fp16 weights,
+        W >= 16, H >= 8) on a tensor that is not better served by the one-launch low-resolution GroupNorm."""
+        H, W = hw
+        return self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256
+
+    def _gn_conv(self, x: Mat, norm: _Norm, st, cv: _Conv, y: Mat, hw, film=None, res: Optional[Mat] = None,
+                 cs=None, table=None, stat=None):
         """y = conv3x3(SiLU(GN(+FiLM)(x))) (+res).  Where the halo-tile kernel runs (split-bf16 weights, W >= 16,
         H >= 8) the normalised tensor is never materialised: statistics -> per-channel table -> applied by the
-        convolution while it stages its input; otherwise GN writes a scratch tensor first."""
+        convolution while it stages its input; otherwise GN writes a scratch tensor first.
+        cs: (colsum, chunks) the convolution that produced x wrote next to it (then no reduction pass over x is
+        needed); table: persistent [B][4][C] buffer for the per-channel table (kept for the backward); stat: forwarded
+        to the convolution (column sums of y).  Returns the convolution's (colsum, chunks) or None."""
         B = self.B
         H, W = hw
-        if self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256:
-            table = self._scr_flat("gnt", B * 4 * x.cols)
-            ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
-            self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True)
-        else:
-            a = self._scr("a", B * H * W, x.cols)
-            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
-            self._conv(a, cv, y, hw, res=res)
+        if self._gn_fusable(cv, hw):
+            if table is None:
+                table = self._scr_flat("gnt", B * 4 * x.cols)
+            if cs is not None:
+                ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0, gamma=norm.g, beta=norm.b, film=film,
+                                     table=table)
+            else:
+                ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
+            return self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True, stat=stat)
+        a = self._scr("a", B * H * W, x.cols)
+        ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
+        return self._conv(a, cv, y, hw, res=res, stat=stat)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):
@@ -324,13 +354,19 @@ class UNetEngine:
                 ops.pool2x2(x, xs, B, H, W, 0.25)
             Mo = B * ho * wo
             h1 = self._buf(Mo, blk.cout)
-            self._conv(a1r, blk.c1, h1, (ho, wo))
+            fuse2 = self._gn_fusable(blk.c2, (ho, wo))
+            tab1 = None
+            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if fuse2 else None)
         else:
             ho, wo = H, W
             xs = x
             Mo = M
             h1 = self._buf(Mo, blk.cout)
-            self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw)
+            fuse2 = self._gn_fusable(blk.c2, (ho, wo))
+            # the per-channel GroupNorm tables are kept: the data-gradient convolutions fold the GroupNorm-backward
+            # reductions into their epilogues with them (see _res_bwd)
+            tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats and self._gn_fusable(blk.c1, hw)) else None
+            cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1, stat=("fwd",) if fuse2 else None)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         if blk.skip is not None:
@@ -338,8 +374,9 @@ class UNetEngine:
             res = dst
         else:
             res = xs
-        self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res)
-        self._saved[id(blk)] = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo))
+        tab2 = self._small(B * 4 * blk.cout) if (self.fuse_stats and fuse2) else None
+        self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res, cs=cs1, table=tab2)
+        self._saved[id(blk)] = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo), tab1=tab1, tab2=tab2)
         return (ho, wo)
 
     def _res_bwd(self, blk: _Res, dy: Mat, dx_dst: Mat, accumulate: bool):
@@ -349,13 +386,23 @@ class UNetEngine:
         ho, wo = s["hwo"]
         M, Mo = B * H * W, B * ho * wo
         dh2 = self._scr("a", Mo, blk.cout)
-        self._conv(dy, blk.c2, dh2, (ho, wo), dgrad=True)
+        # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
+        # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
+        # holds dy in registers and reads x once); what remains is a tiny finalize and the apply pass.
+        cs = self._conv(dy, blk.c2, dh2, (ho, wo), dgrad=True,
+                        stat=("bwd", s["h1"], s["tab2"]) if s["tab2"] is not None else None)
         dh1 = self._scr("b", Mo, blk.cout)
         gst = self._small(B * G * 2)
-        ops.gn_bwd(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], blk.n2.g, blk.n2.b, self.gn_part, gst,
-                   film=s["film"], silu=True)
+        if cs is not None:
+            ops.gn_finalize_cols(cs[0], cs[1], B, ho * wo, blk.cout, G, gst, mode=1)
+            ops.gn_bwd_apply(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], gst, blk.n2.g, blk.n2.b, film=s["film"],
+                             silu=True)
+        else:
+            ops.gn_bwd(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], blk.n2.g, blk.n2.b, self.gn_part, gst,
+                       film=s["film"], silu=True)
         da1r = self._scr("a", Mo, blk.cin)
-        self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True)
+        cs1 = self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True,
+                         stat=("bwd", s["x"], s["tab1"]) if s["tab1"] is not None else None)
         if blk.up:      # forward: nearest 2x upsample  -> backward: 2x2 sum
             da1 = self._scr("b", M, blk.cin)
             ops.pool2x2(da1r, da1, B, ho, wo, 1.0)
@@ -387,8 +434,12 @@ class UNetEngine:
             else:
                 add = dy
         gst1 = self._small(B * G * 2)
-        ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
-                   silu=True, addend=add)
+        if cs1 is not None:
+            ops.gn_finalize_cols(cs1[0], cs1[1], B, H * W, blk.cin, G, gst1, mode=1)
+            ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add)
+        else:
+            ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
+                       silu=True, addend=add)
 
     # ------------------------------------------------------------------ Attention
     def _gemm(self, *a, **kw):

@@ -58,7 +58,11 @@ def _same_family(*ts):
 def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat, B: int, H: int, W: int,
            ksize: int, res: Optional[Mat] = None, accumulate: bool = False,
            splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0,
-           gn_table: Optional[torch.Tensor] = None, gn_silu: bool = True):
+           gn_table: Optional[torch.Tensor] = None, gn_silu: bool = True,
+           colsum: Optional[torch.Tensor] = None, stat_mode: int = 0, stat_x: Optional[Mat] = None,
+           stat_table: Optional[torch.Tensor] = None, stat_silu: bool = True):
+    """colsum (+ stat_*): optional per-column sums of the result for the GroupNorm that follows (stat_mode 1) or whose
+    backward consumes the result (stat_mode 2: stat_x = that GroupNorm's input, stat_table = its per-channel table)."""
     d = ConvDesc()
     d.x, d.w, d.bias = x.p, ptr(w_packed), ptr(bias)
     d.res = res.p if res is not None else None
@@ -69,11 +73,15 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.ldx, d.ldy, d.ldr = x.ld, y.ld, (res.ld if res is not None else 0)
     d.wfmt = wfmt
     d.gn_table, d.gn_silu = ptr(gn_table), int(gn_silu)
-    fam = _same_family(x.t, y.t, res.t if res is not None else None)
+    d.colsum, d.stat_mode, d.stat_silu = ptr(colsum), int(stat_mode), int(stat_silu)
+    d.stat_x, d.ld_sx = (stat_x.p, stat_x.ld) if stat_x is not None else (None, 0)
+    d.stat_table = ptr(stat_table)
+    fam = _same_family(x.t, y.t, res.t if res is not None else None, stat_x.t if stat_x is not None else None)
     if (fam == "_h") != (wfmt == 1):
         raise _lib.OsmosisHipError("fp16 activations go with the fp16 weight image (wfmt 1), fp32 with 0 / 2 / 3")
     call("osm_conv2d_nhwc" + fam, C.byref(d), _s(),
-         keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table))
+         keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table, colsum,
+               stat_x.t if stat_x is not None else None, stat_table))
 
 
 # conv arithmetic modes: weight-image format code of the C ABI
@@ -175,6 +183,29 @@ def splitk_hint(M, N, K, taps, nbatch=1) -> int:
 
 def conv_splitk(B, H, W, Cin, Cout, ksize, wfmt, has_gn_table=False) -> int:
     return query("osm_conv_splitk", B, H, W, Cin, Cout, ksize, wfmt, int(bool(has_gn_table)))
+
+
+def conv_stat_chunks(B, H, W, Cin, Cout, ksize, wfmt, splitk, has_gn_table=False) -> int:
+    """Chunks per image of the column sums conv2d(colsum=...) writes for this layer; 0 = its kernel cannot."""
+    return query("osm_conv_stat_chunks", B, H, W, Cin, Cout, ksize, wfmt, splitk, int(bool(has_gn_table)))
+
+
+def gn_finalize_cols(colsum, nchunk, B, HW, C, G, stats, mode=0, gamma=None, beta=None, film=None, table=None,
+                     eps: float = 1e-5):
+    """GroupNorm statistics (mode 0: mean, rstd [+ the per-channel table]; mode 1: the two backward means) from the
+    column sums a convolution wrote next to its output."""
+    fp, ldf = _film(film)
+    call("osm_gn_finalize_cols", ptr(colsum), nchunk, B, HW, C, G, eps, mode, ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
+         ptr(table), _s(), keep=(colsum, stats, gamma, beta, film, table))
+
+
+def gn_bwd_apply(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gstats, gamma, beta, film=None, silu=True,
+                 addend: Optional[Mat] = None):
+    fp, ldf = _film(film)
+    call("osm_gn_bwd_apply" + _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None), x.p, x.ld,
+         dy.p, dy.ld, dx.p, dx.ld, addend.p if addend is not None else None, addend.ld if addend is not None else 0,
+         B, HW, x.cols, G, ptr(stats), ptr(gstats), ptr(gamma), ptr(beta), fp, ldf, int(silu), _s(),
+         keep=(x.t, dy.t, dx.t, addend.t if addend else None, stats, gstats, gamma, beta, film))
 
 
 def gn_nchunk(HW: int) -> int:

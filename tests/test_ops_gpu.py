@@ -387,6 +387,71 @@ def test_conv_split_bf16_modes(ops, mode, tol, B, Cin, Cout, H, W, k, splitk):
     assert e < tol, (mode, "dgrad", e)
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,splitk", [(2, 64, 96, 16, 24, 1), (1, 128, 64, 32, 32, 4), (1, 96, 128, 9, 17, 1),
+                                                   (2, 64, 64, 8, 8, 2)])
+def test_conv_column_sums_feed_group_norm(ops, mode, B, Cin, Cout, H, W, splitk):
+    """The side output of a convolution (osm_conv_desc.colsum) replaces the reduction passes of the GroupNorm around it:
+    stat_mode 1 -> mean / rstd / per-channel table of GN(y) via osm_gn_finalize_cols; stat_mode 2 -> the two backward
+    means of a GroupNorm whose output-gradient the convolution produces, checked against osm_gn_bwd's own reduction
+    (and dx through osm_gn_bwd_apply against osm_gn_bwd).  Halo-tile epilogue (splitk 1) and split-K combine."""
+    half = mode == "f16"
+    adt = torch.float16 if half else torch.float32
+    wfmt = ops.WFMT[mode]
+    G, HW = 32, H * W
+    g = torch.Generator().manual_seed(Cin + Cout + H + splitk)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), wfmt=wfmt)
+    nch = ops.conv_stat_chunks(B, H, W, Cin, Cout, 3, wfmt, splitk)
+    assert nch > 0
+    xm = ops.Mat.of(to_nhwc(x).to(adt))
+    y = torch.empty(B * HW, Cout, device=DEV, dtype=adt)
+    cs = torch.full((B * nch * 2 * Cout,), float("nan"), device=DEV)
+    ws = torch.empty(splitk * B * HW * Cout, device=DEV) if splitk > 1 else None
+    ops.conv2d(xm, wf, bias.to(DEV), ops.Mat.of(y), B, H, W, 3, splitk=splitk, splitk_ws=ws, wfmt=wfmt, colsum=cs,
+               stat_mode=1)
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    film = 0.2 * torch.randn(B, 2 * Cout, generator=g)
+    st = torch.empty(B * G * 2, device=DEV)
+    table = torch.empty(B * 4 * Cout, device=DEV)
+    ops.gn_finalize_cols(cs, nch, B, HW, Cout, G, st, mode=0, gamma=gamma.to(DEV), beta=beta.to(DEV), film=film.to(DEV),
+                         table=table)
+    yc = y.float().cpu().reshape(B, HW, G, Cout // G).permute(0, 2, 1, 3).reshape(B, G, -1).double()
+    mean, var = yc.mean(-1), yc.var(-1, unbiased=False)
+    stc = st.cpu().reshape(B, G, 2)
+    assert torch.allclose(stc[..., 0], mean.float(), atol=2e-6)
+    assert torch.allclose(stc[..., 1], (1 / torch.sqrt(var + 1e-5)).float(), rtol=2e-6)
+    part = torch.empty(B * ops.gn_nchunk(HW) * G * 2, device=DEV)
+    st_ref, table_ref = torch.empty_like(st), torch.empty_like(table)
+    ops.gn_prep(ops.Mat.of(y), B, HW, G, part, st_ref, gamma.to(DEV), beta.to(DEV), table_ref, film=film.to(DEV))
+    assert torch.allclose(table, table_ref, rtol=3e-6, atol=3e-6)
+
+    # ---- backward sums: the convolution output is d/d(SiLU(FiLM(GN(xg)))) of a GroupNorm over the conv's OUTPUT channels
+    xg = (torch.randn(B, Cout, H, W, generator=g) * 1.3 + 0.2)
+    xgm = ops.Mat.of(to_nhwc(xg).to(adt))
+    st2, tab2 = torch.empty_like(st), torch.empty_like(table)
+    ops.gn_prep(xgm, B, HW, G, part, st2, gamma.to(DEV), beta.to(DEV), tab2, film=film.to(DEV))
+    cs2 = torch.full_like(cs, float("nan"))
+    dy = torch.empty(B * HW, Cout, device=DEV, dtype=adt)
+    ops.conv2d(xm, wf, None, ops.Mat.of(dy), B, H, W, 3, splitk=splitk, splitk_ws=ws, wfmt=wfmt, colsum=cs2, stat_mode=2,
+               stat_x=xgm, stat_table=tab2, stat_silu=True)
+    gst = torch.empty(B * G * 2, device=DEV)
+    ops.gn_finalize_cols(cs2, nch, B, HW, Cout, G, gst, mode=1)
+    gst_ref = torch.empty_like(gst)
+    dx_ref = torch.empty(B * HW, Cout, device=DEV, dtype=adt)
+    add = ops.Mat.of(to_nhwc(torch.randn(B, Cout, H, W, generator=g)).to(adt))
+    ops.gn_bwd(xgm, ops.Mat.of(dy), ops.Mat.of(dx_ref), B, HW, G, st2, gamma.to(DEV), beta.to(DEV), part, gst_ref,
+               film=film.to(DEV), silu=True, addend=add)
+    scale = float(gst_ref.abs().max())
+    assert float((gst - gst_ref).abs().max()) < 1e-5 * scale + 1e-8, (gst - gst_ref).abs().max()
+    dx = torch.empty_like(dx_ref)
+    ops.gn_bwd_apply(xgm, ops.Mat.of(dy), ops.Mat.of(dx), B, HW, G, st2, gst, gamma.to(DEV), beta.to(DEV),
+                     film=film.to(DEV), silu=True, addend=add)
+    assert relerr(dx.float().cpu(), dx_ref.float().cpu()) < (2e-3 if half else 1e-5)
+
+
 @pytest.mark.parametrize("film,B,C,Cout,H,W", [(True, 2, 64, 96, 16, 24), (False, 1, 96, 32, 9, 17), (True, 1, 256, 128, 32, 32)])
 def test_conv_with_fused_group_norm_input(ops, film, B, C, Cout, H, W):
     """conv3x3(SiLU(GN(+FiLM)(x))) with the normalisation applied inside the convolution's staging
