@@ -166,10 +166,16 @@ def roofline(model, args):
             shape = (name, int(a[i0]), int(a[i0 + 1]))
             per_shape.setdefault(shape, [0.0, 0, 4.0 * shape[1] * shape[2] * shape[2] * (3 if i0 == 3 else 4)])
             return ("softmax", 0.0, shape)
+        if name == "osm_gn_finalize_cols":
+            shape = (name, int(a[2]), int(a[1]), int(a[4]))        # B, chunks, C
+            per_shape.setdefault(shape, [0.0, 0, 8.0 * shape[1] * shape[2] * shape[3]])
+            return ("groupnorm", 0.0, shape)
         if name.startswith("osm_gn"):
-            i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 8, "osm_gn_fwd": 4, "osm_gn_prep": 2}[name]
+            i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 8, "osm_gn_bwd_apply": 8, "osm_gn_fwd": 4,
+                  "osm_gn_prep": 2}[name]
             shape = (name, int(a[i0]), int(a[i0 + 1]), int(a[i0 + 2]))
-            passes = {"osm_gn_stats": 1, "osm_gn_apply": 2, "osm_gn_fwd": 3, "osm_gn_prep": 1, "osm_gn_bwd": 5 if a[6] else 4}[name]
+            passes = {"osm_gn_stats": 1, "osm_gn_apply": 2, "osm_gn_fwd": 3, "osm_gn_prep": 1,
+                      "osm_gn_bwd": 5 if a[6] else 4, "osm_gn_bwd_apply": 4 if a[6] else 3}[name]
             per_shape.setdefault(shape, [0.0, 0, 4.0 * shape[1] * shape[2] * shape[3] * passes])
             return ("groupnorm", 0.0, shape)
         return ("other", 0.0, None)

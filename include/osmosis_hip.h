@@ -136,7 +136,7 @@ typedef struct osm_attn_desc {
   long long lddqkv;
   float* ws;
 } osm_attn_desc;
-/* Flash-style core on the matrix cores for T a multiple of 256 (the 16x16 / 32x32 blocks) and 64-wide heads:
+/* Flash-style core on the matrix cores for 64-wide heads and T = 64 or a multiple of 128 (the 8x8 / 16x16 / 32x32 blocks):
  * logits / probabilities stay in registers, fp32 operands are split into 3 bf16 planes (6 MFMAs per product, fp32-class),
  * softmax in fp32.  Forward writes `out` and lse[B*heads][T] (max + log-sum of the scaled logits of each query row);
  * backward takes that lse and the forward output (for delta = rowsum(d(out) * out), scratch `delta` [B*heads][T]),
@@ -176,12 +176,13 @@ int osm_gn_finalize_cols(const float* colsum, int nchunk, int B, int HW, int C, 
                          float* table, void* stream);
 /* the apply pass of osm_gn_bwd alone, with gstats given (osm_gn_finalize_cols mode 1) */
 int osm_gn_bwd_apply(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
-                     const float* addend, long long ldadd, int B, int HW, int C, int G,
+                     const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                      const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
                      long long ldfilm, int silu, void* stream);
-/* dx = dGN(dy) (+ addend).  part: workspace as above. */
+/* dx = dGN(dy) (+ addend) (+ addend2).  part: workspace as above.  An addend may alias dx (in-place accumulation: the
+ * residual / concat gradients of the UNet are added here instead of in a pass of their own). */
 int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
-               const float* addend, long long ldadd, int B, int HW, int C, int G,
+               const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                const float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, float* part, float* gstats, void* stream);
 
@@ -311,11 +312,11 @@ int osm_gn_prep_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int 
                   const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
                   void* stream);
 int osm_gn_bwd_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
-                 const osm_half_t* addend, long long ldadd, int B, int HW, int C, int G,
+                 const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,
                  long long ldfilm, int silu, float* part, float* gstats, void* stream);
 int osm_gn_bwd_apply_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
-                       const osm_half_t* addend, long long ldadd, int B, int HW, int C, int G,
+                       const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                        const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
                        long long ldfilm, int silu, void* stream);
 int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,

@@ -20,25 +20,29 @@
 
 // PW = patch width: 16 (8 x 16 patch = 128 GEMM rows, 4 MFMA row blocks) for W >= 16, or 8 (8 x 8 patch = 64 rows,
 // 2 row blocks: the 8x8 layers, where an 8 x 16 patch would be mostly halo).
-template <int PW> struct HaloGeom {
+// PH = patch height: 8, or 16 with PW = 16 (a 16 x 16 patch = 256 GEMM rows per wave, 8 row blocks: every weight fragment
+// then feeds 48 instead of 24 MFMAs -- the weight-fragment loads are what the CU's vector-memory path spends half its time
+// on at 8 x 16 -- at the price of one workgroup per CU: 88 KB of LDS, accumulators in AGPRs).
+template <int PW, int PH = 8> struct HaloGeom {
   static constexpr int HW = PW + 2;                 // staged pixels per halo row
   static constexpr int HP = PW == 16 ? 20 : 10;     // LDS pitch of a halo row, in pixels
-  static constexpr int PIX = 10 * HW;               // staged pixels
+  static constexpr int PIX = (PH + 2) * HW;         // staged pixels
   static constexpr int NJ = (PIX * 8 + 255) / 256;  // float4 staging loads per thread and slab
-  static constexpr int ROWS = 10 * HP + 8;          // LDS pixel rows (+ a dump row for unused staging slots)
+  static constexpr int ROWS = (PH + 2) * HP + 8;    // LDS pixel rows (+ a dump row for unused staging slots)
   static constexpr int PLANE = ROWS * S_ROWB;       // bytes per plane
-  static constexpr int RB = PW / 4;                 // MFMA row blocks (32 rows each)
+  static constexpr int RB = PW * PH / 32;           // MFMA row blocks (32 rows each)
 };
 // BR = weight-fragment register sets (a divisor of the 18 steps of a slab); a fragment is loaded BR - 1 steps before
 // its use.  3 on the MFMA-bound layers; deeper rings (6 / 9) keep more of the weight stream in flight for the
 // weight-bandwidth-bound low-resolution layers (few rows per weight byte: the loads, not the MFMAs, set the pace).
 
-template <int NP, bool GNF, int PW = 16, int BR = 3>
-__global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
+template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8>
+__global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
   constexpr int B_RING = BR, B_DIST = BR - 1;
-  using GEO = HaloGeom<PW>;
+  static_assert(PH == 8 || (PH == 16 && PW == 16), "patches are 8 x 8, 8 x 16 or 16 x 16");
+  using GEO = HaloGeom<PW, PH>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
                 RB = GEO::RB;
   __shared__ __attribute__((aligned(16))) unsigned char As[NP * H_PLANE];
@@ -53,9 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
   const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
-  const int tpx = (p.W + PW - 1) / PW, tpy = (p.H + 7) >> 3;
+  const int tpx = (p.W + PW - 1) / PW, tpy = (p.H + PH - 1) / PH;
   const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
-  const int x0 = tx * PW, y0 = ty * 8, n0 = tile_n * BN;
+  const int x0 = tx * PW, y0 = ty * PH, n0 = tile_n * BN;
 
   const int ks = blockIdx.y;
   const int nslab = (p.K + BK - 1) / BK;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
   for (int j = 0; j < NJ; ++j) {
     const int hp = (tid >> 3) + 32 * j;
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-    woff[j] = (unsigned)((hp < HALO_PIX ? hy * HALO_P + hx : 10 * HALO_P) * S_ROWB + 8 * cg);
+    woff[j] = (unsigned)((hp < HALO_PIX ? hy * HALO_P + hx : (PH + 2) * HALO_P) * S_ROWB + 8 * cg);
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < HALO_PIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
     const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
@@ -102,10 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  // lane row lr of row block i: PW = 16 -> patch pixel (i + 4 (lr >> 4), lr & 15);  PW = 8 -> (4 i + (lr >> 3), lr & 7)
+  // lane row lr of row block i: PW = 16 -> patch pixel (i + PH/2 (lr >> 4), lr & 15);  PW = 8 -> (4 i + (lr >> 3), lr & 7)
   const int lr = lane & 31, lk = lane >> 5;
   const unsigned char* a_rd =
-      As + (PW == 16 ? (lr >> 4) * (4 * HALO_P) + (lr & 15) : (lr >> 3) * HALO_P + (lr & 7)) * S_ROWB + 16 * lk;
+      As + (PW == 16 ? (lr >> 4) * ((PH / 2) * HALO_P) + (lr & 15) : (lr >> 3) * HALO_P + (lr & 7)) * S_ROWB + 16 * lk;
   constexpr int RB_STRIDE = (PW == 16 ? HALO_P : 4 * HALO_P) * S_ROWB;   // bytes between row blocks
 
   float4 ra[NJ];
@@ -183,8 +187,37 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
       OSM_H_LOAD_A(cn);                      // next slab's halo: in flight during the MFMA stream
       __syncthreads();
       uint4 fx[2][NP], fy[2][NP];
-      OSM_H_READ(fx, 0)
-      if constexpr (PW == 16) {
+      if constexpr (PH == 16) {
+        // 256-row patch: four pairs of row blocks per (tap, k16) step; fx serves pairs 0 and 2, fy pairs 1 and 3
+#define OSM_T_READ(f_, s_, pr_)                                                             \
+        {                                                                                   \
+          const int t_ = (s_) >> 1, kk_ = (s_) & 1;                                         \
+          const int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;              \
+          _Pragma("unroll") for (int t = 0; t < 2; ++t)                                     \
+            _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                               \
+              f_[t][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE +             \
+                                                          (2 * (pr_) + t) * RB_STRIDE + off_); \
+        }
+        OSM_T_READ(fx, 0, 0)
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+          OSM_H_LOAD_B((s + B_DIST) % B_RING, (s + B_DIST < 18 ? c : cn), (s + B_DIST) % 18);
+          OSM_T_READ(fy, s, 1)
+          OSM_H_MMA(fx, s % B_RING, 0)
+          __builtin_amdgcn_sched_barrier(0);
+          OSM_T_READ(fx, s, 2)
+          OSM_H_MMA(fy, s % B_RING, 1)
+          __builtin_amdgcn_sched_barrier(0);
+          OSM_T_READ(fy, s, 3)
+          OSM_H_MMA(fx, s % B_RING, 2)
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < 18) OSM_T_READ(fx, s + 1, 0)
+          OSM_H_MMA(fy, s % B_RING, 3)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#undef OSM_T_READ
+      } else if constexpr (PW == 16) {
+        OSM_H_READ(fx, 0)
 #define OSM_H_STEP(s_)                                                                     \
         OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
         OSM_H_READ(fy, 2 * (s_) + 1)                                                       \
@@ -198,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
         OSM_H_STEP(12) OSM_H_STEP(13) OSM_H_STEP(14) OSM_H_STEP(15) OSM_H_STEP(16) OSM_H_STEP(17)
 #undef OSM_H_STEP
       } else {
+        OSM_H_READ(fx, 0)
         // 64-row patch: one pair of row blocks per step; fx serves the even steps, fy the odd ones
 #define OSM_H_STEP2(s_)                                                                    \
         OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
@@ -226,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
   const int n = n0 + 32 * wave + lr;
   if (n >= p.N) return;
   const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
-  // element e of row block tm is patch pixel  PW = 16: (tm + 4 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
+  // element e of row block tm is patch pixel  PW = 16: (tm + PH/2 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
   //                                            PW = 8 : (4 tm + (e >> 2), (e & 3) + 4 lk)
   const int xl = x0 + 4 * lk;
   const long long pix0 = (long long)img * p.H * p.W + (long long)y0 * p.W + xl;
@@ -249,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16s_kernel(const act_t* _
   for (int tm = 0; tm < RB; ++tm) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int dy = PW == 16 ? tm + 4 * (e >> 3) : 4 * tm + (e >> 2);
+      const int dy = PW == 16 ? tm + (PH / 2) * (e >> 3) : 4 * tm + (e >> 2);
       const int dx = PW == 16 ? (e & 3) + 8 * ((e >> 2) & 1) : (e & 3);
       if (y0 + dy >= p.H || xl + dx >= p.W) continue;
       float v = acc[tm][e];

@@ -1,5 +1,5 @@
-// Flash-style attention core on the matrix cores for the 16x16 and 32x32 AttentionBlocks (T = 256, 1024 tokens,
-// 64-wide heads).  Reference: QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467):
+// Flash-style attention core on the matrix cores for the AttentionBlocks with 64-wide heads (T = 64, 256, 1024 tokens:
+// the 8x8, 16x16 and 32x32 levels).  Reference: QKVAttentionLegacy.forward / QKVAttention.forward (unet.py:416-433, 459-467):
 //     w = softmax(einsum(q * s, k * s)) (in fp32, :431),  a = einsum(w, v),  s = ch^-1/4
 // and its autograd (the reference checkpoints the block, unet.py:376 / nn.py:142-170: P is recomputed in backward;
 // so is it here, from the saved log-sum-exp).
@@ -42,6 +42,7 @@ struct FlashArgs {
   float* dqkv;           // [B*T][lddqkv], same column layout as qkv
   long long lddqkv;
   int B, T, heads;
+  int nw;                // waves that split the other sequence axis: min(4, T / 32)
   float scale;
 };
 
@@ -78,7 +79,9 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// grid (T / 32, heads, B).  Wave w: keys [w T/4, (w+1) T/4), 64 at a time.
+// grid (T / 32, heads, B).  NW = min(4, T / 32) waves split the keys: wave w < NW takes keys [w T/NW, (w+1) T/NW),
+// 32 NSUB at a time (NSUB = 2 independent 32-key logit tiles where the range allows: two MFMA accumulator chains).
+template <int NSUB>
 __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
   __shared__ float os[4][DH][33];
   __shared__ float ms[4][32];
@@ -97,36 +100,41 @@ __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
 
   f32x16 o0 = zero16(), o1 = zero16();   // O^T: rows d (0..31 | 32..63), column = query
   float m = -INFINITY, l = 0.f;
-  const int kw = a.T >> 2;
-  for (int kb = wave * kw; kb < (wave + 1) * kw; kb += 64) {
-    f32x16 s0 = zero16(), s1 = zero16();   // S^T of keys kb .. kb+31 | kb+32 .. kb+63
+  const int kw = a.T / a.nw;
+  const int kend = wave < a.nw ? (wave + 1) * kw : 0;
+  for (int kb = wave * kw; kb < kend; kb += 32 * NSUB) {
+    f32x16 sa[NSUB];   // S^T of keys kb + 32 u .. + 31
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) sa[u] = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      uint4 k0[NP], k1[NP];
-      frag_row(K, ld, rb + kb + lr, 0, s, h, 1.f, k0);
-      frag_row(K, ld, rb + kb + 32 + lr, 0, s, h, 1.f, k1);
+      uint4 kf[NSUB][NP];
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) frag_row(K, ld, rb + kb + 32 * u + lr, 0, s, h, 1.f, kf[u]);
 #pragma unroll
       for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
-        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
-          s0 = mma16<NP>(k0[pa], qf[s][pb], s0);
-          s1 = mma16<NP>(k1[pa], qf[s][pb], s1);
-        }
-    }
-    // online softmax of this lane's query over its 32 keys (the other 32 sit in lane ^ 32)
-    float mx = s0[0];
+        for (int pb = NP - 1 - pa; pb >= 0; --pb)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+          for (int u = 0; u < NSUB; ++u) sa[u] = mma16<NP>(kf[u][pa], qf[s][pb], sa[u]);
+    }
+    // online softmax of this lane's query over its 16 NSUB keys (the other 16 NSUB sit in lane ^ 32)
+    float mx = sa[0][0];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[u][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
     const float alpha = __expf(m - mn);
     float ps = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      s0[e] = __expf(s0[e] - mn);
-      s1[e] = __expf(s1[e] - mn);
-      ps += s0[e] + s1[e];
-    }
+    for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        sa[u][e] = __expf(sa[u][e] - mn);
+        ps += sa[u][e];
+      }
     l = l * alpha + ps;
     m = mn;
 #pragma unroll
@@ -136,9 +144,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
     }
     // O^T += V^T P^T : A = V^T (rows d, key slots), B = P^T straight from the S^T registers
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2 * NSUB; ++t) {
       uint4 pf[NP], v0[NP], v1[NP];
-      frag_acc(t < 2 ? s0 : s1, t & 1, pf);
+      frag_acc(sa[t >> 1], t & 1, pf);
       frag_gather(V, ld, rb + kb + 32 * (t >> 1), lr, t & 1, h, v0);
       frag_gather(V, ld, rb + kb + 32 * (t >> 1), 32 + lr, t & 1, h, v1);
 #pragma unroll
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
         }
     }
   }
-  // ---- combine the four key ranges.  O^T C layout: column = query lr, row d = 32 mb + (e&3) + 8 (e>>2) + 4 h
+  // ---- combine the key ranges.  O^T C layout: column = query lr, row d = 32 mb + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
     float L = 0.f, o = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float sc = __expf(ms[w][q] - M);
+      const float sc = __expf(ms[w][q] - M);     // idle waves: exp(-inf) = 0
       L += (ls[w][q] + ls[w][q + 32]) * sc;
       o += os[w][d][q] * sc;
     }
@@ -213,8 +221,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_q_kernel(FlashArgs a) {
     frag_row(dO, a.lddout, rb + q0 + lr, 0, s, h, 1.f, gf[s]);
   }
   f32x16 g0 = zero16(), g1 = zero16();   // dq^T rows d (0..31 | 32..63), column = query
-  const int kw = a.T >> 2;
-  for (int kb = wave * kw; kb < (wave + 1) * kw; kb += 32) {
+  const int kw = a.T / a.nw;
+  const int kend = wave < a.nw ? (wave + 1) * kw : 0;
+  for (int kb = wave * kw; kb < kend; kb += 32) {
     f32x16 st = zero16(), dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -285,8 +294,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs a) {
     frag_row(V, ld, rb + k0r + lr, 0, s, h, 1.f, vf[s]);
   }
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
-  const int qw = a.T >> 2;
-  for (int qb = wave * qw; qb < (wave + 1) * qw; qb += 32) {
+  const int qw = a.T / a.nw;
+  const int qend = wave < a.nw ? (wave + 1) * qw : 0;
+  for (int qb = wave * qw; qb < qend; qb += 32) {
     f32x16 sc = zero16(), dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -355,10 +365,12 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs a) {
   }
 }
 
+int nw_of(int T) { return T >= 128 ? 4 : (T >= 64 ? 2 : 1); }
+
 int check(const osm_attn_desc* d, const char* who) {
   OSM_REQUIRE(d && d->qkv, "%s: null pointer", who);
-  OSM_REQUIRE(d->ch == DH && d->T >= 256 && d->T % 256 == 0, "%s: needs 64-wide heads and T a multiple of 256 (got ch %d, T %d)",
-              who, d->ch, d->T);
+  OSM_REQUIRE(d->ch == DH && d->T >= 64 && d->T % (32 * nw_of(d->T)) == 0,
+              "%s: needs 64-wide heads and T a multiple of 64 (of 128 from T = 128) (got ch %d, T %d)", who, d->ch, d->T);
   OSM_REQUIRE(d->B > 0 && d->heads > 0, "%s: bad shape", who);
   OSM_REQUIRE(d->ldqkv % 4 == 0 && d->q_off % 4 == 0 && d->k_off % 4 == 0 && d->v_off % 4 == 0 && d->head_stride % 4 == 0 &&
               osm::aligned16(d->qkv), "%s: qkv columns must be 16-byte aligned", who);
@@ -370,12 +382,13 @@ FlashArgs to_args(const osm_attn_desc* d) {
   a.qkv = d->qkv; a.ldqkv = d->ldqkv; a.q_off = d->q_off; a.k_off = d->k_off; a.v_off = d->v_off; a.hs = d->head_stride;
   a.out = d->out; a.ldout = d->ldout; a.dout = d->dout; a.lddout = d->lddout; a.dqkv = d->dqkv; a.lddqkv = d->lddqkv;
   a.B = d->B; a.T = d->T; a.heads = d->heads; a.scale = d->scale;
+  a.nw = nw_of(d->T);
   return a;
 }
 
 }  // namespace
 
-extern "C" int osm_attn_flash_supported(int T, int ch) { return ch == DH && T >= 256 && T % 256 == 0; }
+extern "C" int osm_attn_flash_supported(int T, int ch) { return ch == DH && T >= 64 && T % (32 * nw_of(T)) == 0; }
 
 extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stream) {
   int rc = check(d, "osm_attn_flash_fwd");
@@ -383,7 +396,11 @@ extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stre
   OSM_REQUIRE(d->out && lse, "osm_attn_flash_fwd: null pointer");
   FlashArgs a = to_args(d);
   a.lse = lse;
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3(d->T / 32, d->heads, d->B), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 g(d->T / 32, d->heads, d->B);
+  if ((d->T / a.nw) % 64 == 0)
+    hipLaunchKernelGGL(flash_fwd_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(flash_fwd_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, a);
   return osm::check_launch("flash_fwd_kernel");
 }
 

@@ -481,6 +481,17 @@ int skinny_max_m() {
   }();
   return v;
 }
+// OSM_TALL_MINM: from this many pixel rows on, 3x3 layers with W, H >= 16 use 16 x 16 patches (256 GEMM rows per wave)
+// instead of 8 x 16; 0 = never.
+int tall_min_m() {
+  static const int v = [] {
+    const char* e = std::getenv("OSM_TALL_MINM");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+bool tall_ok(int M, int H, int W) { return tall_min_m() > 0 && M >= tall_min_m() && H >= 16 && W >= 16; }
+
 bool skinny_ok(int M, int K, int wfmt, bool gn_table) {
   return wfmt != 0 && !gn_table && K % 32 == 0 && M <= skinny_max_m();
 }
@@ -545,8 +556,9 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
     // halo-tile kernel: M-tiles are 8 x 16 (W >= 16) or 8 x 8 pixel patches, K is consumed in 32-channel slabs of all 9 taps
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const bool wide = p.W >= 16;
+    const bool tall = tall_ok(p.M, p.H, p.W);
     const int nimg = p.M / (p.H * p.W);
-    p.mtiles = nimg * ((p.H + 7) / 8) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
+    p.mtiles = nimg * ((p.H + (tall ? 15 : 7)) / (tall ? 16 : 8)) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     p.stat_chunks = p.mtiles / nimg;
@@ -559,7 +571,9 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 #define OSM_HALO_LAUNCH(NP_, GN_, PW_, BR_) \
     hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_, BR_>), g2, dim3(256), 0, st, p.A, Bp, p)
 #define OSM_HALO_PICK(NP_)                                                                                  \
-    if (wide && deep16) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 6); else OSM_HALO_LAUNCH(NP_, false, 16, 6); } \
+    if (tall) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); \
+                else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, false, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); }       \
+    else if (wide && deep16) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 6); else OSM_HALO_LAUNCH(NP_, false, 16, 6); } \
     else if (wide)      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 3); else OSM_HALO_LAUNCH(NP_, false, 16, 3); } \
     else if (deep8)     { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 9);  else OSM_HALO_LAUNCH(NP_, false, 8, 9); }  \
     else                { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 3);  else OSM_HALO_LAUNCH(NP_, false, 8, 3); }
@@ -661,8 +675,13 @@ extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int 
                                     int has_gn_table) {
   const int M = B * H * W;
   if (wfmt == 0 || skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return 0;
+  const bool halo = ksize == 3 && W >= 8 && H >= 8 && halo_enabled();
+  // the split launch() will really use: it is clamped to the number of K chunks (32-channel slabs of the halo kernel /
+  // 32-channel chunks per tap of the tap-chunked kernel)
+  const int nchunks = (halo ? 1 : ksize * ksize) * ((Cin + BK - 1) / BK);
+  if (splitk > nchunks) splitk = nchunks;
   if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
-  if (ksize == 3 && W >= 8 && H >= 8 && halo_enabled()) return ((H + 7) / 8) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
+  if (halo) return ((H + (tall_ok(M, H, W) ? 15 : 7)) / (tall_ok(M, H, W) ? 16 : 8)) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
   return 0;
 }
 #endif   // !OSM_ACT_F16

@@ -30,12 +30,13 @@ struct GNArgs {
   const float* beta;
   const float* film;    // [B][2C] or null
   const act_t* addend;
+  const act_t* addend2;   // second optional addend of the backward apply (out = dGN(dy) + addend + addend2)
   act_t* out;
   float* part;
   float* fin;           // finalized statistics written by the one-launch kernel / the fused apply prologue
   double n;             // elements per group
   int fuse;             // apply kernels: combine the chunk partials in the prologue (no finalize launch)
-  long long ldx, lddy, ldo, ldadd, ldf;
+  long long ldx, lddy, ldo, ldadd, ldadd2, ldf;
   int B, HW, C, G, gs, nchunk, ppc, silu;
   float eps;
 };
@@ -218,49 +219,64 @@ __global__ __launch_bounds__(256) void gn_finalize_table_kernel(const float* __r
   }
 }
 
-// Statistics from the column sums a convolution wrote next to its output ([B][nchunk][2][C], igemm.hip): one wave per
-// (image, group) adds nchunk x (C / G) x 2 values in fp64.  MODE 0: (mean, rstd) (+ table);  MODE 1: (s1 / n, s2 / n).
+// Statistics from the column sums a convolution wrote next to its output ([B][nchunk][2][C], igemm.hip): one WORKGROUP
+// per (image, group) adds nchunk x (C / G) x 2 values (thread = chunk, the group's channels contiguous: full-line reads),
+// fp64 from the wave level up.  MODE 0: (mean, rstd) (+ table);  MODE 1: (s1 / n, s2 / n).
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ cs, float* __restrict__ out,
                                                                 float* __restrict__ table, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ film,
                                                                 long long ldf, int B, int G, int C, int nchunk, double n,
                                                                 float eps) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= B * G) return;
-  const int b = i / G, g = i % G;
+  __shared__ double red[2][4];
+  __shared__ float bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
   const int gs = C / G;
   const float* base = cs + (long long)b * nchunk * 2 * C + g * gs;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = lane; k < nchunk * gs; k += 64) {
-    const int ch = k / gs, e = k - ch * gs;
-    s1 += (double)base[(long long)ch * 2 * C + e];
-    s2 += (double)base[(long long)ch * 2 * C + C + e];
+  float f1 = 0.f, f2 = 0.f;
+  for (int ch = tid; ch < nchunk; ch += 256) {
+    const float* p1 = base + (long long)ch * 2 * C;
+    for (int e = 0; e < gs; ++e) {
+      f1 += p1[e];
+      f2 += p1[C + e];
+    }
   }
+  double s1 = (double)f1, s2 = (double)f2;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     s1 += __shfl_xor(s1, o, 64);
     s2 += __shfl_xor(s2, o, 64);
   }
-  if (MODE == 1) {
-    if (lane == 0) {
-      out[i * 2] = (float)(s1 / n);
-      out[i * 2 + 1] = (float)(s2 / n);
-    }
-    return;
-  }
-  const double mu = s1 / n;
-  double var = s2 / n - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (lane == 0) {
-    out[i * 2] = mean;
-    out[i * 2 + 1] = rstd;
+    red[0][wave] = s1;
+    red[1][wave] = s2;
   }
-  if (!table) return;
+  __syncthreads();
+  if (tid == 0) {
+    const double t1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double t2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    float o0, o1;
+    if (MODE == 1) {
+      o0 = (float)(t1 / n);
+      o1 = (float)(t2 / n);
+    } else {
+      const double mu = t1 / n;
+      double var = t2 / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      o0 = (float)mu;
+      o1 = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    out[(b * G + g) * 2] = o0;
+    out[(b * G + g) * 2 + 1] = o1;
+    bc[0] = o0;
+    bc[1] = o1;
+  }
+  if (MODE == 1 || !table) return;
+  __syncthreads();
+  const float mean = bc[0], rstd = bc[1];
   float* t = table + (long long)b * 4 * C;
-  for (int e = lane; e < gs; e += 64) {
+  for (int e = tid; e < gs; e += 256) {
     const int c = g * gs + e;
     const float sc = film ? film[(long long)b * ldf + c] : 0.f;
     const float sh = film ? film[(long long)b * ldf + C + c] : 0.f;
@@ -351,9 +367,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
     const act_t* xp = a.x + ((long long)b * a.HW + p0 + tr) * a.ldx + c;
     const act_t* dp = MODE == 1 ? a.dy + ((long long)b * a.HW + p0 + tr) * a.lddy + c : nullptr;
     const act_t* ap = (MODE == 1 && a.addend) ? a.addend + ((long long)b * a.HW + p0 + tr) * a.ldadd + c : nullptr;
+    const act_t* ap2 = (MODE == 1 && a.addend2) ? a.addend2 + ((long long)b * a.HW + p0 + tr) * a.ldadd2 + c : nullptr;
     act_t* op = a.out + ((long long)b * a.HW + p0 + tr) * a.ldo + c;
     const long long sx = (long long)rowT * a.ldx, sd = (long long)rowT * a.lddy, sa = (long long)rowT * a.ldadd,
-                    so = (long long)rowT * a.ldo;
+                    sa2 = (long long)rowT * a.ldadd2, so = (long long)rowT * a.ldo;
 #pragma unroll 4
     for (int p = p0 + tr; p < p1; p += rowT) {
       float xv[VEC], dv[VEC], ov[VEC], av[VEC];
@@ -367,12 +384,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
             const float4 w = osm::ld4(ap);
             av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
           }
+          if (ap2) {
+            const float4 w = osm::ld4(ap2);
+            av[0] = (ap ? av[0] : 0.f) + w.x; av[1] = (ap ? av[1] : 0.f) + w.y;
+            av[2] = (ap ? av[2] : 0.f) + w.z; av[3] = (ap ? av[3] : 0.f) + w.w;
+          }
         }
       } else {
         xv[0] = osm::ld1(xp);
         if (MODE == 1) {
           dv[0] = osm::ld1(dp);
           if (ap) av[0] = osm::ld1(ap);
+          if (ap2) av[0] = (ap ? av[0] : 0.f) + osm::ld1(ap2);
         }
       }
 #pragma unroll
@@ -386,7 +409,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
           if (film) dz *= (1.0f + sc[e]);
           const float dxh = dz * ga[e];
           float r = rstd * (dxh - m1 - xh * m2);
-          if (ap) r += av[e];
+          if (ap || ap2) r += av[e];
           ov[e] = r;
         }
       }
@@ -400,6 +423,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
       if (MODE == 1) {
         dp += sd;
         if (ap) ap += sa;
+        if (ap2) ap2 += sa2;
       }
     }
   }
@@ -518,6 +542,10 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
         const float4 w = osm::ld4(a.addend + (row0 + p) * a.ldadd + c);
         av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
       }
+      if (a.addend2) {
+        const float4 w = osm::ld4(a.addend2 + (row0 + p) * a.ldadd2 + c);
+        av[0] += w.x; av[1] += w.y; av[2] += w.z; av[3] += w.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float xh, z;
@@ -538,7 +566,8 @@ bool use_vec4(const GNArgs& a) {
   return a.gs % 4 == 0 && a.ldx % 4 == 0 && osm::aligned_act4(a.x) &&
          (!a.dy || (a.lddy % 4 == 0 && osm::aligned_act4(a.dy))) &&
          (!a.out || (a.ldo % 4 == 0 && osm::aligned_act4(a.out))) &&
-         (!a.addend || (a.ldadd % 4 == 0 && osm::aligned_act4(a.addend)));
+         (!a.addend || (a.ldadd % 4 == 0 && osm::aligned_act4(a.addend))) &&
+         (!a.addend2 || (a.ldadd2 % 4 == 0 && osm::aligned_act4(a.addend2)));
 }
 
 int check_common(const GNArgs& a, const char* who) {
@@ -656,20 +685,20 @@ extern "C" int osm_gn_finalize_cols(const float* colsum, int nchunk, int B, int 
   OSM_REQUIRE(mode == 0 || mode == 1, "osm_gn_finalize_cols: mode must be 0 or 1");
   OSM_REQUIRE(!table || (mode == 0 && gamma && beta), "osm_gn_finalize_cols: the table needs mode 0, gamma and beta");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_finalize_cols: ldfilm smaller than 2*C");
-  const int n = B * G;
   const double cnt = (double)HW * (C / G);
   if (mode == 0)
-    hipLaunchKernelGGL((gn_finalize_cols_kernel<0>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, colsum, stats,
+    hipLaunchKernelGGL((gn_finalize_cols_kernel<0>), dim3(G, B), dim3(256), 0, (hipStream_t)stream, colsum, stats,
                        table, gamma, beta, film, ldfilm, B, G, C, nchunk, cnt, eps);
   else
-    hipLaunchKernelGGL((gn_finalize_cols_kernel<1>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, colsum, stats,
+    hipLaunchKernelGGL((gn_finalize_cols_kernel<1>), dim3(G, B), dim3(256), 0, (hipStream_t)stream, colsum, stats,
                        (float*)nullptr, gamma, beta, film, ldfilm, B, G, C, nchunk, cnt, eps);
   return osm::check_launch("gn_finalize_cols_kernel");
 }
 #endif
 
 extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy,
-                                        abi_act_t* dx, long long lddx, const abi_act_t* addend, long long ldadd, int B,
+                                        abi_act_t* dx, long long lddx, const abi_act_t* addend, long long ldadd,
+                                        const abi_act_t* addend2, long long ldadd2, int B,
                                         int HW, int C, int G, const float* stats, const float* gstats, const float* gamma,
                                         const float* beta, const float* film, long long ldfilm, int silu, void* stream) {
   OSM_REQUIRE(x && dy && dx && stats && gstats && gamma && beta, "osm_gn_bwd_apply: null pointer");
@@ -677,6 +706,7 @@ extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const
   GNArgs a{};
   a.x = OSM_CACT(x); a.ldx = ldx;
   a.dy = OSM_CACT(dy); a.lddy = lddy; a.out = OSM_ACT(dx); a.ldo = lddx; a.addend = OSM_CACT(addend); a.ldadd = ldadd;
+  a.addend2 = OSM_CACT(addend2); a.ldadd2 = ldadd2;
   a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
   a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_bwd_apply");
@@ -686,13 +716,15 @@ extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const
 }
 
 extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy, abi_act_t* dx,
-                          long long lddx, const abi_act_t* addend, long long ldadd, int B, int HW, int C, int G,
+                          long long lddx, const abi_act_t* addend, long long ldadd, const abi_act_t* addend2, long long ldadd2,
+                          int B, int HW, int C, int G,
                           const float* stats, const float* gamma, const float* beta, const float* film,
                           long long ldfilm, int silu, float* part, float* gstats, void* stream) {
   OSM_REQUIRE(x && dy && dx && stats && gamma && beta && part && gstats, "osm_gn_bwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd: ldfilm smaller than 2*C");
   GNArgs a{};
   a.x = OSM_CACT(x); a.ldx = ldx; a.dy = OSM_CACT(dy); a.lddy = lddy; a.out = OSM_ACT(dx); a.ldo = lddx; a.addend = OSM_CACT(addend); a.ldadd = ldadd;
+  a.addend2 = OSM_CACT(addend2); a.ldadd2 = ldadd2;
   a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
   a.film = film; a.ldf = ldfilm; a.silu = silu; a.part = part;
   int rc = check_common(a, "osm_gn_bwd");

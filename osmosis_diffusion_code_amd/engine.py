@@ -232,8 +232,13 @@ class UNetEngine:
         self._fwd_graph = self._bwd_graph = None
         # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
         self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
-        # GroupNorm reductions (forward statistics, backward sums) as column sums from the epilogue of the producing conv
-        self.fuse_stats = self.fuse_gn and os.environ.get("OSM_FUSE_STATS", "1") != "0"
+        # GroupNorm reductions as column sums from the epilogue of the producing conv.  OSM_FUSE_STATS = "fwd" (default):
+        # the forward statistics of a ResBlock's second GroupNorm come from its first convolution; "all": also the two
+        # backward reductions, from the data-gradient convolutions (measured a net loss: the epilogue must re-read the
+        # GroupNorm input with 4-byte accesses: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1); "0": neither
+        fs = os.environ.get("OSM_FUSE_STATS", "fwd")
+        self.fuse_stats = self.fuse_gn and fs != "0"
+        self.fuse_stats_bwd = self.fuse_stats and fs == "all"
 
         w = weights
         self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
@@ -365,7 +370,7 @@ class UNetEngine:
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
             # the per-channel GroupNorm tables are kept: the data-gradient convolutions fold the GroupNorm-backward
             # reductions into their epilogues with them (see _res_bwd)
-            tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats and self._gn_fusable(blk.c1, hw)) else None
+            tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._gn_fusable(blk.c1, hw)) else None
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1, stat=("fwd",) if fuse2 else None)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
@@ -374,7 +379,7 @@ class UNetEngine:
             res = dst
         else:
             res = xs
-        tab2 = self._small(B * 4 * blk.cout) if (self.fuse_stats and fuse2) else None
+        tab2 = self._small(B * 4 * blk.cout) if (self.fuse_stats_bwd and fuse2) else None
         self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res, cs=cs1, table=tab2)
         self._saved[id(blk)] = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo), tab1=tab1, tab2=tab2)
         return (ho, wo)
@@ -411,7 +416,9 @@ class UNetEngine:
             ops.upsample2x(da1r, da1, B, ho, wo, 0.25)
         else:
             da1 = da1r
-        # skip path gradient into dx_dst, then dx_dst = dGN(da1) + dx_dst
+        # skip-path gradient + the gradient already sitting in dx_dst (concat / residual accumulation) are ADDENDS of the
+        # GroupNorm-backward apply pass (up to two, one of which may be dx_dst itself): no accumulation pass of its own
+        add2 = None
         if blk.up or blk.down:
             assert blk.skip is None
             t = self._scr("c", M, blk.cin)
@@ -419,27 +426,22 @@ class UNetEngine:
                 ops.pool2x2(dy, t, B, ho, wo, 1.0)
             else:
                 ops.upsample2x(dy, t, B, ho, wo, 0.25)
-            if accumulate:
-                ops.copy2d(t, dx_dst, accumulate=True)
-                add = dx_dst
-            else:
-                add = t
+            add = t
+            add2 = dx_dst if accumulate else None
         elif blk.skip is not None:
             self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate)
             add = dx_dst
         else:
-            if accumulate:
-                ops.copy2d(dy, dx_dst, accumulate=True)
-                add = dx_dst
-            else:
-                add = dy
+            add = dy
+            add2 = dx_dst if accumulate else None
         gst1 = self._small(B * G * 2)
         if cs1 is not None:
             ops.gn_finalize_cols(cs1[0], cs1[1], B, H * W, blk.cin, G, gst1, mode=1)
-            ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add)
+            ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add,
+                             addend2=add2)
         else:
             ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
-                       silu=True, addend=add)
+                       silu=True, addend=add, addend2=add2)
 
     # ------------------------------------------------------------------ Attention
     def _gemm(self, *a, **kw):
@@ -482,10 +484,12 @@ class UNetEngine:
         a = self._scr("c", M, C, torch.float32)
         # fused core: measured faster at T = 64 (3 launches instead of 14); at T = 256 its fp32 FMA work sits on
         # only 64 workgroups and the unfused GEMM pipeline wins (OSM_ATTN_FUSED=all / 0 to force either way)
+        # 64-wide heads (every block of the 256-channel model): flash-style core on the matrix cores
+        # (OSM_ATTN_FLASH=0: the round-1 paths -- FMA core at T = 64, GEMM pipeline above; =256: flash from T = 256 only)
+        fl = os.environ.get("OSM_ATTN_FLASH", "1")
+        flash = fl != "0" and ops.attn_flash_supported(T, ch) and T >= (int(fl) if fl not in ("0", "1") else 64)
         mode = os.environ.get("OSM_ATTN_FUSED", "64")
-        fused = ops.attn_small_supported(T, ch) and (mode == "all" or (mode != "0" and T <= 64))
-        # 16x16 / 32x32 with 64-wide heads: flash-style core on the matrix cores (OSM_ATTN_FLASH=0: the GEMM pipeline)
-        flash = (not fused) and os.environ.get("OSM_ATTN_FLASH", "1") != "0" and ops.attn_flash_supported(T, ch)
+        fused = (not flash) and ops.attn_small_supported(T, ch) and (mode == "all" or (mode != "0" and T <= 64))
         P = PT = lse = None
         if flash:      # logits / probabilities stay in registers; the output and its log-sum-exp are kept for the backward
             a = self._buf(M, C, torch.float32)
@@ -558,14 +562,9 @@ class UNetEngine:
             dqkv = dqkv_h
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
-        if accumulate:
-            ops.copy2d(dy, dx_dst, accumulate=True)
-            add = dx_dst
-        else:
-            add = dy
         gst = self._small(B * G * 2)
         ops.gn_bwd(s["x"], dxn, dx_dst, B, T, G, s["st"], blk.norm.g, blk.norm.b, self.gn_part, gst,
-                   silu=False, addend=add)
+                   silu=False, addend=dy, addend2=dx_dst if accumulate else None)
 
     # ------------------------------------------------------------------ whole network
     @staticmethod

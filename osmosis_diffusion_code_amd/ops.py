@@ -200,12 +200,13 @@ def gn_finalize_cols(colsum, nchunk, B, HW, C, G, stats, mode=0, gamma=None, bet
 
 
 def gn_bwd_apply(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gstats, gamma, beta, film=None, silu=True,
-                 addend: Optional[Mat] = None):
+                 addend: Optional[Mat] = None, addend2: Optional[Mat] = None):
     fp, ldf = _film(film)
-    call("osm_gn_bwd_apply" + _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None), x.p, x.ld,
-         dy.p, dy.ld, dx.p, dx.ld, addend.p if addend is not None else None, addend.ld if addend is not None else 0,
+    fam = _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None, addend2.t if addend2 is not None else None)
+    call("osm_gn_bwd_apply" + fam, x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, *_addends(addend, addend2),
          B, HW, x.cols, G, ptr(stats), ptr(gstats), ptr(gamma), ptr(beta), fp, ldf, int(silu), _s(),
-         keep=(x.t, dy.t, dx.t, addend.t if addend else None, stats, gstats, gamma, beta, film))
+         keep=(x.t, dy.t, dx.t, addend.t if addend else None, addend2.t if addend2 else None, stats, gstats, gamma, beta,
+               film))
 
 
 def gn_nchunk(HW: int) -> int:
@@ -243,13 +244,21 @@ def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, fi
          ptr(table), _s(), keep=(x.t, part, stats, gamma, beta, film, table))
 
 
+def _addends(addend, addend2):
+    a1 = (addend.p, addend.ld) if addend is not None else (None, 0)
+    a2 = (addend2.p, addend2.ld) if addend2 is not None else (None, 0)
+    return a1 + a2
+
+
 def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
-           film=None, silu=True, addend: Optional[Mat] = None):
+           film=None, silu=True, addend: Optional[Mat] = None, addend2: Optional[Mat] = None):
+    """dx = dGN(dy) (+ addend) (+ addend2); an addend may be dx itself (accumulate in place)."""
     fp, ldf = _film(film)
-    call("osm_gn_bwd" + _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None), x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld,
-         addend.p if addend is not None else None, addend.ld if addend is not None else 0,
+    fam = _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None, addend2.t if addend2 is not None else None)
+    call("osm_gn_bwd" + fam, x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, *_addends(addend, addend2),
          B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(part), ptr(gstats), _s(),
-         keep=(x.t, dy.t, dx.t, addend.t if addend else None, stats, gamma, beta, film, part, gstats))
+         keep=(x.t, dy.t, dx.t, addend.t if addend else None, addend2.t if addend2 else None, stats, gamma, beta, film,
+               part, gstats))
 
 
 def pool2x2(x: Mat, y: Mat, B, H, W, scale=0.25):

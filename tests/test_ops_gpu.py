@@ -174,6 +174,18 @@ def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
                film=ed, silu=silu, addend=ops.Mat.of(nhwc(add)))
     gotdx = dxd.cpu().reshape(B, HW, C).permute(0, 2, 1)
     assert float((gotdx - dxr).abs().max()) < 5e-5 * max(1.0, float(dxr.abs().max()))
+    # two addends, one of them the output buffer itself (in-place accumulation of the residual / concat gradient)
+    add2 = torch.randn(B, C, HW, generator=g)
+    acc = nhwc(add2).clone()
+    ops.gn_bwd(xm, ops.Mat.of(nhwc(dy)), ops.Mat.of(acc), B, HW, G, stats, gd, bd, part, gstats,
+               film=ed, silu=silu, addend=ops.Mat.of(nhwc(add)), addend2=ops.Mat.of(acc))
+    got2 = acc.cpu().reshape(B, HW, C).permute(0, 2, 1)
+    assert float((got2 - (dxr + add2)).abs().max()) < 5e-5 * max(1.0, float(dxr.abs().max()))
+    acc3 = nhwc(add2).clone()       # the in-place buffer as the only addend
+    ops.gn_bwd(xm, ops.Mat.of(nhwc(dy)), ops.Mat.of(acc3), B, HW, G, stats, gd, bd, part, gstats,
+               film=ed, silu=silu, addend2=ops.Mat.of(acc3))
+    got3 = acc3.cpu().reshape(B, HW, C).permute(0, 2, 1)
+    assert float((got3 - (dxr - add + add2)).abs().max()) < 5e-5 * max(1.0, float(dxr.abs().max()))
 
 
 def test_pool_upsample(ops):
@@ -247,9 +259,9 @@ def test_attn_small_fwd_bwd(ops, B, T, heads, ch, new_order):
 
 
 @pytest.mark.parametrize("new_order", [False, True])
-@pytest.mark.parametrize("B,T,heads", [(1, 1024, 2), (2, 256, 3), (1, 512, 1)])
+@pytest.mark.parametrize("B,T,heads", [(1, 1024, 2), (2, 256, 3), (1, 512, 1), (2, 64, 3), (1, 128, 2)])
 def test_attn_flash_fwd_bwd(ops, B, T, heads, new_order):
-    """Flash-style attention on the matrix cores (T multiple of 256, 64-wide heads, bf16x6 arithmetic) vs the
+    """Flash-style attention on the matrix cores (T = 64 or a multiple of 128, 64-wide heads, bf16x6 arithmetic) vs the
     reference formulation in fp64 (unet.py:416-433 legacy / :459-467 new order).  Tolerance: 5e-6 of the max-abs
     (forward) / 1e-5 (gradients: 5 chained GEMMs), fp32-class."""
     ch = 64
@@ -272,7 +284,7 @@ def test_attn_flash_fwd_bwd(ops, B, T, heads, new_order):
         outs.append(torch.einsum("bts,bsc->btc", torch.softmax(logits, dim=-1), head(2, h)))
     ref = torch.cat(outs, dim=-1)
     (dref,) = torch.autograd.grad(ref, x, dout.double())
-    assert ops.attn_flash_supported(T, ch) and not ops.attn_flash_supported(T, 32) and not ops.attn_flash_supported(64, 64)
+    assert ops.attn_flash_supported(T, ch) and not ops.attn_flash_supported(T, 32) and not ops.attn_flash_supported(96, 64)
 
     qd = qkv.reshape(B * T, 3 * C).to(DEV)
     od = torch.full((B * T, C), float("nan"), device=DEV)
@@ -389,7 +401,7 @@ def test_conv_split_bf16_modes(ops, mode, tol, B, Cin, Cout, H, W, k, splitk):
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f16"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,splitk", [(2, 64, 96, 16, 24, 1), (1, 128, 64, 32, 32, 4), (1, 96, 128, 9, 17, 1),
-                                                   (2, 64, 64, 8, 8, 2)])
+                                                   (2, 64, 64, 8, 8, 2), (1, 32, 64, 32, 32, 2)])   # last: split clamped to 1 slab
 def test_conv_column_sums_feed_group_norm(ops, mode, B, Cin, Cout, H, W, splitk):
     """The side output of a convolution (osm_conv_desc.colsum) replaces the reduction passes of the GroupNorm around it:
     stat_mode 1 -> mean / rstd / per-channel table of GN(y) via osm_gn_finalize_cols; stat_mode 2 -> the two backward
