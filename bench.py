@@ -171,11 +171,11 @@ def roofline(model, args):
             per_shape.setdefault(shape, [0.0, 0, 8.0 * shape[1] * shape[2] * shape[3]])
             return ("groupnorm", 0.0, shape)
         if name.startswith("osm_gn"):
-            i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 8, "osm_gn_bwd_apply": 8, "osm_gn_fwd": 4,
-                  "osm_gn_prep": 2}[name]
+            i0 = {"osm_gn_stats": 2, "osm_gn_apply": 4, "osm_gn_bwd": 10, "osm_gn_bwd_apply": 10, "osm_gn_fwd": 4,
+                  "osm_gn_prep": 2}[name]     # position of (B, HW, C) in the C argument list
             shape = (name, int(a[i0]), int(a[i0 + 1]), int(a[i0 + 2]))
             passes = {"osm_gn_stats": 1, "osm_gn_apply": 2, "osm_gn_fwd": 3, "osm_gn_prep": 1,
-                      "osm_gn_bwd": 5 if a[6] else 4, "osm_gn_bwd_apply": 4 if a[6] else 3}[name]
+                      "osm_gn_bwd": 4 + bool(a[6]) + bool(a[8]), "osm_gn_bwd_apply": 3 + bool(a[6]) + bool(a[8])}[name]
             per_shape.setdefault(shape, [0.0, 0, 4.0 * shape[1] * shape[2] * shape[3] * passes])
             return ("groupnorm", 0.0, shape)
         return ("other", 0.0, None)
@@ -213,7 +213,8 @@ def roofline(model, args):
                     "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1"}[args.conv_mode]
             hit = [k for k in json.load(open(path))["kernels"]
                    if k["kernel"].replace(" ", "").startswith(pref)
-                   and (args.conv_mode == "f32" or k["kernel"].replace(" ", "").endswith(",16>"))]   # 8 x 16 patches
+                   and (args.conv_mode == "f32"                         # template <NP, GN, PW, BR, PH>: PW = 16 patches
+                        or (k["kernel"].replace(" ", "").split("<")[1].rstrip(">").split(",") + ["", "", ""])[2] == "16")]
             if hit:   # launch-weighted mean over the template instances of the dominant kernel
                 traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in hit) / sum(k["launches"] for k in hit))
                 traffic_src = os.path.relpath(path, ROOT)

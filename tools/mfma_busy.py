@@ -4,10 +4,12 @@
     tools/mfma_busy.py <out.json>          # runs rocprofv3 --pmc over tools/conv_probe.py itself (on a GPU box)
 
 Counters: SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipe is busy, summed over every SIMD of the chip: 32 per
-v_mfma_f32_32x32x16_bf16), GRBM_GUI_ACTIVE (shader-clock cycles the GPU was busy during the dispatch), SQ_WAVE_CYCLES,
-SQ_BUSY_CU_CYCLES.  Derived per dispatch:
-    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)
-    clock_ghz       = GRBM_GUI_ACTIVE / dispatch duration          (what the power manager grants under this load)
+v_mfma_f32_32x32x16_bf16 -- the count below reproduces the analytic number of MFMAs exactly), GRBM_GUI_ACTIVE
+(shader-clock cycles the GPU was busy during the dispatch; rocprofv3 reports the SUM over the 8 XCDs, each with its
+own GRBM, hence the / 8), SQ_WAVE_CYCLES, SQ_BUSY_CU_CYCLES.  Derived per dispatch:
+    gui_cycles      = GRBM_GUI_ACTIVE / 8
+    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x gui_cycles)
+    clock_ghz       = gui_cycles / dispatch duration               (what the power manager grants under this load)
     expected_mfma   = algorithmic flops x 6 / (2 x 32 x 32 x 16)   (bf16x6: six MFMAs per fp32 product group)
     mfma_count_seen = SQ_VALU_MFMA_BUSY_CYCLES / 32                (sanity check against expected_mfma)
 """
@@ -52,8 +54,9 @@ def main():
         rows.append({
             "shape_B,H,W,Cin,Cout,k": shape, "kernel": "conv3_halo_bf16s_kernel<3,*> (bf16x6)", "dispatches": acc["GRBM_GUI_ACTIVE"][1],
             "avg_us_under_pmc": round(us, 2), "counters_avg_per_dispatch": {k: round(v, 1) for k, v in avg.items()},
-            "mfma_busy_frac": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"]), 4),
-            "clock_ghz": round(avg["GRBM_GUI_ACTIVE"] / (us * 1e3), 3),
+            "mfma_busy_frac": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0), 4),
+            "clock_ghz": round(avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3), 3),
+            "bf16x6_roof_at_that_clock_tflops": round(2500.0 / 6.0 * (avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)) / 2.4, 1),
             "expected_mfma_instructions": round(flops * 6 / (2 * 32 * 32 * 16)),
             "mfma_instructions_seen": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 32),
             "algorithmic_tflops_under_pmc": round(flops / us / 1e6, 1)})

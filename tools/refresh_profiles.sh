@@ -24,4 +24,5 @@ rm -rf "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/kt"
 cd "$repo"
 cp "$out/${tag}_pmc_hbm_traffic.json" profiles/ 2>/dev/null   # so that the bench line below carries the new traffic
 python bench.py --steps 8 --warmup 2 --dump-layers "$out/${tag}_conv_layer_timings.json" 2> "$out/bench.err" > "$out/${tag}_bench.json"
+python "$repo/tools/mfma_busy.py" "$out/${tag}_pmc_mfma_busy.json" > "$out/mfma_busy.txt" 2>&1
 tail -c 600 "$out/${tag}_bench.json"; cat "$out/pmc_summary.txt" | head -8
