@@ -245,3 +245,74 @@ def test_c_abi_header_is_plain_c_and_links_from_c(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "rc -1" in run.stdout and "null pointer" in run.stdout
+
+
+def test_poisson_and_gaussian_noisers_follow_the_reference_recipe():
+    """measurements.py:471-507: gaussian adds sigma * randn; poisson draws np.random.poisson(255 * rate * img01) and maps
+    back to [-1, 1] (seeded numpy stream, clamped)."""
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    x = torch.linspace(-1, 1, 3 * 8 * 8).reshape(1, 3, 8, 8)
+    torch.manual_seed(5)
+    y = M.get_noise("gaussian", sigma=0.1)(x)
+    torch.manual_seed(5)
+    assert torch.allclose(y, x + 0.1 * torch.randn_like(x))
+    np.random.seed(3)
+    yp = M.get_noise("poisson", rate=1.0)(x)
+    np.random.seed(3)
+    d01 = ((x + 1.0) / 2.0).clamp(0, 1)
+    want = (torch.from_numpy(np.random.poisson(d01 * 255.0 * 1.0) / 255.0 / 1.0) * 2.0 - 1.0).clamp(-1, 1)
+    assert torch.equal(yp, want) and float(yp.min()) >= -1 and float(yp.max()) <= 1
+    assert M.get_noise("clean")(x) is x
+    with pytest.raises(NameError):
+        M.get_noise("salt")
+
+
+def test_process_grid_layout(tmp_path):
+    """`<name>_process.png` of the fused loop's recording (gaussian_diffusion.py:308-333): RGB row over depth row, one column
+    per snapshot, 2-pixel padding like torchvision.utils.make_grid."""
+    from PIL import Image
+    from osmosis_diffusion_code_amd.guided_diffusion.gaussian_diffusion import GaussianDiffusion
+    g = torch.Generator().manual_seed(0)
+    recs = [(idx, torch.rand(1, 4, 16, 12, generator=g) * 2 - 1) for idx in (999, 800, 0)]
+    path = GaussianDiffusion._save_process_grid(recs, str(tmp_path), "img7")
+    assert path.endswith("img7_process.png")
+    im = np.asarray(Image.open(path))
+    assert im.shape == (2 * (16 + 2) + 2, 3 * (12 + 2) + 2, 3)
+    assert (im[:2] == 0).all() and (im[:, :2] == 0).all()          # padding
+    want = (torch.clamp(0.5 * (recs[1][1][0, 0:3] + 1), 0, 1).mul(255).add(0.5).clamp(0, 255)).to(torch.uint8)
+    assert np.array_equal(im[2:18, 2 + 14:2 + 14 + 12], want.permute(1, 2, 0).numpy())
+    assert GaussianDiffusion._save_process_grid(recs, None, "x") is None
+
+
+def test_activation_footprint_estimate_and_architecture_walk():
+    """engine.describe_architecture / activation_bytes_per_image (sizes batches per pass): shapes-only, no device."""
+    import contextlib
+    import io
+    from osmosis_diffusion_code_amd.engine import activation_bytes_per_image, describe_architecture
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = unet.create_model(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2",
+                              attention_resolutions="128,64", num_head_channels=16, num_heads=4, learn_sigma=True,
+                              use_scale_shift_norm=True, resblock_updown=True, pretrain_model="osmosis")
+    a = describe_architecture(m)
+    assert a["cin"] == 4 and a["cout"] == 8 and a["inp"][0] == [("conv", 4, 32)]
+    assert [l[0] for l in a["mid"]] == ["res", "attn", "res"]
+    # channel_mult 1,2,2 with attention at ds 2 and 4: 2 input + 1 middle + 4 output attention blocks
+    assert sum(1 for s in a["inp"] + a["outb"] + [a["mid"]] for l in s if l[0] == "attn") == 7
+    b32 = activation_bytes_per_image(a, 32, 32, 4)
+    b64 = activation_bytes_per_image(a, 64, 64, 4)
+    h64 = activation_bytes_per_image(a, 64, 64, 2)
+    assert 3.0 < (b64 - 16 * 2 ** 20) / (b32 - 16 * 2 ** 20) < 17.0     # 4x the pixels, 16x the T^2 attention terms
+    assert h64 < b64
+
+
+def test_fused_loop_argument_checks_need_no_gpu():
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    from osmosis_diffusion_code_amd.osmosis_utils.diffusion import GaussianDiffusion as Prior
+    c = CM.PosteriorSamplingOsmosis(operator=None, noiser=None, scale="7,7,7,0.9", gradient_x_prev=False,
+                                    gradient_clip="True,0.005")
+    assert c.gradient_clip and c.clip_value == -1.0      # the x0-gradient branch of the reference is not clipped (:222-224)
+    c0 = CM.PosteriorSamplingOsmosis(operator=None, noiser=None, scale="1", gradient_x_prev=True, gradient_clip="True,0")
+    assert c0.clip_value == 0.0                           # clamp to zero, like torch.clamp(g, -0, 0)
+    with pytest.raises(NotImplementedError):              # inverse() drives the HIP UNetModel only
+        Prior(1000, "linear").inverse(object(), shape=(4, 8, 8), steps=5, start_t=3)
