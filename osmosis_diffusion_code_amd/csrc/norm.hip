@@ -90,17 +90,8 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
       for (int p = p0 + tr; p < p1; p += rowT) {
         const long long row = (long long)b * a.HW + p;
         float xv[VEC], dv[VEC];
-        if (VEC == 4) {
-          const float4 t = osm::ld4(a.x + row * a.ldx + c);
-          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-          if (MODE == 1) {
-            const float4 u = osm::ld4(a.dy + row * a.lddy + c);
-            dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
-          }
-        } else {
-          xv[0] = osm::ld1(a.x + row * a.ldx + c);
-          if (MODE == 1) dv[0] = osm::ld1(a.dy + row * a.lddy + c);
-        }
+        osm::ldv<VEC>(a.x + row * a.ldx + c, xv);
+        if (MODE == 1) osm::ldv<VEC>(a.dy + row * a.lddy + c, dv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           if (MODE == 0) {
@@ -374,28 +365,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
 #pragma unroll 4
     for (int p = p0 + tr; p < p1; p += rowT) {
       float xv[VEC], dv[VEC], ov[VEC], av[VEC];
-      if (VEC == 4) {
-        const float4 t = osm::ld4(xp);
-        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-        if (MODE == 1) {
-          const float4 u = osm::ld4(dp);
-          dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
-          if (ap) {
-            const float4 w = osm::ld4(ap);
-            av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
-          }
-          if (ap2) {
-            const float4 w = osm::ld4(ap2);
-            av[0] = (ap ? av[0] : 0.f) + w.x; av[1] = (ap ? av[1] : 0.f) + w.y;
-            av[2] = (ap ? av[2] : 0.f) + w.z; av[3] = (ap ? av[3] : 0.f) + w.w;
-          }
-        }
-      } else {
-        xv[0] = osm::ld1(xp);
-        if (MODE == 1) {
-          dv[0] = osm::ld1(dp);
-          if (ap) av[0] = osm::ld1(ap);
-          if (ap2) av[0] = (ap ? av[0] : 0.f) + osm::ld1(ap2);
+      osm::ldv<VEC>(xp, xv);
+      if (MODE == 1) {
+        osm::ldv<VEC>(dp, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) av[e] = 0.f;
+        if (ap) osm::ldv<VEC>(ap, av);
+        if (ap2) {
+          float a2[VEC];
+          osm::ldv<VEC>(ap2, a2);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) av[e] += a2[e];
         }
       }
 #pragma unroll
@@ -413,11 +393,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
           ov[e] = r;
         }
       }
-      if (VEC == 4) {
-        osm::st4(op, make_float4(ov[0], ov[1], ov[2], ov[3]));
-      } else {
-        osm::st1(op, ov[0]);
-      }
+      osm::stv<VEC>(op, ov);
       xp += sx;
       op += so;
       if (MODE == 1) {

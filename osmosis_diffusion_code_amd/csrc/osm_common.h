@@ -44,6 +44,39 @@ __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+// VEC (1, 4 or 8) consecutive activations <-> fp32 registers; 8 halfs = one 16-byte access
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx8_t __attribute__((ext_vector_type(8)));
+template <int VEC, typename T>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    v[0] = ld1(p);
+  } else if constexpr (VEC == 8 && sizeof(T) == 2) {
+    const floatx8_t f = __builtin_convertvector(*reinterpret_cast<const half8_t*>(p), floatx8_t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f[e];
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 t = ld4(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void stv(T* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    st1(p, v[0]);
+  } else if constexpr (VEC == 8 && sizeof(T) == 2) {
+    floatx8_t f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = v[e];
+    *reinterpret_cast<half8_t*>(p) = __builtin_convertvector(f, half8_t);
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) st4(p + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
+  }
+}
 // alignment of a 4-element activation vector access
 inline bool aligned_act4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(act_t) - 1)) == 0; }
 
