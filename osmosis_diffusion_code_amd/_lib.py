@@ -163,31 +163,58 @@ class Recorder:
         return False
 
     def replay(self):
-        for fn, args in self.calls:
+        """Launch by launch on the stream the calls were recorded on (side-branch tags are ignored: one stream)."""
+        for c in self.calls:
+            if c[0] is JOIN:
+                continue
+            fn, args = c[0], c[1]
             rc = fn(*args)
             if rc != 0:
                 raise OsmosisHipError(f"{fn.__name__} failed ({rc}): {load().osm_last_error().decode()}")
 
     def to_graph(self):
         """Capture the recorded launches into a hipGraph (torch.cuda.CUDAGraph).  Every recorded call ends
-        with its stream argument, which is re-targeted to the capture stream."""
+        with its stream argument, which is re-targeted to the capture stream -- or, for calls recorded inside
+        `side_branch(k)`, to side stream k, forked from the capture stream at the branch's first call and joined back at
+        its `join(k)` marker: independent branches (a ResBlock's 1x1 skip convolution next to its 3x3 chain) become
+        parallel paths of the graph."""
         g = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.graph(g, stream=side):
-            sp = torch.cuda.current_stream().cuda_stream
-            for fn, args in self.calls:
-                rc = fn(*args[:-1], sp)
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        sides, open_ = {}, set()
+        with torch.cuda.graph(g, stream=cap):
+            cs = torch.cuda.current_stream()
+            for c in self.calls:
+                if c[0] is JOIN:
+                    if c[1] in open_:
+                        cs.wait_stream(sides[c[1]])
+                        open_.discard(c[1])
+                    continue
+                fn, args = c[0], c[1]
+                k = c[2] if len(c) > 2 else None
+                if k is None:
+                    st = cs
+                else:
+                    st = sides.setdefault(k, torch.cuda.Stream())
+                    if k not in open_:
+                        st.wait_stream(cs)       # fork: everything recorded so far precedes the branch
+                        open_.add(k)
+                rc = fn(*args[:-1], st.cuda_stream)
                 if rc != 0:
                     raise OsmosisHipError(f"{fn.__name__} failed during capture ({rc}): "
                                           f"{load().osm_last_error().decode()}")
+            for k in list(open_):                # a capture must end with every forked stream joined
+                cs.wait_stream(sides[k])
         return g
 
     def replay_timed(self, select):
         """Replay with HIP events around the selected launches (events are recorded on the stream
         the kernels run on).  `select(fn_name, args)` returns a tag or None.  Returns [(tag, ms)]."""
         marks = []
-        for fn, args in self.calls:
+        for c in self.calls:
+            if c[0] is JOIN:
+                continue
+            fn, args = c[0], c[1]
             tag = select(fn.__name__, args)
             if tag is None:
                 fn(*args)
@@ -202,13 +229,41 @@ class Recorder:
         return [(tag, e0.elapsed_time(e1)) for tag, e0, e1 in marks]
 
     def __len__(self):
-        return len(self.calls)
+        return sum(1 for c in self.calls if c[0] is not JOIN)
 
 
 class _State(threading.local):
     def __init__(self):
         self.recorders: List[Recorder] = []
         self.stream: Optional[int] = None
+        self.side: Optional[int] = None
+
+
+JOIN = object()     # marker in Recorder.calls: (JOIN, k)
+
+
+class side_branch:
+    """Calls made inside `with side_branch(k):` are independent of the main-stream calls that follow them until
+    `join(k)`: when the recording is captured as a graph they run on side stream k (a parallel path).  While recording
+    (and in launch-by-launch replay) they simply run in program order on the one stream."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def __enter__(self):
+        self.prev = _state.side
+        _state.side = self.k
+        return self
+
+    def __exit__(self, *exc):
+        _state.side = self.prev
+        return False
+
+
+def join(k: int):
+    """Everything recorded after this point may depend on the calls of side branch k."""
+    for r in _state.recorders:
+        r.calls.append((JOIN, k))
 
 
 _state = _State()
@@ -228,7 +283,7 @@ def call(name: str, *args, keep=()):
     if rc != 0:
         raise OsmosisHipError(f"{name} failed ({rc}): {lib.osm_last_error().decode()}")
     for r in _state.recorders:
-        r.calls.append((fn, args))
+        r.calls.append((fn, args) if _state.side is None else (fn, args, _state.side))
         r.keep.extend(keep)
         r.keep.extend(a for a in args if isinstance(a, C.Structure) or hasattr(a, "_obj"))
 

@@ -19,6 +19,7 @@ Design (MI355X-first, not a module-by-module translation):
 Per ResBlock (unet.py:315-335):   GN+SiLU -> [pool|upsample] -> conv3x3 -> GN*(1+s)+t, SiLU -> conv3x3 (+skip)
 Per AttentionBlock (:378-433):    GN -> qkv 1x1 -> per-head softmax(q k^T / sqrt(ch)) v -> proj 1x1 (+x)
 """
+import contextlib
 import math
 import os
 from typing import Dict, List, Optional, Tuple
@@ -26,7 +27,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import OsmosisHipError, Recorder, current_stream_ptr
+from ._lib import OsmosisHipError, Recorder, current_stream_ptr, join, side_branch
 from .ops import Mat
 
 G = 32  # GroupNorm32 groups (nn.py:93-100)
@@ -236,6 +237,10 @@ class UNetEngine:
         # the forward statistics of a ResBlock's second GroupNorm come from its first convolution; "all": also the two
         # backward reductions, from the data-gradient convolutions (measured a net loss: the epilogue must re-read the
         # GroupNorm input with 4-byte accesses: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1); "0": neither
+        # independent branches (a ResBlock's 1x1 skip convolution, forward and data-gradient) as parallel graph paths.
+        # OFF by default: measured 31.98 vs 31.54 ms / step -- the memory-bound 1x1 next to the power-limited 3x3 slows
+        # the 3x3 by more than it hides (OSM_SIDE_STREAMS=1 to enable)
+        self.side_streams = self.use_graph and os.environ.get("OSM_SIDE_STREAMS", "0") != "0"
         fs = os.environ.get("OSM_FUSE_STATS", "fwd")
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs == "all"
@@ -279,7 +284,7 @@ class UNetEngine:
         return t[:n]
 
     def _conv(self, x: Mat, cv: _Conv, y: Mat, hw: Tuple[int, int], dgrad=False, res: Optional[Mat] = None,
-              accumulate=False, gn_table=None, gn_silu=True, stat=None):
+              accumulate=False, gn_table=None, gn_silu=True, stat=None, ws_slot="splitk"):
         """stat: None, ("fwd",) -- also emit the per-column (sum, sum of squares) of y for the GroupNorm that reads it --
         or ("bwd", x_gn, table) -- y is the gradient w.r.t. SiLU(GN(x_gn)): emit that GroupNorm's two backward
         reductions.  Returns (colsum, chunks per image) when the layer's kernel produced them, else None (the caller
@@ -292,7 +297,7 @@ class UNetEngine:
         sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, cv.wfmt, gn_table is not None)
         ws = None
         if sk > 1:
-            ws = self._scr_flat("splitk", sk * M * cout)
+            ws = self._scr_flat(ws_slot, sk * M * cout)
         cs, nch, skw = None, 0, {}
         if stat is not None and self.fuse_stats:
             nch = ops.conv_stat_chunks(self.B, H, W, cin, cout, cv.k, cv.wfmt, sk, gn_table is not None)
@@ -371,11 +376,16 @@ class UNetEngine:
             # the per-channel GroupNorm tables are kept: the data-gradient convolutions fold the GroupNorm-backward
             # reductions into their epilogues with them (see _res_bwd)
             tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._gn_fusable(blk.c1, hw)) else None
+            if blk.skip is not None:
+                # the 1x1 skip convolution depends on x only: a parallel path of the graph next to GN -> conv3x3 -> GN
+                # (memory-bound 1x1 beside the MFMA-bound 3x3); joined before the second 3x3 adds it as its residual
+                with side_branch(1) if self.side_streams else contextlib.nullcontext():
+                    self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1, stat=("fwd",) if fuse2 else None)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         if blk.skip is not None:
-            self._conv(xs, blk.skip, dst, (ho, wo))
+            join(1)
             res = dst
         else:
             res = xs
@@ -390,6 +400,9 @@ class UNetEngine:
         H, W = s["hw"]
         ho, wo = s["hwo"]
         M, Mo = B * H * W, B * ho * wo
+        if blk.skip is not None:      # skip-path gradient: independent of the main chain until the final GroupNorm apply
+            with side_branch(1) if self.side_streams else contextlib.nullcontext():
+                self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2")
         dh2 = self._scr("a", Mo, blk.cout)
         # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
         # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
@@ -429,7 +442,7 @@ class UNetEngine:
             add = t
             add2 = dx_dst if accumulate else None
         elif blk.skip is not None:
-            self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate)
+            join(1)
             add = dx_dst
         else:
             add = dy
