@@ -104,6 +104,19 @@ long long osm_packed_weight_elems(int Cout, int Cin, int ksize, int wfmt, int dg
 int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize,
                                int wfmt, void* stream);
 
+/* Winograd F(2x2, 3x3) weight images (fp32 family; 3x3, stride 1): U = G g G^T of every (Cout, Cin) filter, formed
+ * in double, rounded to fp32 and split into `wfmt` (2 / 3) bf16 planes, in MFMA-fragment order
+ * [plane][xi = 16 transform positions][16-channel slab][n/32][lane][8].  A layer with osm_conv_winograd_ok(...) == 1
+ * (H, W >= 16, Cin >= 16, Cout >= 64) may be run with desc.w = such an image and desc.wfmt = wfmt | OSM_WFMT_WINOGRAD:
+ * 2.25x fewer MFMAs than the direct kernel, same fp32-class result (the transforms add roughly one more fp32 rounding
+ * per operand).  gn_table, splitk, res / bias / accumulate work as in the direct kernel; colsum only with splitk > 1
+ * (osm_conv_stat_chunks / osm_conv_splitk take the flagged wfmt). */
+#define OSM_WFMT_WINOGRAD 0x10
+int osm_conv_winograd_ok(int H, int W, int Cin, int Cout, int ksize, int wfmt);
+long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int dgrad);
+int osm_pack_conv_weight_winograd(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int wfmt,
+                                  void* stream);
+
 int osm_gemm(const osm_gemm_desc* d, void* stream);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);

@@ -74,6 +74,8 @@ _SIGS = {
     "osm_pack_conv_weight_bf16s": [_P, _P, _P, _I, _I, _I, _I, _P],
     "osm_splitk_hint": [_I, _I, _I, _I, _I],
     "osm_conv_splitk": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "osm_conv_winograd_ok": [_I, _I, _I, _I, _I, _I],
+    "osm_pack_conv_weight_winograd": [_P, _P, _P, _I, _I, _I, _P],
     "osm_conv_stat_chunks": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
     "osm_gn_finalize_cols": [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _LL, _P, _P],
     "osm_gn_bwd_apply": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _P, _LL, _I, _P],
@@ -115,7 +117,7 @@ for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm
     _SIGS[_n + "_h"] = _SIGS[_n]
 _SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]
 _SIGS["osm_f32_to_half"] = [_P, _LL, _P, _LL, _LL, _I, _P]
-EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems"])
+EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems", "osm_winograd_weight_elems"])
 
 _lib = None
 _lock = threading.Lock()
@@ -140,6 +142,8 @@ def load():
                 fn.restype = C.c_int
             lib.osm_packed_weight_elems.argtypes = [_I, _I, _I, _I, _I]
             lib.osm_packed_weight_elems.restype = C.c_longlong
+            lib.osm_winograd_weight_elems.argtypes = [_I, _I, _I, _I]
+            lib.osm_winograd_weight_elems.restype = C.c_longlong
             lib.osm_last_error.argtypes = []
             lib.osm_last_error.restype = C.c_char_p
             _lib = lib

@@ -466,6 +466,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 #include "igemm_bf16s.inc.h"
 #include "conv3_halo.inc.h"
+#include "conv3_wino.inc.h"
 #include "skinny.inc.h"
 
 // ---- small-M path (skinny.inc.h): eligibility and its split of K
@@ -518,7 +519,10 @@ bool halo_enabled() {
   return on;
 }
 
-int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
+// Winograd F(2x2, 3x3) path (conv3_wino.inc.h): 3x3, split-bf16 image in the Winograd domain, fp32 activations
+bool wino_shape_ok(int H, int W, int K, int N) { return H >= 16 && W >= 16 && K >= 16 && N >= 64 && N % 32 == 0; }
+
+int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bool wino = false) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
   p.nchunks = taps * ((p.K + BK - 1) / BK);
@@ -530,6 +534,34 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
 #else
   if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
 #endif
+#ifndef OSM_ACT_F16
+  if (wino) {
+    if (!(taps == 9 && (wfmt == 2 || wfmt == 3) && wino_shape_ok(p.H, p.W, p.K, p.N)))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 2 / 3, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
+    if (p.colsum && p.splitk <= 1)
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel emits column sums through the split-K combine only");
+    if (!(p.ldc % 4 == 0 && osm::aligned16(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned16(p.res))) &&
+          (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 16-byte vectors: ldy, ldr multiples of 4, aligned y / res / bias");
+    const int nimg = p.M / (p.H * p.W);
+    p.mtiles = nimg * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+    p.ntiles = (p.N + 63) / 64;
+    p.nchunks = p.ksteps;                       // 16-channel slabs
+    if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+    const unsigned short* Up = reinterpret_cast<const unsigned short*>(p.Bm);
+    const dim3 gw(p.mtiles * p.ntiles, p.splitk, 1);
+    if (wfmt == 3) {
+      if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<3, true>), gw, dim3(256), 0, st, p.A, Up, p);
+      else hipLaunchKernelGGL((conv3_wino_kernel<3, false>), gw, dim3(256), 0, st, p.A, Up, p);
+    } else {
+      if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<2, true>), gw, dim3(256), 0, st, p.A, Up, p);
+      else hipLaunchKernelGGL((conv3_wino_kernel<2, false>), gw, dim3(256), 0, st, p.A, Up, p);
+    }
+  } else
+#else
+  if (wino) return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd path serves the fp32 family only");
+#endif
+  {
   const bool halo_path = wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled();
   if (p.colsum && (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) || wfmt == 0 || !(halo_path || p.splitk > 1)))
     return osm::fail(OSM_ERR_UNSUPPORTED, "column sums are produced by the halo-tile kernel or the split-K combine only "
@@ -619,6 +651,7 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0) {
     hipLaunchKernelGGL((igemm_f32_kernel<1, false>), grid, dim3(256), 0, st, p.A, p.Bm, p);
   }
 #endif
+  }
   int rc = osm::check_launch("igemm kernel");
   if (rc) return rc;
   if (p.splitk > 1 && p.colsum) {
@@ -667,6 +700,14 @@ extern "C" int osm_splitk_hint(int M, int N, int K, int taps, int nbatch) {
 // split-K factor osm_conv2d_nhwc(_h) wants for a layer (callers size the fp32 workspace splitk * M * Cout from it)
 extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int has_gn_table) {
   const int M = B * H * W;
+  if (wfmt & OSM_WFMT_WINOGRAD) {   // workgroups of 16 x 16 pixels x 64 columns, 16-channel slabs, one workgroup per CU
+    const long long tiles = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + 63) / 64);
+    const int nslab = 2 * ((Cin + 31) / 32);
+    if (tiles >= 192) return 1;
+    long long s = (256 + tiles - 1) / tiles;
+    if (s > nslab / 4) s = nslab / 4;
+    return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
+  }
   if (skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return skinny_gridy(M, Cout, Cin, ksize * ksize);
   return osm_splitk_hint(M, Cout, Cin, ksize * ksize, 1);
 }
@@ -674,6 +715,11 @@ extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize
 extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int splitk,
                                     int has_gn_table) {
   const int M = B * H * W;
+  if (wfmt & OSM_WFMT_WINOGRAD) {
+    const int nslab = 2 * ((Cin + 31) / 32);
+    if (splitk > nslab) splitk = nslab;
+    return (splitk > 1 && Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
+  }
   if (wfmt == 0 || skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return 0;
   const bool halo = ksize == 3 && W >= 8 && H >= 8 && halo_enabled();
   // the split launch() will really use: it is clamped to the number of K chunks (32-channel slabs of the halo kernel /
@@ -683,6 +729,31 @@ extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int 
   if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
   if (halo) return ((H + (tall_ok(M, H, W) ? 15 : 7)) / (tall_ok(M, H, W) ? 16 : 8)) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
   return 0;
+}
+
+// 1 when a layer may be given a Winograd weight image (OSM_WFMT_WINOGRAD): 3x3, stride 1, wfmt 2 / 3, fp32 family
+extern "C" int osm_conv_winograd_ok(int H, int W, int Cin, int Cout, int ksize, int wfmt) {
+  return ksize == 3 && (wfmt == 2 || wfmt == 3) && wino_shape_ok(H, W, Cin, Cout) ? 1 : 0;
+}
+extern "C" long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int dgrad) {
+  const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  return (long long)wfmt * 16 * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // bf16 (uint16) elements
+}
+extern "C" int osm_pack_conv_weight_winograd(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int wfmt,
+                                             void* stream) {
+  OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_winograd: null pointer");
+  OSM_REQUIRE(wfmt == 2 || wfmt == 3, "osm_pack_conv_weight_winograd: wfmt must be 2 or 3 (bf16 planes)");
+  for (int dg = 0; dg < 2; ++dg) {
+    unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
+    if (!out) continue;
+    const long long per_plane = osm_winograd_weight_elems(Cout, Cin, wfmt, dg) / wfmt;
+    int blocks = (int)((per_plane + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, wfmt, dg);
+    int rc = osm::check_launch("pack_weight_wino_kernel");
+    if (rc) return rc;
+  }
+  return OSM_OK;
 }
 #endif   // !OSM_ACT_F16
 
@@ -708,7 +779,7 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   p.tapstrideB = (long long)d->Cout * d->Cin;
   p.nb1 = 1; p.nbatch = 1;
   if (d->gn_table) {
-    OSM_REQUIRE(d->wfmt != 0 && d->ksize == 3 && d->W >= 8 && d->H >= 8 && halo_enabled(),
+    OSM_REQUIRE((d->wfmt & ~OSM_WFMT_WINOGRAD) != 0 && d->ksize == 3 && d->W >= 8 && d->H >= 8 && halo_enabled(),
                 "osm_conv2d_nhwc: gn_table needs the halo-tile kernel (3x3, split-bf16 weights, W >= 8, H >= 8)");
     OSM_REQUIRE(osm::aligned16(d->gn_table), "osm_conv2d_nhwc: gn_table must be 16-byte aligned");
     p.gn_table = d->gn_table;
@@ -721,12 +792,16 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
     p.colsum = d->colsum; p.stat_mode = d->stat_mode; p.stat_silu = d->stat_silu;
     p.stat_x = OSM_CACT(d->stat_x); p.ld_sx = d->ld_sx; p.stat_table = d->stat_table;
   }
-  if (d->wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
-    OSM_REQUIRE(d->wfmt >= 1 && d->wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");
+  const bool wino = (d->wfmt & OSM_WFMT_WINOGRAD) != 0;
+  const int wfmt = d->wfmt & ~OSM_WFMT_WINOGRAD;
+  OSM_REQUIRE(!wino || (d->ksize == 3 && (wfmt == 2 || wfmt == 3)),
+              "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 2 / 3");
+  if (wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
+    OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");
     p.nt32 = (d->Cout + 31) / 32;
     p.ksteps = 2 * ((d->Cin + 31) / 32);
   }
-  return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream, d->wfmt);
+  return launch(p, d->ksize * d->ksize, false, (hipStream_t)stream, wfmt, wino);
 }
 
 #ifndef OSM_ACT_F16

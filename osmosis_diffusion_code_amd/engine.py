@@ -33,6 +33,11 @@ from .ops import Mat
 G = 32  # GroupNorm32 groups (nn.py:93-100)
 
 
+def _winograd_on() -> bool:
+    """OSM_WINOGRAD=0: direct halo-tile kernel on every 3x3 layer (A/B measurements)."""
+    return os.environ.get("OSM_WINOGRAD", "1") != "0"
+
+
 class _Conv:
     def __init__(self, slot, dev, wfmt=0):
         w = slot.weight.detach().to(dev, torch.float32)
@@ -40,6 +45,11 @@ class _Conv:
         self.k = w.shape[2] if w.dim() == 4 else 1
         self.wfmt = wfmt
         self.wf, self.wd = ops.pack_conv_weight(w, wfmt=wfmt)
+        # Winograd F(2x2, 3x3) images next to the direct ones (the layer picks per (H, W): 16 x 16 and larger)
+        self.wwf = self.wwd = None
+        if self.k == 3 and wfmt in (2, 3) and _winograd_on() and ops.conv_winograd_ok(16, 16, self.cin, self.cout, 3, wfmt) \
+                and ops.conv_winograd_ok(16, 16, self.cout, self.cin, 3, wfmt):
+            self.wwf, self.wwd = ops.pack_conv_weight_winograd(w, wfmt=wfmt)
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
 
 
@@ -241,6 +251,7 @@ class UNetEngine:
         # OFF by default: measured 31.98 vs 31.54 ms / step -- the memory-bound 1x1 next to the power-limited 3x3 slows
         # the 3x3 by more than it hides (OSM_SIDE_STREAMS=1 to enable)
         self.side_streams = self.use_graph and os.environ.get("OSM_SIDE_STREAMS", "0") != "0"
+        self.winograd_min_hw = int(os.environ.get("OSM_WINOGRAD_MIN_HW", "16"))   # smallest H, W served by the Winograd kernel
         fs = os.environ.get("OSM_FUSE_STATS", "fwd")
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs == "all"
@@ -294,20 +305,24 @@ class UNetEngine:
         cin = cv.cout if dgrad else cv.cin
         cout = cv.cin if dgrad else cv.cout
         assert x.cols == cin and y.cols == cout and x.rows == M and y.rows == M, (x.cols, cin, y.cols, cout)
-        sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, cv.wfmt, gn_table is not None)
+        wfmt, wimg = cv.wfmt, (cv.wd if dgrad else cv.wf)
+        if cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
+                ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt):
+            wfmt, wimg = cv.wfmt | ops.WINOGRAD, (cv.wwd if dgrad else cv.wwf)
+        sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, wfmt, gn_table is not None)
         ws = None
         if sk > 1:
             ws = self._scr_flat(ws_slot, sk * M * cout)
         cs, nch, skw = None, 0, {}
         if stat is not None and self.fuse_stats:
-            nch = ops.conv_stat_chunks(self.B, H, W, cin, cout, cv.k, cv.wfmt, sk, gn_table is not None)
+            nch = ops.conv_stat_chunks(self.B, H, W, cin, cout, cv.k, wfmt, sk, gn_table is not None)
             if nch > 0:
                 cs = self._scr_flat("colsum", self.B * nch * 2 * cout)      # consumed by the finalize that follows
                 skw = dict(colsum=cs, stat_mode=1)
                 if stat[0] == "bwd":
                     skw = dict(colsum=cs, stat_mode=2, stat_x=stat[1], stat_table=stat[2], stat_silu=True)
-        ops.conv2d(x, cv.wd if dgrad else cv.wf, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
-                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=cv.wfmt, gn_table=gn_table, gn_silu=gn_silu,
+        ops.conv2d(x, wimg, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
+                   accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=wfmt, gn_table=gn_table, gn_silu=gn_silu,
                    **skw)
         return (cs, nch) if cs is not None else None
 

@@ -77,7 +77,7 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.stat_x, d.ld_sx = (stat_x.p, stat_x.ld) if stat_x is not None else (None, 0)
     d.stat_table = ptr(stat_table)
     fam = _same_family(x.t, y.t, res.t if res is not None else None, stat_x.t if stat_x is not None else None)
-    if (fam == "_h") != (wfmt == 1):
+    if (fam == "_h") != ((wfmt & ~WINOGRAD) == 1):
         raise _lib.OsmosisHipError("fp16 activations go with the fp16 weight image (wfmt 1), fp32 with 0 / 2 / 3")
     call("osm_conv2d_nhwc" + fam, C.byref(d), _s(),
          keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table, colsum,
@@ -87,6 +87,23 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
 # conv arithmetic modes: weight-image format code of the C ABI
 # "f16": activations AND weights in IEEE half, fp32 accumulation (the reference's use_fp16): fp16-storage family
 WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}
+WINOGRAD = 0x10   # OSM_WFMT_WINOGRAD: the weight image is in the Winograd F(2x2, 3x3) domain (pack_conv_weight_winograd)
+
+
+def conv_winograd_ok(H, W, Cin, Cout, ksize, wfmt) -> bool:
+    return bool(query("osm_conv_winograd_ok", H, W, Cin, Cout, ksize, wfmt))
+
+
+def pack_conv_weight_winograd(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True, wfmt: int = 3):
+    """OIHW 3x3 -> (fwd, dgrad) Winograd-domain split-bf16 images; run them with conv2d(wfmt=wfmt | WINOGRAD)."""
+    w = w_oihw.contiguous()
+    O, I = w.shape[0], w.shape[1]
+    assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    lib = _lib.load()
+    wf = torch.empty(lib.osm_winograd_weight_elems(O, I, wfmt, 0), device=w.device, dtype=torch.int16) if want_fwd else None
+    wd = torch.empty(lib.osm_winograd_weight_elems(O, I, wfmt, 1), device=w.device, dtype=torch.int16) if want_dgrad else None
+    call("osm_pack_conv_weight_winograd", ptr(w), ptr(wf), ptr(wd), O, I, wfmt, _s(), keep=(w, wf, wd))
+    return wf, wd
 
 
 def pack_conv_weight(w_oihw: torch.Tensor, want_fwd=True, want_dgrad=True, wfmt: int = 0):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--mode", default="bf16x6")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--winograd", action="store_true", help="Winograd F(2x2,3x3) image where the layer allows it")
+    ap.add_argument("--dgrad", action="store_true", help="run the data-gradient image (Cout -> Cin)")
     a = ap.parse_args()
     shapes = a.shape or ["1,256,256,256,256,3", "1,128,128,512,512,3", "1,128,128,256,256,3", "1,64,64,512,512,3",
                          "1,32,32,512,512,3", "1,16,16,1024,1024,3", "1,8,8,1024,1024,3", "1,256,256,256,512,1"]
@@ -34,7 +36,9 @@ def main():
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, device=dev, generator=g)
         y = torch.empty(M, Cout, device=dev, dtype=adt)
-        wf, _ = ops.pack_conv_weight(w, wfmt=wfmt)
+        wino = a.winograd and ops.conv_winograd_ok(H, W, Cin, Cout, k, ops.WFMT[a.mode])
+        wfmt = ops.WFMT[a.mode] | (ops.WINOGRAD if wino else 0)
+        wf, _ = (ops.pack_conv_weight_winograd(w, wfmt=wfmt & 3) if wino else ops.pack_conv_weight(w, wfmt=wfmt))
         sk = ops.conv_splitk(B, H, W, Cin, Cout, k, wfmt)
         ws = torch.empty(sk * M * Cout, device=dev) if sk > 1 else None
         run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt)  # noqa: E731
@@ -49,7 +53,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         fl = 2.0 * M * Cin * Cout * k * k
-        msg = f"{a.mode:7s} {s:28s} splitk={sk:2d}  {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s"
+        msg = f"{a.mode + ('+wino' if wino else ''):12s} {s:28s} splitk={sk:2d}  {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s"
         if a.check:
             ref = torch.nn.functional.conv2d(x.float().view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
             err = float((y.float().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
