@@ -147,6 +147,8 @@ def roofline(model, args):
             # split-bf16 modes: layers with W >= 16 run the halo-tile kernel (the dominant one), the 8x8
             # layers the tap-chunked kernel
             halo = args.conv_mode != "f32" and d.W >= 16 and d.H >= 8
+            if d.wfmt & 0x10:            # OSM_WFMT_WINOGRAD: the F(2x2, 3x3) kernel (executes 16/36 of the algorithmic flops)
+                wino_shapes.add(shape)
             return ("conv3x3" if halo or args.conv_mode == "f32" else "conv3x3_8x8", fl, shape)
         if name == "osm_gemm":
             d = a[0]._obj
@@ -182,6 +184,7 @@ def roofline(model, args):
 
     agg = {}
     per_shape = {}
+    wino_shapes = set()
     reps = 3
     for _ in range(reps):
         for plan in (eng._fwd_plan, eng._bwd_plan):
@@ -203,6 +206,10 @@ def roofline(model, args):
             json.dump(rows, f, indent=0)
     c = out["conv3x3"]
     achieved = c["gflop_per_step"] / c["ms_per_step"]  # GFLOP/ms == TFLOP/s
+    # share of the 3x3 class served by the Winograd kernel (time, algorithmic flops)
+    w_ms = sum(per_shape[k][0] for k in wino_shapes) / reps
+    w_gf = sum(per_shape[k][2] * per_shape[k][1] for k in wino_shapes) / reps / 1e9
+    wino_dominant = w_ms > 0.5 * c["ms_per_step"]
     # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py); null when none is committed.
     traffic, traffic_src = None, None
@@ -211,9 +218,11 @@ def roofline(model, args):
         try:
             pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
                     "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1"}[args.conv_mode]
+            if wino_dominant:
+                pref = pref.replace("conv3_halo_bf16s_kernel", "conv3_wino_kernel")
             hit = [k for k in json.load(open(path))["kernels"]
                    if k["kernel"].replace(" ", "").startswith(pref)
-                   and (args.conv_mode == "f32"                         # template <NP, GN, PW, BR, PH>: PW = 16 patches
+                   and (args.conv_mode == "f32" or wino_dominant        # template <NP, GN, PW, BR, PH>: PW = 16 patches
                         or (k["kernel"].replace(" ", "").split("<")[1].rstrip(">").split(",") + ["", "", ""])[2] == "16")]
             if hit:   # launch-weighted mean over the template instances of the dominant kernel
                 traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in hit) / sum(k["launches"] for k in hit))
@@ -238,6 +247,15 @@ def roofline(model, args):
                 "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one v_mfma_f32_32x32x16_f16 "
                 "per product; peak = dense fp16 MFMA peak 2500 TFLOP/s"),
     }[args.conv_mode]
+    extra = {}
+    if wino_dominant:
+        kname = kname.replace("conv3_halo_bf16s_kernel", "conv3_wino_kernel")
+        note += ("; " + f"{100.0 * w_ms / c['ms_per_step']:.0f} % of the 3x3 time ({100.0 * w_gf / c['gflop_per_step']:.0f} % of its flops) runs "
+                 "the Winograd F(2x2,3x3) kernel, which EXECUTES 16/36 of the algorithmic multiply-adds: `achieved` stays "
+                 "algorithmic (what a direct convolution would have to do), `executed_tflops` is what the matrix cores did")
+        executed = (c["gflop_per_step"] - w_gf * (1.0 - 16.0 / 36.0)) / c["ms_per_step"]
+        extra = {"winograd_share_of_time": round(w_ms / c["ms_per_step"], 4), "executed_tflops": round(executed, 2),
+                 "executed_frac": round(executed / peak, 4)}
     att = {k: out[k] for k in ("attention_core", "attn_gemm", "softmax") if k in out}
     if att:
         ams = sum(v["ms_per_step"] for v in att.values())
@@ -251,7 +269,7 @@ def roofline(model, args):
                     "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound"}
     return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4),
+            "frac": round(achieved / peak, 4), **extra,
             "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # 157.3 TF: the exact-fp32 MFMA / vector peak
             "traffic": traffic, "traffic_source": traffic_src,
             # achieved HBM GB/s of the conv kernel (north_star asks for it; the kernel is MFMA-bound, not HBM-bound):

@@ -548,6 +548,10 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     p.ntiles = (p.N + 63) / 64;
     p.nchunks = p.ksteps;                       // 16-channel slabs
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+    // column tiles that share an input patch in time (conv3_wino.inc.h, tile mapping): the largest divisor of ntiles <= 4
+    static const int ngrp = [] { const char* e = std::getenv("OSM_WINO_NGROUP"); return e ? atoi(e) : 4; }();
+    p.nb1 = 1;
+    for (int g = 2; g <= ngrp; ++g) if (p.ntiles % g == 0) p.nb1 = g;
     const unsigned short* Up = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 gw(p.mtiles * p.ntiles, p.splitk, 1);
     if (wfmt == 3) {

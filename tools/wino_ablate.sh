@@ -1,12 +1,18 @@
-# builds ablated variants of the library (Winograd kernel with one stage removed) and times them: where does the time go?
-cd /root/repo/osmosis_diffusion_code_amd/csrc
-for v in 16 32; do
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWN_ABL=$v -c igemm.hip -o /tmp/igemm_abl$v.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_abl$v.o norm.o elementwise.o guidance.o attention.o flash.o igemm_h.o norm_h.o elementwise_h.o -o /tmp/libosm_abl$v.so ) &
-done
+# measurement builds of the library (Winograd kernel variants selected by -D flags) timed against the normal build
+V=$(readlink -f "$1"); cd /root/repo/osmosis_diffusion_code_amd/csrc
+i=0
+while read -r flags; do
+  i=$((i+1))
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c igemm.hip -o /tmp/igemm_v$i.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_v$i.o norm.o elementwise.o guidance.o attention.o flash.o igemm_h.o norm_h.o elementwise_h.o -o /tmp/libosm_v$i.so ) &
+done < "$V"
 wait
 cd /root/repo
-for v in 16 32; do
-  echo "== WN_ABL=$v"
-  OSM_LIB=/tmp/libosm_abl$v.so timeout 200 python tools/conv_probe.py --shape 1,256,256,256,256,3 --shape 1,128,128,512,512,3 --iters 20 --winograd --check 2>&1 | grep wino
-done
+SH="--shape 1,256,256,256,256,3 --shape 1,128,128,512,512,3 --shape 1,64,64,1024,512,3"
+echo "== normal"; timeout 200 python tools/conv_probe.py $SH --iters 20 --winograd --check 2>&1 | grep wino
+i=0
+while read -r flags; do
+  i=$((i+1))
+  echo "== $flags"
+  OSM_LIB=/tmp/libosm_v$i.so timeout 200 python tools/conv_probe.py $SH --iters 20 --winograd --check 2>&1 | grep wino
+done < "$V"
