@@ -31,6 +31,9 @@
 
 #ifndef OSM_ACT_F16
 
+#ifndef WN_VPM
+#define WN_VPM 5      // VALU instructions asked for after every MFMA of a region
+#endif
 #ifndef WN_ABL
 #define WN_ABL 0        // measurement builds (tools/wino_ablate.sh): 1 no activation loads, 2 no U loads
 #endif
@@ -120,28 +123,32 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   float4 gm, gr, gg, gb;
   gm = gr = gg = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
-  unsigned okm = 0;
   uint4 uq[4][2][NP];       // [xi column j][column tile][plane]: filled two xi ahead of their use
 
-#define OSM_W_LOAD_RAW(cc_)                                                                \
+// activation pieces j0_ .. j0_ + n_ - 1 of slab cc_ -> registers; the GroupNorm table rows of the slab with piece 0 ... 
+#define OSM_W_LOAD_RAW(cc_, j0_, n_)                                                       \
   {                                                                                        \
     const bool cok_ = (cc_) * 16 + 4 * q4 < p.K;                                           \
     const unsigned d_ = (unsigned)((cc_) * 64 + 16 * q4);                                  \
-    okm = cok_ ? vmask : 0u;                                                               \
-    _Pragma("unroll") for (int j = 0; j < WN_NJ; ++j)                                      \
+    _Pragma("unroll") for (int j = (j0_); j < (j0_) + (n_); ++j)                           \
       ra[j] = (WN_ABL & 1) ? make_float4(1.f, 2.f, 3.f, (float)d_)                         \
                            : *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u))); \
-    if (GNF) {                                                                             \
-      const float* gt_ = gtab + (cok_ ? (cc_) * 16 + 4 * q4 : 0);                          \
-      gm = *reinterpret_cast<const float4*>(gt_);                                          \
-      gr = *reinterpret_cast<const float4*>(gt_ + p.K);                                    \
-      gg = *reinterpret_cast<const float4*>(gt_ + 2 * p.K);                                \
-      gb = *reinterpret_cast<const float4*>(gt_ + 3 * p.K);                                \
-    }                                                                                      \
   }
-#define OSM_W_STORE_RAW(buf_)                                                              \
+// ... are loaded separately: they must outlive the stores of the previous slab
+#define OSM_W_LOAD_TAB(cc_)                                                                \
+  if (GNF) {                                                                               \
+    const bool cok_ = (cc_) * 16 + 4 * q4 < p.K;                                           \
+    const float* gt_ = gtab + (cok_ ? (cc_) * 16 + 4 * q4 : 0);                            \
+    gm = *reinterpret_cast<const float4*>(gt_);                                            \
+    gr = *reinterpret_cast<const float4*>(gt_ + p.K);                                      \
+    gg = *reinterpret_cast<const float4*>(gt_ + 2 * p.K);                                  \
+    gb = *reinterpret_cast<const float4*>(gt_ + 3 * p.K);                                  \
+  }
+// pieces j0_ .. of slab cc_ (in registers) -> LDS buffer cc_ & 1, GroupNorm(+SiLU) applied, zero outside image / channels
+#define OSM_W_STORE_RAW(cc_, j0_, n_)                                                      \
   {                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < WN_NJ; ++j) {                                    \
+    const unsigned okm_ = ((cc_) * 16 + 4 * q4 < p.K) ? vmask : 0u;                        \
+    _Pragma("unroll") for (int j = (j0_); j < (j0_) + (n_); ++j) {                         \
       float4 v = ra[j];                                                                    \
       if (GNF) {                                                                           \
         v.x = ((v.x - gm.x) * gr.x) * gg.x + gb.x;                                         \
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
           v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w); \
         }                                                                                  \
       }                                                                                    \
-      raw[(buf_) * (4 * WN_QP) + woff[j]] = sel4((okm >> j) & 1u, v);                      \
+      raw[((cc_) & 1) * (4 * WN_QP) + woff[j]] = sel4((okm_ >> j) & 1u, v);                \
     }                                                                                      \
   }
 #define OSM_W_LOAD_U(cc_, j_)                                                              \
@@ -164,87 +171,135 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
             : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(             \
                   ursrc, (int)u_lane, (int)(so_ + (unsigned)q2 * u_plane + (unsigned)b * u_nt), 0)); \
   }
-// t column j_ of both tile blocks: 8 LDS reads (2 rows x 2 channel quads x 2 blocks), t = x + sg y
-#define OSM_W_TCOL(j_)                                                                     \
+// t column j_ of both tile blocks: 8 LDS reads (2 rows x 2 channel quads x 2 blocks) into qx / qy ...
+#define OSM_W_TRD(j_, bo_)                                                                 \
   _Pragma("unroll") for (int a = 0; a < 2; ++a)                                            \
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                        \
-      const int o_ = bo + h * WN_QP + 8 * a * WN_ROWP + ((j_) & 1) * 10 + ((j_) >> 1);     \
-      const osm::floatx4_t x_ = t_x[o_], y_ = t_y[o_];                                     \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) tc[j_][a][4 * h + e] = fmaf(sg, y_[e], x_[e]); \
+      const int o_ = (bo_) + h * WN_QP + 8 * a * WN_ROWP + ((j_) & 1) * 10 + ((j_) >> 1);  \
+      qx[a][h] = t_x[o_];                                                                  \
+      qy[a][h] = t_y[o_];                                                                  \
     }
-// V_xi for xi column jv_ = sa_ t[ja_] + sb_ t[jb_], split into the NP planes of the two A fragments
-#define OSM_W_VFRAG(ja_, sa_, jb_, sb_)                                                    \
-  _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                          \
-    float f_[8];                                                                           \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) f_[e] = (sa_) * tc[ja_][a][e] + (sb_) * tc[jb_][a][e]; \
-    split_frag8<NP>(make_float4(f_[0], f_[1], f_[2], f_[3]), make_float4(f_[4], f_[5], f_[6], f_[7]), va[a]); \
-  }
-#define OSM_W_MMA(j_, pa_, pb_)                                                            \
+// ... and t = x + sg y
+#define OSM_W_TFMA(j_)                                                                     \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)                                            \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) tc[j_][a][4 * h + e] = fmaf(sg, qy[a][h][e], qx[a][h][e]);
+// V of tile block a_: f = sa_ t[ja_] + sb_ t[jb_] ...
+#define OSM_W_VADD(a_, ja_, sa_, jb_, sb_)                                                 \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) vf[a_][e] = (sa_) * tc[ja_][a_][e] + (sb_) * tc[jb_][a_][e];
+// ... split: half h_ (4 channels) of tile block a_ -> NP x 2 packed dwords
+#define OSM_W_VSPL(a_, h_)                                                                 \
+  split_planes<NP>(make_float4(vf[a_][4 * (h_)], vf[a_][4 * (h_) + 1], vf[a_][4 * (h_) + 2], vf[a_][4 * (h_) + 3]), vh[a_][h_]);
+// ... the two halves are one 16-byte A fragment per plane
+#define OSM_W_VFIN(par_, a_)                                                               \
+  _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                        \
+    va[par_][a_][q2] = make_uint4(vh[a_][0][q2].x, vh[a_][0][q2].y, vh[a_][1][q2].x, vh[a_][1][q2].y);
+#define OSM_W_MMA(j_, par_, pa_, pb_)                                                      \
   if ((pa_) < NP && (pb_) < NP) {                                                          \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                          \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
-        acc[j_][a][b] = mma16<NP>(va[a][pa_], uq[j_][b][pb_], acc[j_][a][b]);              \
+        acc[j_][a][b] = mma16<NP>(va[par_][a][pa_], uq[j_][b][pb_], acc[j_][a][b]);        \
   }
-#define OSM_W_MMAS(j_)                                                                     \
-  OSM_W_MMA(j_, 2, 0) OSM_W_MMA(j_, 1, 1) OSM_W_MMA(j_, 1, 0) OSM_W_MMA(j_, 0, 2) OSM_W_MMA(j_, 0, 1) OSM_W_MMA(j_, 0, 0)
+// end of a unit = { 4 MFMAs (one plane pair) + a piece of the preparation of the next xi column }: ask for the VALU
+// instructions BETWEEN the MFMAs (one wave per SIMD: <= 5-6 single-issue instructions are free per 32-cycle MFMA),
+// and let nothing cross the unit boundary
+#define OSM_W_UNIT()                                                                       \
+  {                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+      __builtin_amdgcn_sched_group_barrier(0x002, WN_VPM, 0);                              \
+    }                                                                                      \
+    asm volatile("" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  }
+// region = the six units of xi column j_ (operands va[par_]); P0_ .. P5_ = what each unit does besides its MFMAs
+#define OSM_W_REGION(j_, par_, P0_, P1_, P2_, P3_, P4_, P5_)                               \
+  OSM_W_MMA(j_, par_, 2, 0) P0_ OSM_W_UNIT()                                               \
+  OSM_W_MMA(j_, par_, 1, 1) P1_ OSM_W_UNIT()                                               \
+  OSM_W_MMA(j_, par_, 1, 0) P2_ OSM_W_UNIT()                                               \
+  OSM_W_MMA(j_, par_, 0, 2) P3_ OSM_W_UNIT()                                               \
+  OSM_W_MMA(j_, par_, 0, 1) P4_ OSM_W_UNIT()                                               \
+  OSM_W_MMA(j_, par_, 0, 0) P5_ OSM_W_UNIT()
 
+  // Software pipeline: region r_j = the 24 MFMAs of xi column j, and between them everything that prepares xi column
+  // j + 1 (LDS reads of the t column it needs, the V transform and split, ~100 VALU) plus a share of the slab's memory
+  // instructions (U fragments two xi ahead; two of the six activation pieces of slab c + 1 into LDS and of slab c + 2 into
+  // their registers).  r_3 prepares column 0 of the NEXT slab, after the slab's only barrier.
+  float tc[4][2][8];                  // [input column][tile block][channel]: t of the current slab
+  osm::floatx4_t qx[2][2], qy[2][2];  // [tile block][channel quad]: the two input rows of one t column
+  float vf[2][8];                     // V of the xi column being prepared
+  uint2 vh[2][2][NP];                 // its planes, [tile block][half]
+  uint4 va[2][2][NP];                 // A fragments, [xi column parity][tile block][plane]
   if (kc1 > kc0) {
-    OSM_W_LOAD_RAW(kc0);
-    OSM_W_LOAD_U(kc0, 0);
-    OSM_W_LOAD_U(kc0, 1);
-    OSM_W_STORE_RAW(kc0 & 1);
-    OSM_W_LOAD_RAW(min(kc0 + 1, kc1 - 1));
+    const int k1 = min(kc0 + 1, kc1 - 1);
+    OSM_W_LOAD_RAW(kc0, 0, WN_NJ)
+    OSM_W_LOAD_TAB(kc0)
+    OSM_W_LOAD_U(kc0, 0)
+    OSM_W_LOAD_U(kc0, 1)
+    OSM_W_STORE_RAW(kc0, 0, WN_NJ)
+    OSM_W_LOAD_RAW(k1, 0, WN_NJ)
+    OSM_W_LOAD_TAB(k1)
+    __syncthreads();
+    {
+      const int bo = (kc0 & 1) * (4 * WN_QP);
+      OSM_W_TRD(0, bo) OSM_W_TFMA(0)
+      OSM_W_TRD(2, bo) OSM_W_TFMA(2)
+      OSM_W_VADD(0, 0, 1.f, 2, -1.f) OSM_W_VADD(1, 0, 1.f, 2, -1.f)
+      OSM_W_VSPL(0, 0) OSM_W_VSPL(0, 1) OSM_W_VSPL(1, 0) OSM_W_VSPL(1, 1)
+      OSM_W_VFIN(0, 0) OSM_W_VFIN(0, 1)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     for (int c = kc0; c < kc1; ++c) {
-      __syncthreads();          // raw(c) is complete in buffer c & 1; nobody reads the other buffer any more
-      const int cn = min(c + 1, kc1 - 1);
-      const int bo = (c & 1) * (4 * WN_QP);
-      float tc[4][2][8];        // [input column][tile block][channel]
-      uint4 va[2][NP];          // the two A fragments of the current xi
-
-#define OSM_W_PIN()                       \
-  {                                        \
-    asm volatile("" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);     \
-  }
-      OSM_W_TCOL(0)
-      OSM_W_TCOL(2)
-      OSM_W_VFRAG(0, 1.f, 2, -1.f)
-      OSM_W_PIN()
-      OSM_W_MMAS(0)
-      OSM_W_LOAD_U(c, 2);
-      OSM_W_STORE_RAW((c + 1) & 1);          // raw(c + 1), loaded one slab ago, into the buffer slab c - 1 used
-      OSM_W_PIN()
-
-      OSM_W_TCOL(1)
-      OSM_W_VFRAG(1, 1.f, 2, 1.f)
-      OSM_W_PIN()
-      OSM_W_MMAS(1)
-      OSM_W_LOAD_U(c, 3);
-      OSM_W_LOAD_RAW(min(c + 2, kc1 - 1));
-      OSM_W_PIN()
-
-      OSM_W_VFRAG(2, 1.f, 1, -1.f)
-      OSM_W_PIN()
-      OSM_W_MMAS(2)
-      OSM_W_LOAD_U(cn, 0);
-      OSM_W_PIN()
-
-      OSM_W_TCOL(3)
-      OSM_W_VFRAG(1, 1.f, 3, -1.f)
-      OSM_W_PIN()
-      OSM_W_MMAS(3)
-      OSM_W_LOAD_U(cn, 1);
-      OSM_W_PIN()
-#undef OSM_W_PIN
+      const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
+      const int bo = (c & 1) * (4 * WN_QP), bn = ((c + 1) & 1) * (4 * WN_QP);
+      // r0: xi column 0 | prepares V1 = t1 + t2
+      OSM_W_REGION(0, 0,
+                   OSM_W_LOAD_U(c, 2) OSM_W_TRD(1, bo) OSM_W_STORE_RAW(c + 1, 0, 2) OSM_W_LOAD_RAW(c2, 0, 2),
+                   OSM_W_TFMA(1) OSM_W_VADD(0, 1, 1.f, 2, 1.f),
+                   OSM_W_VSPL(0, 0),
+                   OSM_W_VSPL(0, 1) OSM_W_VADD(1, 1, 1.f, 2, 1.f),
+                   OSM_W_VSPL(1, 0),
+                   OSM_W_VSPL(1, 1) OSM_W_VFIN(1, 0) OSM_W_VFIN(1, 1))
+      // r1: xi column 1 | prepares V2 = t2 - t1, reads t column 3
+      OSM_W_REGION(1, 1,
+                   OSM_W_LOAD_U(c, 3) OSM_W_TRD(3, bo) OSM_W_STORE_RAW(c + 1, 2, 2) OSM_W_LOAD_RAW(c2, 2, 2),
+                   OSM_W_VADD(0, 2, 1.f, 1, -1.f) OSM_W_TFMA(3),
+                   OSM_W_VSPL(0, 0),
+                   OSM_W_VSPL(0, 1) OSM_W_VADD(1, 2, 1.f, 1, -1.f),
+                   OSM_W_VSPL(1, 0),
+                   OSM_W_VSPL(1, 1) OSM_W_VFIN(0, 0) OSM_W_VFIN(0, 1))
+      // r2: xi column 2 | prepares V3 = t1 - t3
+      OSM_W_REGION(2, 0,
+                   OSM_W_LOAD_U(c1, 0) OSM_W_STORE_RAW(c + 1, 4, 2) OSM_W_LOAD_RAW(c2, 4, 2) OSM_W_LOAD_TAB(c2),
+                   OSM_W_VADD(0, 1, 1.f, 3, -1.f),
+                   OSM_W_VSPL(0, 0),
+                   OSM_W_VSPL(0, 1) OSM_W_VADD(1, 1, 1.f, 3, -1.f),
+                   OSM_W_VSPL(1, 0),
+                   OSM_W_VSPL(1, 1) OSM_W_VFIN(1, 0) OSM_W_VFIN(1, 1))
+      __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
+      // r3: xi column 3 | prepares V0 = t0 - t2 of slab c + 1
+      OSM_W_REGION(3, 1,
+                   OSM_W_LOAD_U(c1, 1) OSM_W_TRD(0, bn),
+                   OSM_W_TFMA(0) OSM_W_TRD(2, bn),
+                   OSM_W_TFMA(2) OSM_W_VADD(0, 0, 1.f, 2, -1.f) OSM_W_VSPL(0, 0),
+                   OSM_W_VSPL(0, 1) OSM_W_VADD(1, 0, 1.f, 2, -1.f),
+                   OSM_W_VSPL(1, 0),
+                   OSM_W_VSPL(1, 1) OSM_W_VFIN(0, 0) OSM_W_VFIN(0, 1))
     }
   }
 #undef OSM_W_LOAD_RAW
+#undef OSM_W_LOAD_TAB
 #undef OSM_W_STORE_RAW
 #undef OSM_W_LOAD_U
-#undef OSM_W_TCOL
-#undef OSM_W_VFRAG
+#undef OSM_W_TRD
+#undef OSM_W_TFMA
+#undef OSM_W_VADD
+#undef OSM_W_VSPL
+#undef OSM_W_VFIN
 #undef OSM_W_MMA
-#undef OSM_W_MMAS
+#undef OSM_W_UNIT
+#undef OSM_W_REGION
 
   // ---- Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  xi columns (in this wave): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3;
   // xi rows (= waves): Y[0][.] = s(0) + s(1) + s(2), Y[1][.] = s(1) - s(2) - s(3).  One tile block per round.
