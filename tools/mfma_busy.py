@@ -10,8 +10,10 @@ own GRBM, hence the / 8), SQ_WAVE_CYCLES, SQ_BUSY_CU_CYCLES.  Derived per dispat
     gui_cycles      = GRBM_GUI_ACTIVE / 8
     mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x gui_cycles)
     clock_ghz       = gui_cycles / dispatch duration               (what the power manager grants under this load)
-    expected_mfma   = algorithmic flops x 6 / (2 x 32 x 32 x 16)   (bf16x6: six MFMAs per fp32 product group)
+    expected_mfma   = algorithmic flops x 6 / (2 x 32 x 32 x 16)   (bf16x6: six MFMAs per fp32 product group;
+                      x 16/36 for the Winograd F(2x2,3x3) kernel, which multiplies 16 instead of 36 times per tile)
     mfma_count_seen = SQ_VALU_MFMA_BUSY_CYCLES / 32                (sanity check against expected_mfma)
+Each shape is measured twice: the direct halo-tile kernel and (--winograd) the Winograd kernel the engine now uses.
 """
 import csv
 import glob
@@ -29,16 +31,16 @@ COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ
 def main():
     out_json = sys.argv[1]
     rows = []
-    for shape in SHAPES:
+    for shape, wino in [(s, w) for s in SHAPES for w in (False, True)]:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = ["rocprofv3", "--pmc", *COUNTERS, "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(REPO, "tools", "conv_probe.py"), "--shape", shape, "--iters", "10"]
+               os.path.join(REPO, "tools", "conv_probe.py"), "--shape", shape, "--iters", "10"] + (["--winograd"] if wino else [])
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400)
         acc = {}
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if "conv3_halo" not in r["Kernel_Name"]:
+                if ("conv3_wino" if wino else "conv3_halo") not in r["Kernel_Name"]:
                     continue
                 a = acc.setdefault(r["Counter_Name"], [0.0, 0, 0.0])
                 a[0] += float(r["Counter_Value"])
@@ -51,13 +53,15 @@ def main():
         us = acc["GRBM_GUI_ACTIVE"][2] / acc["GRBM_GUI_ACTIVE"][1]
         B, H, W, Cin, Cout, k = (int(v) for v in shape.split(","))
         flops = 2.0 * B * H * W * Cin * Cout * k * k
+        exec_frac = 16.0 / 36.0 if wino else 1.0
         rows.append({
-            "shape_B,H,W,Cin,Cout,k": shape, "kernel": "conv3_halo_bf16s_kernel<3,*> (bf16x6)", "dispatches": acc["GRBM_GUI_ACTIVE"][1],
+            "shape_B,H,W,Cin,Cout,k": shape,
+            "kernel": "conv3_wino_kernel<3,*> (bf16x6, Winograd F(2x2,3x3))" if wino else "conv3_halo_bf16s_kernel<3,*> (bf16x6)", "dispatches": acc["GRBM_GUI_ACTIVE"][1],
             "avg_us_under_pmc": round(us, 2), "counters_avg_per_dispatch": {k: round(v, 1) for k, v in avg.items()},
             "mfma_busy_frac": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0), 4),
             "clock_ghz": round(avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3), 3),
             "bf16x6_roof_at_that_clock_tflops": round(2500.0 / 6.0 * (avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)) / 2.4, 1),
-            "expected_mfma_instructions": round(flops * 6 / (2 * 32 * 32 * 16)),
+            "expected_mfma_instructions": round(flops * exec_frac * 6 / (2 * 32 * 32 * 16)),
             "mfma_instructions_seen": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 32),
             "algorithmic_tflops_under_pmc": round(flops / us / 1e6, 1)})
     json.dump({"note": __doc__.split("Counters:")[1].strip(), "rows": rows}, open(out_json, "w"), indent=1)
