@@ -109,8 +109,9 @@ int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, 
  * [plane][xi = 16 transform positions][16-channel slab][n/32][lane][8].  A layer with osm_conv_winograd_ok(...) == 1
  * (H, W >= 16, Cin >= 16, Cout >= 64) may be run with desc.w = such an image and desc.wfmt = wfmt | OSM_WFMT_WINOGRAD:
  * 2.25x fewer MFMAs than the direct kernel, same fp32-class result (the transforms add roughly one more fp32 rounding
- * per operand).  gn_table, splitk, res / bias / accumulate work as in the direct kernel; colsum only with splitk > 1
- * (osm_conv_stat_chunks / osm_conv_splitk take the flagged wfmt). */
+ * per operand).  gn_table, splitk, res / bias / accumulate and colsum (both stat modes; chunks = 16 x 16 patches per
+ * image without split-K) work as in the direct kernel; osm_conv_stat_chunks / osm_conv_splitk take the flagged wfmt.
+ * y, res, bias, stat_x, stat_table: 16-byte aligned, ld multiples of 4. */
 #define OSM_WFMT_WINOGRAD 0x10
 int osm_conv_winograd_ok(int H, int W, int Cin, int Cout, int ksize, int wfmt);
 long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int dgrad);

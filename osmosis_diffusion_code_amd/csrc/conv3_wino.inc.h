@@ -321,6 +321,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   const bool xok = x0 + ox + dx < p.W;
   const int lane_o = dx * ldo + c4, lane_r = dx * (int)p.ldr + c4;
   const float* red_rd = red + ((ox * 2) * 16 + e_lo) * 64 + lk2 * 32 + c4;      // + ((row * 4 + b) * 16 + 4 i) * 64
+  // optional column sums of the final values (IGemmParams::colsum; the split-K case is served by the combine kernel):
+  // every lane accumulates its 4 columns over the pixels it stores, the lanes of a wave and the four waves are folded
+  // at the end -> one (sum, sum) pair per column and workgroup patch
+  const bool stats = p.colsum != nullptr && !partial;
+  float st1[2][4], st2[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st1[b][k] = st2[b][k] = 0.f;
+  const float* __restrict__ sxbase =
+      (stats && p.stat_mode == 2) ? p.stat_x + ((long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox)) * p.ld_sx : nullptr;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     if (a) __syncthreads();     // the previous round's reads of red are over
@@ -338,6 +349,14 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
       const bool nok = n < p.N && (b == 0 || u_nt != 0u);
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!partial && p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+      StatCol sc[4] = {};
+      if (sxbase && nok) {
+        const float* tb = p.stat_table + (long long)img * 4 * p.N + n;
+        const float4 tm = *reinterpret_cast<const float4*>(tb), tr = *reinterpret_cast<const float4*>(tb + p.N);
+        const float4 tg = *reinterpret_cast<const float4*>(tb + 2 * p.N), tbb = *reinterpret_cast<const float4*>(tb + 3 * p.N);
+        sc[0] = StatCol{tm.x, tr.x, tg.x, tbb.x}; sc[1] = StatCol{tm.y, tr.y, tg.y, tbb.y};
+        sc[2] = StatCol{tm.z, tr.z, tg.z, tbb.z}; sc[3] = StatCol{tm.w, tr.w, tg.w, tbb.w};
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                 // e' = 4 i + e_lo: tile row 4 a + i of the patch
         const float4 s0 = *reinterpret_cast<const float4*>(red_rd + (((oy + 0) * 4 + b) * 16 + 4 * i) * 64);
@@ -366,7 +385,47 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
           if (ok) *reinterpret_cast<float4*>(op) = v;
+          if (stats && ok) {
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sxbase) xv = *reinterpret_cast<const float4*>(sxbase + (dy * p.W + dx) * (int)p.ld_sx + c4 + (jn0 + b) * 32);
+            stat_add(p.stat_mode, p.stat_silu, sc[0], v.x, xv.x, st1[b][0], st2[b][0]);
+            stat_add(p.stat_mode, p.stat_silu, sc[1], v.y, xv.y, st1[b][1], st2[b][1]);
+            stat_add(p.stat_mode, p.stat_silu, sc[2], v.z, xv.z, st1[b][2], st2[b][2]);
+            stat_add(p.stat_mode, p.stat_silu, sc[3], v.w, xv.w, st1[b][3], st2[b][3]);
+          }
         }
+      }
+    }
+  }
+  if (stats) {       // wave-uniform
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {        // lanes with the same (lane & 7) hold the same columns
+          st1[b][k] += __shfl_xor(st1[b][k], m, 64);
+          st2[b][k] += __shfl_xor(st2[b][k], m, 64);
+        }
+      }
+    __syncthreads();            // the last round's reads of red are over
+    if (lane < 8) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          red[((wave * 2 + b) * 2 + 0) * 32 + 4 * lane + k] = st1[b][k];
+          red[((wave * 2 + b) * 2 + 1) * 32 + 4 * lane + k] = st2[b][k];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {            // (column tile b, which sum, column)
+      const int b = tid >> 6, w2 = (tid >> 5) & 1, col = tid & 31;
+      const int n = (jn0 + b) * 32 + col;
+      if (n < p.N && (b == 0 || u_nt != 0u)) {
+        const float v = (red[((0 * 2 + b) * 2 + w2) * 32 + col] + red[((1 * 2 + b) * 2 + w2) * 32 + col]) +
+                        (red[((2 * 2 + b) * 2 + w2) * 32 + col] + red[((3 * 2 + b) * 2 + w2) * 32 + col]);
+        p.colsum[(((long long)img * p.stat_chunks + (ty * tpx + tx)) * 2 + w2) * p.N + n] = v;
       }
     }
   }

@@ -538,8 +538,6 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
   if (wino) {
     if (!(taps == 9 && (wfmt == 2 || wfmt == 3) && wino_shape_ok(p.H, p.W, p.K, p.N)))
       return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 2 / 3, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
-    if (p.colsum && p.splitk <= 1)
-      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel emits column sums through the split-K combine only");
     if (!(p.ldc % 4 == 0 && osm::aligned16(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned16(p.res))) &&
           (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
       return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 16-byte vectors: ldy, ldr multiples of 4, aligned y / res / bias");
@@ -548,6 +546,9 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     p.ntiles = (p.N + 63) / 64;
     p.nchunks = p.ksteps;                       // 16-channel slabs
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
+    p.stat_chunks = p.mtiles / nimg;            // column sums without split-K: one chunk per 16 x 16 patch
+    if (p.colsum && p.stat_mode == 2 && !(p.ld_sx % 4 == 0 && osm::aligned16(p.stat_x) && osm::aligned16(p.stat_table)))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel reads stat_x / stat_table as 16-byte vectors");
     // column tiles that share an input patch in time (conv3_wino.inc.h, tile mapping): the largest divisor of ntiles <= 4
     static const int ngrp = [] { const char* e = std::getenv("OSM_WINO_NGROUP"); return e ? atoi(e) : 4; }();
     p.nb1 = 1;
@@ -722,7 +723,8 @@ extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int 
   if (wfmt & OSM_WFMT_WINOGRAD) {
     const int nslab = 2 * ((Cin + 31) / 32);
     if (splitk > nslab) splitk = nslab;
-    return (splitk > 1 && Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
+    if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
+    return ((H + 15) / 16) * ((W + 15) / 16);   // the kernel's epilogue: one chunk per 16 x 16 patch
   }
   if (wfmt == 0 || skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return 0;
   const bool halo = ksize == 3 && W >= 8 && H >= 8 && halo_enabled();

@@ -116,24 +116,61 @@ def test_winograd_with_fused_group_norm_input(ops, film, B, C, Cout, H, W, split
     assert relerr(from_nhwc(out, B, H, W), ref) < 6e-6
 
 
-def test_winograd_column_sums_with_split_k(ops):
-    """With split-K the combine kernel emits the column sums (same contract as for the direct kernel)."""
-    B, Cin, Cout, H, W, sk = 1, 256, 64, 32, 32, 4
+@pytest.mark.parametrize("B,Cin,Cout,H,W,sk", [(1, 256, 64, 32, 32, 4), (2, 64, 96, 24, 40, 1), (1, 128, 128, 64, 64, 1)])
+def test_winograd_column_sums(ops, B, Cin, Cout, H, W, sk):
+    """Column sums of the output (stat_mode 1) from the kernel's own epilogue (no split-K: one chunk per 16 x 16 patch)
+    or from the split-K combine -- same contract as the direct kernel."""
     wfmt = 3 | ops.WINOGRAD
-    g = torch.Generator().manual_seed(9)
+    g = torch.Generator().manual_seed(9 + H)
     x = to_nhwc(torch.randn(B, Cin, H, W, generator=g))
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    res = to_nhwc(torch.randn(B, Cout, H, W, generator=g))
     uf, _ = ops.pack_conv_weight_winograd(w, wfmt=3)
-    assert ops.conv_stat_chunks(B, H, W, Cin, Cout, 3, wfmt, 1) == 0
     nch = ops.conv_stat_chunks(B, H, W, Cin, Cout, 3, wfmt, sk)
-    assert nch == H * W // 8
+    assert nch == (H * W // 8 if sk > 1 else ((H + 15) // 16) * ((W + 15) // 16))
     y = torch.empty(B * H * W, Cout, device=DEV)
     cs = torch.full((B * nch * 2 * Cout,), float("nan"), device=DEV)
-    ws = torch.empty(sk * B * H * W * Cout, device=DEV)
-    ops.conv2d(ops.Mat.of(x), uf, None, ops.Mat.of(y), B, H, W, 3, splitk=sk, splitk_ws=ws, wfmt=wfmt, colsum=cs, stat_mode=1)
-    c = cs.view(B, nch, 2, Cout).double().sum(1)
-    assert relerr(c[:, 0].cpu(), y.double().sum(0, keepdim=True).cpu()) < 1e-5
-    assert relerr(c[:, 1].cpu(), (y.double() ** 2).sum(0, keepdim=True).cpu()) < 1e-5
+    ws = torch.empty(sk * B * H * W * Cout, device=DEV) if sk > 1 else None
+    ops.conv2d(ops.Mat.of(x), uf, bias, ops.Mat.of(y), B, H, W, 3, res=ops.Mat.of(res), splitk=sk, splitk_ws=ws, wfmt=wfmt,
+               colsum=cs, stat_mode=1)
+    c = cs.view(B, nch, 2, Cout).double().sum(1).cpu()
+    yb = y.view(B, H * W, Cout).double().cpu()
+    assert relerr(c[:, 0], yb.sum(1)) < 1e-5
+    assert relerr(c[:, 1], (yb ** 2).sum(1)) < 1e-5
+
+
+def test_winograd_backward_sums_for_group_norm(ops):
+    """stat_mode 2: y is the gradient w.r.t. SiLU(GN(x)); the epilogue emits sum(dxh), sum(dxh xh) per column."""
+    B, Cin, Cout, H, W, G = 2, 64, 64, 32, 16, 32
+    wfmt = 3 | ops.WINOGRAD
+    g = torch.Generator().manual_seed(3)
+    dy = to_nhwc(torch.randn(B, Cin, H, W, generator=g))
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).to(DEV)
+    uf, _ = ops.pack_conv_weight_winograd(w, wfmt=3)
+    xg = torch.randn(B, Cout, H, W, generator=g) * 1.5 + 0.3           # the GroupNorm input whose backward is reduced
+    xm = ops.Mat.of(to_nhwc(xg))
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV), (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    HW = H * W
+    part = torch.empty(B * ops.gn_nchunk(HW) * G * 2, device=DEV)
+    stats = torch.empty(B * G * 2, device=DEV)
+    table = torch.empty(B * 4 * Cout, device=DEV)
+    ops.gn_prep(xm, B, HW, G, part, stats, gamma, beta, table)
+    nch = ops.conv_stat_chunks(B, H, W, Cin, Cout, 3, wfmt, 1)
+    y = torch.empty(B * HW, Cout, device=DEV)
+    cs = torch.full((B * nch * 2 * Cout,), float("nan"), device=DEV)
+    ops.conv2d(ops.Mat.of(dy), uf, None, ops.Mat.of(y), B, H, W, 3, wfmt=wfmt, colsum=cs, stat_mode=2, stat_x=xm,
+               stat_table=table, stat_silu=True)
+    t = table.view(B, 4, Cout).double().cpu()
+    mean, rstd, gg, bb = t[:, 0:1], t[:, 1:2], t[:, 2:3], t[:, 3:4]
+    xb = xm.t.view(B, HW, Cout).double().cpu()
+    xh = (xb - mean) * rstd
+    z = xh * gg + bb
+    sig = torch.sigmoid(z)
+    dxh = y.view(B, HW, Cout).double().cpu() * (sig * (1 + z * (1 - sig))) * gg
+    c = cs.view(B, nch, 2, Cout).double().sum(1).cpu()
+    assert relerr(c[:, 0], dxh.sum(1)) < 2e-5
+    assert relerr(c[:, 1], (dxh * xh).sum(1)) < 2e-5
 
 
 def test_winograd_refusals(ops):
@@ -150,7 +187,3 @@ def test_winograd_refusals(ops):
     uf, _ = ops.pack_conv_weight_winograd(w, wfmt=3)
     with pytest.raises(OsmosisHipError, match="Winograd"):
         ops.conv2d(ops.Mat.of(x), uf, None, ops.Mat.of(y), 1, 8, 8, 3, wfmt=3 | ops.WINOGRAD)
-    cs = torch.empty(2 * 64 * 32, device=DEV)
-    x2, y2 = torch.randn(256, 64, device=DEV), torch.empty(256, 64, device=DEV)
-    with pytest.raises(OsmosisHipError, match="column sums"):
-        ops.conv2d(ops.Mat.of(x2), uf, None, ops.Mat.of(y2), 1, 16, 16, 3, wfmt=3 | ops.WINOGRAD, colsum=cs, stat_mode=1)
