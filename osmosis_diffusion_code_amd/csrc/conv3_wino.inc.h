@@ -1,5 +1,6 @@
-// Winograd F(2x2, 3x3) form of the 3x3 convolution, split-bf16 arithmetic, fp32 activations (included inside
-// igemm.hip's anonymous namespace, after conv3_halo.inc.h; fp32 entry-point family only).
+// Winograd F(2x2, 3x3) form of the 3x3 convolution (included inside igemm.hip's anonymous namespace, after
+// conv3_halo.inc.h): split-bf16 arithmetic on fp32 activations (NP = 3 / 2 planes), or -- fp16 family -- ONE half plane
+// per operand on half activations (NP = 1; the transforms run in fp32 either way).
 //
 // Why: the direct halo-tile kernel keeps the matrix pipe 77-80 % busy and runs the chip into its 1400 W power cap
 // (profiles/r02_power_under_conv.txt): with six bf16 MFMAs per fp32 product the only lever left is to issue fewer MFMAs
@@ -29,8 +30,6 @@
 //          they exchange through LDS (transposing to 4 consecutive columns per lane) and wave (oy, ox) finishes output
 //          pixel (oy, ox) of every tile with 16-byte stores (bias, residual, accumulate, or a split-K partial).
 
-#ifndef OSM_ACT_F16
-
 #ifndef WN_VPM
 #define WN_VPM 5      // VALU instructions asked for after every MFMA of a region
 #endif
@@ -42,7 +41,7 @@ constexpr int WN_QP = 18 * WN_ROWP + 1;      // slots per channel-quad plane (+1
 constexpr int WN_NJ = 6;                     // raw staging pieces per thread and slab (18 x 18 pixels x 4 quads = 1296)
 
 template <int NP, bool GNF>
-__global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restrict__ Aglob,
+__global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const act_t* __restrict__ Aglob,
                                                              const unsigned short* __restrict__ Uglob, IGemmParams p) {
   __shared__ __attribute__((aligned(16))) float4 raw[2 * 4 * WN_QP];       // two slabs: 46 KB
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 16 * 64];      // epilogue exchange: 64 KB
@@ -70,11 +69,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   const int nslab = p.ksteps;                       // 16-channel slabs (the weight image is zero padded to 32 channels)
   const int per = (nslab + p.splitk - 1) / p.splitk;
   const int kc0 = ks * per;
-  const int kc1 = min(nslab, kc0 + per);
+  int kc1_ = min(nslab, kc0 + per);
 
   // ---- raw staging coordinates: piece s = tid + 256 j -> channel quad tid & 3, halo pixel (tid >> 2) + 64 j
   const int q4 = tid & 3;
-  const long long rowB = (long long)p.lda * 4;
+  const long long rowB = (long long)p.lda * ACT_B;
   const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
   unsigned voff[WN_NJ], woff[WN_NJ], vmask = 0;
 #pragma unroll
@@ -129,10 +128,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
 #define OSM_W_LOAD_RAW(cc_, j0_, n_)                                                       \
   {                                                                                        \
     const bool cok_ = (cc_) * 16 + 4 * q4 < p.K;                                           \
-    const unsigned d_ = (unsigned)((cc_) * 64 + 16 * q4);                                  \
+    const unsigned d_ = (unsigned)(((cc_) * 16 + 4 * q4) * ACT_B);                         \
     _Pragma("unroll") for (int j = (j0_); j < (j0_) + (n_); ++j)                           \
       ra[j] = (WN_ABL & 1) ? make_float4(1.f, 2.f, 3.f, (float)d_)                         \
-                           : *reinterpret_cast<const float4*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u))); \
+                           : osm::ld4(reinterpret_cast<const act_t*>(sbaseA + (voff[j] + (cok_ ? d_ : 0u)))); \
   }
 // ... are loaded separately: they must outlive the stores of the previous slab
 #define OSM_W_LOAD_TAB(cc_)                                                                \
@@ -194,8 +193,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
 #define OSM_W_VFIN(par_, a_)                                                               \
   _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                        \
     va[par_][a_][q2] = make_uint4(vh[a_][0][q2].x, vh[a_][0][q2].y, vh[a_][1][q2].x, vh[a_][1][q2].y);
-#define OSM_W_MMA(j_, par_, pa_, pb_)                                                      \
-  if ((pa_) < NP && (pb_) < NP) {                                                          \
+// the u_-th plane pair of the product group (smallest terms first): NP = 3: six pairs, 2: three, 1: one
+#define OSM_W_MMA(j_, par_, u_)                                                            \
+  if ((u_) < (NP == 3 ? 6 : (NP == 2 ? 3 : 1))) {                                          \
+    constexpr int pa_ = NP == 3 ? (u_ == 0 ? 2 : (u_ <= 2 ? 1 : 0)) : (NP == 2 ? (u_ == 0 ? 1 : 0) : 0);              \
+    constexpr int pb_ = NP == 3 ? (u_ == 0 ? 0 : (u_ == 1 ? 1 : (u_ == 2 ? 0 : 5 - u_))) : (NP == 2 ? (u_ == 1 ? 1 : 0) : 0); \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                          \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
         acc[j_][a][b] = mma16<NP>(va[par_][a][pa_], uq[j_][b][pb_], acc[j_][a][b]);        \
@@ -214,12 +216,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   }
 // region = the six units of xi column j_ (operands va[par_]); P0_ .. P5_ = what each unit does besides its MFMAs
 #define OSM_W_REGION(j_, par_, P0_, P1_, P2_, P3_, P4_, P5_)                               \
-  OSM_W_MMA(j_, par_, 2, 0) P0_ OSM_W_UNIT()                                               \
-  OSM_W_MMA(j_, par_, 1, 1) P1_ OSM_W_UNIT()                                               \
-  OSM_W_MMA(j_, par_, 1, 0) P2_ OSM_W_UNIT()                                               \
-  OSM_W_MMA(j_, par_, 0, 2) P3_ OSM_W_UNIT()                                               \
-  OSM_W_MMA(j_, par_, 0, 1) P4_ OSM_W_UNIT()                                               \
-  OSM_W_MMA(j_, par_, 0, 0) P5_ OSM_W_UNIT()
+  OSM_W_MMA(j_, par_, 0) P0_ OSM_W_UNIT()                                                  \
+  OSM_W_MMA(j_, par_, 1) P1_ OSM_W_UNIT()                                                  \
+  OSM_W_MMA(j_, par_, 2) P2_ OSM_W_UNIT()                                                  \
+  OSM_W_MMA(j_, par_, 3) P3_ OSM_W_UNIT()                                                  \
+  OSM_W_MMA(j_, par_, 4) P4_ OSM_W_UNIT()                                                  \
+  OSM_W_MMA(j_, par_, 5) P5_ OSM_W_UNIT()
 
   // Software pipeline: region r_j = the 24 MFMAs of xi column j, and between them everything that prepares xi column
   // j + 1 (LDS reads of the t column it needs, the V transform and split, ~100 VALU) plus a share of the slab's memory
@@ -230,7 +232,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   float vf[2][8];                     // V of the xi column being prepared
   uint2 vh[2][2][NP];                 // its planes, [tile block][half]
   uint4 va[2][2][NP];                 // A fragments, [xi column parity][tile block][plane]
-  if (kc1 > kc0) {
+  if ((WN_ABL & 8) && p.alpha != 12345.f) kc1_ = kc0;      // measurement build: no slab loop
+  if (kc1_ > kc0) {
+    const int kc1 = kc1_;
     const int k1 = min(kc0 + 1, kc1 - 1);
     OSM_W_LOAD_RAW(kc0, 0, WN_NJ)
     OSM_W_LOAD_TAB(kc0)
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
 #undef OSM_W_UNIT
 #undef OSM_W_REGION
 
+  if ((WN_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
   // ---- Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  xi columns (in this wave): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3;
   // xi rows (= waves): Y[0][.] = s(0) + s(1) + s(2), Y[1][.] = s(1) - s(2) - s(3).  One tile block per round.
   // Stores are issue-bound (one 4-byte store per lane and instruction costs as much as a 16-byte one), so the exchange
@@ -309,17 +314,15 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   // red: [wave = xi row][ox][column tile][e][lane = 32 lk + column]
   const int oy = wave >> 1, ox = wave & 1;
   const bool partial = p.splitk > 1;
-  const int ldo = partial ? p.N : (int)p.ldc;
-  float* __restrict__ obase = (partial ? p.ws + ((long long)ks * p.M) * p.N : p.C) +
-                              ((long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox)) * ldo;
-  const float* __restrict__ rbase =
-      (!partial && p.res) ? p.res + ((long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox)) * p.ldr : nullptr;
+  const long long pix0 = (long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox);
+  float* __restrict__ wbase = p.ws + ((long long)ks * p.M + pix0) * p.N;            // split-K partials: fp32, ld = N
+  act_t* __restrict__ obase = p.C + pix0 * p.ldc;
+  const act_t* __restrict__ rbase = (!partial && p.res) ? p.res + pix0 * p.ldr : nullptr;
   // item it = 64 i + lane of a (tile block, column tile): columns 4 (it & 7) .. + 3 of accumulator element
   // e' = it >> 4 in lane half lk' = (it >> 3) & 1, i.e. tile (4 a + (e' >> 2), (e' & 3) + 4 lk') of the patch
   const int c4 = 4 * (lane & 7), lk2 = (lane >> 3) & 1, e_lo = lane >> 4;      // e' = 4 i + e_lo
   const int dx = 2 * (e_lo + 4 * lk2);                                          // pixel column offset in the patch
   const bool xok = x0 + ox + dx < p.W;
-  const int lane_o = dx * ldo + c4, lane_r = dx * (int)p.ldr + c4;
   const float* red_rd = red + ((ox * 2) * 16 + e_lo) * 64 + lk2 * 32 + c4;      // + ((row * 4 + b) * 16 + 4 i) * 64
   // optional column sums of the final values (IGemmParams::colsum; the split-K case is served by the combine kernel):
   // every lane accumulates its 4 columns over the pixels it stores, the lanes of a wave and the four waves are folded
@@ -330,8 +333,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int k = 0; k < 4; ++k) st1[b][k] = st2[b][k] = 0.f;
-  const float* __restrict__ sxbase =
-      (stats && p.stat_mode == 2) ? p.stat_x + ((long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox)) * p.ld_sx : nullptr;
+  const act_t* __restrict__ sxbase = (stats && p.stat_mode == 2) ? p.stat_x + pix0 * p.ld_sx : nullptr;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     if (a) __syncthreads();     // the previous round's reads of red are over
@@ -371,27 +373,29 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
         const int dy = 8 * a + 2 * i;
         if (y0 + oy + dy >= p.H) continue;          // wave-uniform
         const bool ok = nok && xok;
-        float* __restrict__ op = obase + (dy * p.W) * ldo + lane_o + (jn0 + b) * 32;
+        const int po = dy * p.W + dx;               // pixel offset inside the image
         if (partial) {
-          if (ok) *reinterpret_cast<float4*>(op) = v;
+          if (ok) *reinterpret_cast<float4*>(wbase + po * p.N + n) = v;
         } else {
+          act_t* __restrict__ op = obase + po * (int)p.ldc + n;
           v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
           if (rbase && ok) {
-            const float4 r = *reinterpret_cast<const float4*>(rbase + (dy * p.W) * (int)p.ldr + lane_r + (jn0 + b) * 32);
+            const float4 r = osm::ld4(rbase + po * (int)p.ldr + n);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
           if (p.accumulate && ok) {
-            const float4 r = *reinterpret_cast<const float4*>(op);
+            const float4 r = osm::ld4(op);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
-          if (ok) *reinterpret_cast<float4*>(op) = v;
+          if (ok) osm::st4(op, v);
           if (stats && ok) {
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sxbase) xv = *reinterpret_cast<const float4*>(sxbase + (dy * p.W + dx) * (int)p.ld_sx + c4 + (jn0 + b) * 32);
-            stat_add(p.stat_mode, p.stat_silu, sc[0], v.x, xv.x, st1[b][0], st2[b][0]);
-            stat_add(p.stat_mode, p.stat_silu, sc[1], v.y, xv.y, st1[b][1], st2[b][1]);
-            stat_add(p.stat_mode, p.stat_silu, sc[2], v.z, xv.z, st1[b][2], st2[b][2]);
-            stat_add(p.stat_mode, p.stat_silu, sc[3], v.w, xv.w, st1[b][3], st2[b][3]);
+            if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
+            // the sums are over the values as stored (rounded to the storage type)
+            stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, st1[b][0], st2[b][0]);
+            stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, st1[b][1], st2[b][1]);
+            stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, st1[b][2], st2[b][2]);
+            stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, st1[b][3], st2[b][3]);
           }
         }
       }
@@ -431,7 +435,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const float* __restr
   }
 }
 
-// OIHW fp32 -> Winograd-domain weights U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], as np bf16 planes in
+#ifndef OSM_ACT_F16
+// OIHW fp32 -> Winograd-domain weights U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], as np bf16 planes (np = 1: ONE
+// plane of IEEE half, the fp16 family's image) in
 // MFMA-fragment order [plane][xi = 4 a + b][16-channel slab s][n/32 j][lane l][e]: n = 32 j + (l & 31),
 // k = 16 s + 8 (l >> 5) + e.  forward: n = Cout, k = Cin; data-gradient: n = Cin, k = Cout, taps flipped.
 // U is formed in double, rounded once to fp32, and that fp32 value is split exactly into the planes.
@@ -466,6 +472,10 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned sh
         }
     }
     float rr = (float)u;
+    if (np == 1) {
+      out[i] = __builtin_bit_cast(unsigned short, (_Float16)rr);
+      continue;
+    }
     for (int q2 = 0; q2 < np; ++q2) {
       const __bf16 bb = (__bf16)rr;
       out[q2 * per_plane + i] = __builtin_bit_cast(unsigned short, bb);

@@ -534,38 +534,36 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
 #else
   if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
 #endif
-#ifndef OSM_ACT_F16
   if (wino) {
-    if (!(taps == 9 && (wfmt == 2 || wfmt == 3) && wino_shape_ok(p.H, p.W, p.K, p.N)))
-      return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 2 / 3, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
-    if (!(p.ldc % 4 == 0 && osm::aligned16(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned16(p.res))) &&
+    if (!(taps == 9 && wfmt >= 1 && wfmt <= 3 && wino_shape_ok(p.H, p.W, p.K, p.N)))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 1 / 2 / 3, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
+    if (!(p.ldc % 4 == 0 && osm::aligned_act4(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned_act4(p.res))) &&
           (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
-      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 16-byte vectors: ldy, ldr multiples of 4, aligned y / res / bias");
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 4-element vectors: ldy, ldr multiples of 4, aligned y / res / bias");
     const int nimg = p.M / (p.H * p.W);
     p.mtiles = nimg * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     p.ntiles = (p.N + 63) / 64;
     p.nchunks = p.ksteps;                       // 16-channel slabs
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     p.stat_chunks = p.mtiles / nimg;            // column sums without split-K: one chunk per 16 x 16 patch
-    if (p.colsum && p.stat_mode == 2 && !(p.ld_sx % 4 == 0 && osm::aligned16(p.stat_x) && osm::aligned16(p.stat_table)))
-      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel reads stat_x / stat_table as 16-byte vectors");
+    if (p.colsum && p.stat_mode == 2 && !(p.ld_sx % 4 == 0 && osm::aligned_act4(p.stat_x) && osm::aligned16(p.stat_table)))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel reads stat_x / stat_table as 4-element vectors");
     // column tiles that share an input patch in time (conv3_wino.inc.h, tile mapping): the largest divisor of ntiles <= 4
     static const int ngrp = [] { const char* e = std::getenv("OSM_WINO_NGROUP"); return e ? atoi(e) : 4; }();
     p.nb1 = 1;
     for (int g = 2; g <= ngrp; ++g) if (p.ntiles % g == 0) p.nb1 = g;
     const unsigned short* Up = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 gw(p.mtiles * p.ntiles, p.splitk, 1);
-    if (wfmt == 3) {
-      if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<3, true>), gw, dim3(256), 0, st, p.A, Up, p);
-      else hipLaunchKernelGGL((conv3_wino_kernel<3, false>), gw, dim3(256), 0, st, p.A, Up, p);
-    } else {
-      if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<2, true>), gw, dim3(256), 0, st, p.A, Up, p);
-      else hipLaunchKernelGGL((conv3_wino_kernel<2, false>), gw, dim3(256), 0, st, p.A, Up, p);
-    }
-  } else
+#define OSM_WINO_LAUNCH(NP_)                                                                               \
+    if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<NP_, true>), gw, dim3(256), 0, st, p.A, Up, p);  \
+    else hipLaunchKernelGGL((conv3_wino_kernel<NP_, false>), gw, dim3(256), 0, st, p.A, Up, p);
+#ifdef OSM_ACT_F16
+    OSM_WINO_LAUNCH(1)
 #else
-  if (wino) return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd path serves the fp32 family only");
+    if (wfmt == 3) { OSM_WINO_LAUNCH(3) } else { OSM_WINO_LAUNCH(2) }
 #endif
+#undef OSM_WINO_LAUNCH
+  } else
   {
   const bool halo_path = wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled();
   if (p.colsum && (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) || wfmt == 0 || !(halo_path || p.splitk > 1)))
@@ -739,7 +737,7 @@ extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int 
 
 // 1 when a layer may be given a Winograd weight image (OSM_WFMT_WINOGRAD): 3x3, stride 1, wfmt 2 / 3, fp32 family
 extern "C" int osm_conv_winograd_ok(int H, int W, int Cin, int Cout, int ksize, int wfmt) {
-  return ksize == 3 && (wfmt == 2 || wfmt == 3) && wino_shape_ok(H, W, Cin, Cout) ? 1 : 0;
+  return ksize == 3 && wfmt >= 1 && wfmt <= 3 && wino_shape_ok(H, W, Cin, Cout) ? 1 : 0;
 }
 extern "C" long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int dgrad) {
   const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
@@ -748,7 +746,7 @@ extern "C" long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int 
 extern "C" int osm_pack_conv_weight_winograd(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int wfmt,
                                              void* stream) {
   OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_winograd: null pointer");
-  OSM_REQUIRE(wfmt == 2 || wfmt == 3, "osm_pack_conv_weight_winograd: wfmt must be 2 or 3 (bf16 planes)");
+  OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_pack_conv_weight_winograd: wfmt must be 1 (fp16), 2 or 3 (bf16 planes)");
   for (int dg = 0; dg < 2; ++dg) {
     unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
     if (!out) continue;
@@ -800,8 +798,8 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   }
   const bool wino = (d->wfmt & OSM_WFMT_WINOGRAD) != 0;
   const int wfmt = d->wfmt & ~OSM_WFMT_WINOGRAD;
-  OSM_REQUIRE(!wino || (d->ksize == 3 && (wfmt == 2 || wfmt == 3)),
-              "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 2 / 3");
+  OSM_REQUIRE(!wino || (d->ksize == 3 && wfmt >= 1 && wfmt <= 3),
+              "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 1 / 2 / 3");
   if (wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
     OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");
     p.nt32 = (d->Cout + 31) / 32;

@@ -47,7 +47,10 @@ class _Conv:
         self.wf, self.wd = ops.pack_conv_weight(w, wfmt=wfmt)
         # Winograd F(2x2, 3x3) images next to the direct ones (the layer picks per (H, W): 16 x 16 and larger)
         self.wwf = self.wwd = None
-        if self.k == 3 and wfmt in (2, 3) and _winograd_on() and ops.conv_winograd_ok(16, 16, self.cin, self.cout, 3, wfmt) \
+        # (the fp16 family's instance exists and is tested, but loses to the direct fp16 kernel -- one MFMA per product leaves
+        # the transform as the whole cost: 10.1 vs 7.3 ms of 3x3 time per step -- so it is opt-in: OSM_WINOGRAD_F16=1)
+        if self.k == 3 and (wfmt in (2, 3) or (wfmt == 1 and os.environ.get("OSM_WINOGRAD_F16", "0") == "1")) \
+                and _winograd_on() and ops.conv_winograd_ok(16, 16, self.cin, self.cout, 3, wfmt) \
                 and ops.conv_winograd_ok(16, 16, self.cout, self.cin, 3, wfmt):
             self.wwf, self.wwd = ops.pack_conv_weight_winograd(w, wfmt=wfmt)
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()

@@ -187,3 +187,57 @@ def test_winograd_refusals(ops):
     uf, _ = ops.pack_conv_weight_winograd(w, wfmt=3)
     with pytest.raises(OsmosisHipError, match="Winograd"):
         ops.conv2d(ops.Mat.of(x), uf, None, ops.Mat.of(y), 1, 8, 8, 3, wfmt=3 | ops.WINOGRAD)
+
+
+# ----------------------------------------------------------------------------- fp16 family (use_fp16)
+def to_nhwc_h(x):
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV, torch.float16)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,splitk,gn", [(1, 64, 64, 16, 16, 1, False), (2, 32, 96, 16, 32, 1, False),
+                                                     (1, 96, 160, 24, 40, 1, True), (1, 256, 64, 32, 32, 4, False),
+                                                     (1, 128, 128, 64, 64, 1, True), (1, 40, 64, 17, 19, 1, False)])
+def test_winograd_fp16_family(ops, B, Cin, Cout, H, W, splitk, gn):
+    """Half activations, one fp16 plane per operand (wfmt 1 | WINOGRAD), transforms in fp32: against an fp64 convolution
+    of the SAME half-rounded inputs / weights.  Stated tolerance: V and U are each rounded once more to half (2^-11
+    relative) and the output transform adds 9 of the 16 products, so the result is within ~3x the rounding of one
+    half-stored tensor (measured 3-6e-4 of the output's max-abs; the direct fp16 kernel: 3e-4)."""
+    g = torch.Generator().manual_seed(B * 31 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    xh, rh = to_nhwc_h(x), to_nhwc_h(res)
+    xin = xh.float().cpu().view(B, H, W, Cin).permute(0, 3, 1, 2).double()
+    G = 32
+    table = None
+    if gn:
+        gamma, beta = 1 + 0.1 * torch.randn(Cin, generator=g), 0.1 * torch.randn(Cin, generator=g)
+        part = torch.empty(B * ops.gn_nchunk(H * W) * G * 2, device=DEV)
+        stats = torch.empty(B * G * 2, device=DEV)
+        table = torch.empty(B * 4 * Cin, device=DEV)
+        ops.gn_prep(ops.Mat.of(xh), B, H * W, G, part, stats, gamma.to(DEV), beta.to(DEV), table)
+        xin = F.silu(F.group_norm(xin, G, gamma.double(), beta.double(), eps=1e-5))
+    ref = F.conv2d(xin, w.half().double(), bias.double(), padding=1) + \
+        rh.float().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2).double()
+    assert ops.conv_winograd_ok(H, W, Cin, Cout, 3, 1)
+    uf, ud = ops.pack_conv_weight_winograd(w.to(DEV), wfmt=1)
+    y = torch.full((B * H * W, Cout), float("nan"), device=DEV, dtype=torch.float16)
+    ws = torch.empty(splitk * B * H * W * Cout, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(xh), uf, bias.to(DEV), ops.Mat.of(y), B, H, W, 3, res=ops.Mat.of(rh), splitk=splitk, splitk_ws=ws,
+               wfmt=1 | ops.WINOGRAD, gn_table=table, gn_silu=True)
+    e = relerr(from_nhwc(y.float(), B, H, W), ref.float())
+    assert e < 1.5e-3, e
+    if gn or not ops.conv_winograd_ok(H, W, Cout, Cin, 3, 1):
+        return
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    dyh = to_nhwc_h(dy)
+    xr = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    (dref,) = torch.autograd.grad(F.conv2d(xr, w.half().double(), None, padding=1), xr,
+                                  dyh.float().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2).double())
+    dx = torch.full((B * H * W, Cin), float("nan"), device=DEV, dtype=torch.float16)
+    ws2 = torch.empty(splitk * B * H * W * Cin, device=DEV) if splitk > 1 else None
+    ops.conv2d(ops.Mat.of(dyh), ud, None, ops.Mat.of(dx), B, H, W, 3, splitk=splitk, splitk_ws=ws2, wfmt=1 | ops.WINOGRAD)
+    e = relerr(from_nhwc(dx.float(), B, H, W), dref.float())
+    assert e < 1.5e-3, ("dgrad", e)
