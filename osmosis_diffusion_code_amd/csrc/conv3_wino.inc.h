@@ -30,6 +30,9 @@
 //          they exchange through LDS (transposing to 4 consecutive columns per lane) and wave (oy, ox) finishes output
 //          pixel (oy, ox) of every tile with 16-byte stores (bias, residual, accumulate, or a split-K partial).
 
+#ifndef WN_NT_STORE
+#define WN_NT_STORE 0
+#endif
 #ifndef WN_VPM
 #define WN_VPM 5      // VALU instructions asked for after every MFMA of a region
 #endif
@@ -387,7 +390,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const act_t* __restr
             const float4 r = osm::ld4(op);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
+#if WN_NT_STORE && !OSM_ACT_IS_F16
+          if (ok) __builtin_nontemporal_store(osm::floatx4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<osm::floatx4_t*>(op));
+#else
           if (ok) osm::st4(op, v);
+#endif
           if (stats && ok) {
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
