@@ -36,12 +36,16 @@ template <int PW, int PH = 8> struct HaloGeom {
 // its use.  3 on the MFMA-bound layers; deeper rings (6 / 9) keep more of the weight stream in flight for the
 // weight-bandwidth-bound low-resolution layers (few rows per weight byte: the loads, not the MFMAs, set the pace).
 
-template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8>
+// NARROW (8 x 16 patches only): layers with <= 32 output columns (the network's head: 256 -> 8, and the stem's data-gradient:
+// 256 -> 4).  The four waves then split the four row blocks of the patch instead of the (empty) column tiles: 108 instead of
+// 432 MFMAs per wave and slab.
+template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8, bool NARROW = false>
 __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
   constexpr int B_RING = BR, B_DIST = BR - 1;
   static_assert(PH == 8 || (PH == 16 && PW == 16), "patches are 8 x 8, 8 x 16 or 16 x 16");
+  static_assert(!NARROW || (PW == 16 && PH == 8), "the narrow variant works on 8 x 16 patches");
   using GEO = HaloGeom<PW, PH>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
                 RB = GEO::RB;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 
   // ---- B fragment addressing (image [plane][tap][k16-step][n/32][lane][8])
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int jn = (n0 >> 5) + wave_u;
+  const int jn = (n0 >> 5) + (NARROW ? 0 : wave_u);
   const bool b_ok = jn < p.nt32;
   const unsigned b_lane = b_ok ? (unsigned)((jn * 64 + lane) * 16) : (unsigned)(lane & 1) * 16u;
   // uniform 32-bit byte offsets (the largest image, 2048 -> 1024 channels, is 113 MB)
@@ -108,9 +112,10 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 
   // lane row lr of row block i: PW = 16 -> patch pixel (i + PH/2 (lr >> 4), lr & 15);  PW = 8 -> (4 i + (lr >> 3), lr & 7)
   const int lr = lane & 31, lk = lane >> 5;
-  const unsigned char* a_rd =
-      As + (PW == 16 ? (lr >> 4) * ((PH / 2) * HALO_P) + (lr & 15) : (lr >> 3) * HALO_P + (lr & 7)) * S_ROWB + 16 * lk;
   constexpr int RB_STRIDE = (PW == 16 ? HALO_P : 4 * HALO_P) * S_ROWB;   // bytes between row blocks
+  const unsigned char* a_rd =
+      As + (PW == 16 ? (lr >> 4) * ((PH / 2) * HALO_P) + (lr & 15) : (lr >> 3) * HALO_P + (lr & 7)) * S_ROWB + 16 * lk +
+      (NARROW ? wave_u * RB_STRIDE : 0);
 
   float4 ra[NJ];
   float4 gm, gr, gg, gb;   // GNF: mean | rstd | g | b of this thread's 4 channels of the current slab
@@ -187,7 +192,23 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
       OSM_H_LOAD_A(cn);                      // next slab's halo: in flight during the MFMA stream
       __syncthreads();
       uint4 fx[2][NP], fy[2][NP];
-      if constexpr (PH == 16) {
+      if constexpr (NARROW) {
+        // one row block (= this wave's) per step, two accumulators alternate so that consecutive MFMAs are independent
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+          OSM_H_LOAD_B((s + B_DIST) % B_RING, (s + B_DIST < 18 ? c : cn), (s + B_DIST) % 18);
+          const int t_ = s >> 1, kk_ = s & 1;
+          const int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;
+#pragma unroll
+          for (int q2 = 0; q2 < NP; ++q2) fx[0][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE + off_);
+          int cnt = 0;
+#pragma unroll
+          for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+            for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)
+              acc[cnt & 1] = mma16<NP>(fx[0][pa], bq[s % B_RING][pb], acc[cnt & 1]);
+        }
+      } else if constexpr (PH == 16) {
         // 256-row patch: four pairs of row blocks per (tap, k16) step; fx serves pairs 0 and 2, fy pairs 1 and 3
 #define OSM_T_READ(f_, s_, pr_)                                                             \
         {                                                                                   \
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool partial = p.splitk > 1;
   const long long ldc = partial ? (long long)p.N : p.ldc;
-  const int n = n0 + 32 * wave + lr;
+  const int n = n0 + (NARROW ? 0 : 32 * wave) + lr;
   if (n >= p.N) return;
   const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
   // element e of row block tm is patch pixel  PW = 16: (tm + PH/2 (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 lk)
@@ -280,13 +301,14 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
     sxp = p.stat_x + pix0 * p.ld_sx + n;
   }
 #pragma unroll
-  for (int tm = 0; tm < RB; ++tm) {
+  for (int tm0 = 0; tm0 < (NARROW ? 1 : RB); ++tm0) {
+    const int tm = NARROW ? wave : tm0;        // narrow: this wave's row block, its two accumulators summed
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int dy = PW == 16 ? tm + (PH / 2) * (e >> 3) : 4 * tm + (e >> 2);
       const int dx = PW == 16 ? (e & 3) + 8 * ((e >> 2) & 1) : (e & 3);
       if (y0 + dy >= p.H || xl + dx >= p.W) continue;
-      float v = acc[tm][e];
+      float v = NARROW ? acc[0][e] + acc[1][e] : acc[tm0][e];
       if (partial) {
         wp[dy * crow + dx * ldc] = v;
       } else {

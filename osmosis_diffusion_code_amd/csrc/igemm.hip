@@ -603,10 +603,15 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     static const int ring16 = [] { const char* e = std::getenv("OSM_BRING16"); return e ? atoi(e) : 3; }();
     static const int ring8 = [] { const char* e = std::getenv("OSM_BRING8"); return e ? atoi(e) : 3; }();
     const bool deep16 = ring16 == 6 && p.M <= 4096, deep8 = ring8 == 9;
+    // <= 32 output columns (head / stem data-gradient): the waves split the row blocks instead of the column tiles
+    static const bool narrow_on = [] { const char* e = std::getenv("OSM_NARROW"); return !(e && e[0] == '0'); }();
+    const bool narrow = narrow_on && wide && !tall && p.N <= 32 && !p.colsum;
 #define OSM_HALO_LAUNCH(NP_, GN_, PW_, BR_) \
     hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_, BR_>), g2, dim3(256), 0, st, p.A, Bp, p)
 #define OSM_HALO_PICK(NP_)                                                                                  \
-    if (tall) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); \
+    if (narrow) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 8, true>), g2, dim3(256), 0, st, p.A, Bp, p); \
+                  else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, false, 16, 3, 8, true>), g2, dim3(256), 0, st, p.A, Bp, p); }       \
+    else if (tall) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); \
                 else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, false, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); }       \
     else if (wide && deep16) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 6); else OSM_HALO_LAUNCH(NP_, false, 16, 6); } \
     else if (wide)      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 3); else OSM_HALO_LAUNCH(NP_, false, 16, 3); } \
