@@ -276,6 +276,99 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 #undef OSM_H_MMA
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // Vector form (see igemm_bf16s.inc.h: stores are issue-bound): each wave transposes its (RB x 32) x 32 tile through its
+  // own slice of the staging LDS, RP rows per pass, so that a lane owns 4 consecutive columns of a pixel.
+  if constexpr (!NARROW) {
+    const bool partial_ = p.splitk > 1;
+    const auto al = [](const void* q_, unsigned bytes) { return (reinterpret_cast<unsigned long long>(q_) & (bytes - 1)) == 0; };
+    const bool vec = (p.N & 3) == 0 &&
+                     (partial_ ? al(p.ws, 16)
+                               : ((p.ldc & 3) == 0 && al(p.C, 4 * ACT_B) && (!p.bias || al(p.bias, 16)) &&
+                                  (!p.res || ((p.ldr & 3) == 0 && al(p.res, 4 * ACT_B))) &&
+                                  (!p.colsum || p.stat_mode == 1 || ((p.ld_sx & 3) == 0 && al(p.stat_x, 4 * ACT_B) && al(p.stat_table, 16)))));
+    if (vec) {
+      constexpr int LDSB = NP * H_PLANE;
+      constexpr int RP = LDSB >= 4 * 64 * 128 ? 64 : (LDSB >= 4 * 32 * 128 ? 32 : (LDSB >= 4 * 16 * 128 ? 16 : 8));
+      static_assert(LDSB >= 4 * RP * 128 && (RB * 32) % RP == 0, "transpose slices must fit the staging LDS");
+      float* tb = reinterpret_cast<float*>(As) + wave * (RP * 32);
+      const int c4 = 4 * (lane & 7), rr = lane >> 3;
+      const int nb = n0 + 32 * wave + c4;
+      const bool nok = nb < p.N;
+      float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!partial_ && p.bias && nok) bv4 = *reinterpret_cast<const float4*>(p.bias + nb);
+      const bool stats_ = p.colsum != nullptr && !partial_;
+      float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+      StatCol sc[4] = {};
+      if (stats_ && p.stat_mode == 2 && nok) {
+        const float* tbl = p.stat_table + (long long)img * 4 * p.N + nb;
+        const float4 tm_ = *reinterpret_cast<const float4*>(tbl), tr_ = *reinterpret_cast<const float4*>(tbl + p.N);
+        const float4 tg_ = *reinterpret_cast<const float4*>(tbl + 2 * p.N), tb_ = *reinterpret_cast<const float4*>(tbl + 3 * p.N);
+        sc[0] = StatCol{tm_.x, tr_.x, tg_.x, tb_.x}; sc[1] = StatCol{tm_.y, tr_.y, tg_.y, tb_.y};
+        sc[2] = StatCol{tm_.z, tr_.z, tg_.z, tb_.z}; sc[3] = StatCol{tm_.w, tr_.w, tg_.w, tb_.w};
+      }
+      const long long pimg = (long long)img * p.H * p.W;
+#pragma unroll
+      for (int pass = 0; pass < RB * 32 / RP; ++pass) {
+#pragma unroll
+        for (int tm = 0; tm < RB; ++tm)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int R0 = 32 * tm + 8 * (e >> 2);                       // first row of this element's 8-row group
+            if (R0 / RP != pass) continue;                               // compile-time
+            tb[(R0 % RP + (e & 3) + 4 * lk) * 32 + lr] = acc[tm][e];
+          }
+#pragma unroll
+        for (int it = 0; it < RP / 8; ++it) {
+          const int row = 8 * it + rr;
+          float4 v = *reinterpret_cast<const float4*>(tb + row * 32 + c4);
+          const int R = pass * RP + row, tm = R >> 5, r = R & 31;
+          const int dy = PW == 16 ? tm + (PH / 2) * (r >> 4) : 4 * tm + (r >> 3);
+          const int dx = PW == 16 ? (r & 15) : (r & 7);
+          if (y0 + dy >= p.H || x0 + dx >= p.W || !nok) continue;
+          const long long pix = pimg + (long long)(y0 + dy) * p.W + (x0 + dx);
+          if (partial_) {
+            *reinterpret_cast<float4*>(p.ws + ((long long)ks * p.M + pix) * p.N + nb) = v;
+          } else {
+            act_t* c = p.C + pix * p.ldc + nb;
+            v = make_float4(v.x * p.alpha + bv4.x, v.y * p.alpha + bv4.y, v.z * p.alpha + bv4.z, v.w * p.alpha + bv4.w);
+            if (p.res) {
+              const float4 r4 = osm::ld4(p.res + pix * p.ldr + nb);
+              v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
+            if (p.accumulate) {
+              const float4 r4 = osm::ld4(c);
+              v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
+            osm::st4(c, v);
+            if (stats_) {
+              float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (p.stat_mode == 2) xv = osm::ld4(p.stat_x + pix * p.ld_sx + nb);
+              stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, q1[0], q2[0]);
+              stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, q1[1], q2[1]);
+              stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, q1[2], q2[2]);
+              stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, q1[3], q2[3]);
+            }
+          }
+        }
+      }
+      if (stats_) {      // lanes with the same (lane & 7) hold the same 4 columns: fold them, lanes 0-7 write
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int m_ = 8; m_ < 64; m_ <<= 1) {
+            q1[k] += __shfl_xor(q1[k], m_, 64);
+            q2[k] += __shfl_xor(q2[k], m_, 64);
+          }
+        if (lane < 8 && nok) {
+          float* o = p.colsum + ((long long)img * p.stat_chunks + (ty * tpx + tx)) * 2 * p.N + nb;
+          *reinterpret_cast<float4*>(o) = make_float4(q1[0], q1[1], q1[2], q1[3]);
+          *reinterpret_cast<float4*>(o + p.N) = make_float4(q2[0], q2[1], q2[2], q2[3]);
+        }
+      }
+      return;
+    }
+  }
+  // scalar form (unaligned / odd shapes, and the narrow variant)
   const bool partial = p.splitk > 1;
   const long long ldc = partial ? (long long)p.N : p.ldc;
   const int n = n0 + (NARROW ? 0 : 32 * wave) + lr;

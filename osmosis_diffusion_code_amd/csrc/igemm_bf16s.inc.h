@@ -233,6 +233,56 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool partial = p.splitk > 1;
   float* Wb = p.ws + ((long long)ks * p.M) * p.N;       // fp32 partials [ks][M][N]
+  // Stores are ISSUE-bound (a store instruction costs the same whether a lane writes 4 or 16 bytes, and the 64 four-byte
+  // stores of this layout were two thirds of a 256-channel 1x1 convolution): each wave transposes its 128 x 32 tile
+  // through its own slice of the (now idle) staging LDS, RP rows at a time, so that a lane owns 4 consecutive columns
+  // of a row: 16 x (ds_read_b128 + one 16-byte store) instead of 64 scalar stores.  LDS executes a wave's operations in
+  // order, so no barrier is needed around the wave-private slice.
+  const auto al = [](const void* q, unsigned bytes) { return (reinterpret_cast<unsigned long long>(q) & (bytes - 1)) == 0; };
+  const bool vec = (p.N & 3) == 0 &&
+                   (partial ? al(p.ws, 16)
+                            : ((p.ldc & 3) == 0 && al(p.C, 4 * ACT_B) && (!p.bias || al(p.bias, 16)) &&
+                               (!p.res || ((p.ldr & 3) == 0 && al(p.res, 4 * ACT_B)))));
+  if (vec) {
+    constexpr int RP = NP == 1 ? 32 : 64;               // rows per pass (the fp16 family's staging LDS is 20 KB)
+    float* tb = reinterpret_cast<float*>(smem) + wave * (RP * 32);
+    const int c4 = 4 * (lane & 7), rr = lane >> 3;
+    const int nb = n0 + 32 * wave + c4;
+    const bool nok = nb < p.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!partial && p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + nb);
+#pragma unroll
+    for (int pass = 0; pass < 128 / RP; ++pass) {
+#pragma unroll
+      for (int t = 0; t < RP / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          tb[(32 * t + (e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + lr] = acc[pass * (RP / 32) + t][e];
+#pragma unroll
+      for (int it = 0; it < RP / 8; ++it) {
+        const int row = 8 * it + rr;
+        float4 v = *reinterpret_cast<const float4*>(tb + row * 32 + c4);
+        const int m = m0 + pass * RP + row;
+        if (m >= p.M || !nok) continue;
+        if (partial) {
+          *reinterpret_cast<float4*>(Wb + (long long)m * p.N + nb) = v;
+        } else {
+          act_t* cp = p.C + (long long)m * p.ldc + nb;
+          v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
+          if (p.res) {
+            const float4 r4 = osm::ld4(p.res + (long long)m * p.ldr + nb);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          if (p.accumulate) {
+            const float4 r4 = osm::ld4(cp);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          osm::st4(cp, v);
+        }
+      }
+    }
+    return;
+  }
   const int n = n0 + 32 * wave + lr;
   if (n >= p.N) return;
   const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
