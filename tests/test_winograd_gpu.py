@@ -241,3 +241,38 @@ def test_winograd_fp16_family(ops, B, Cin, Cout, H, W, splitk, gn):
     ops.conv2d(ops.Mat.of(dyh), ud, None, ops.Mat.of(dx), B, H, W, 3, splitk=splitk, splitk_ws=ws2, wfmt=1 | ops.WINOGRAD)
     e = relerr(from_nhwc(dx.float(), B, H, W), dref.float())
     assert e < 1.5e-3, ("dgrad", e)
+
+
+def test_full_size_unet_winograd_vs_direct_kernel(monkeypatch):
+    """The real 552.8 M-parameter UNet at 1x4x256x256, forward and input gradient, with the Winograd kernel on its 3x3
+    layers (default) and with the direct halo-tile kernel everywhere (OSM_WINOGRAD=0): same network, two algorithms for
+    88 of its convolutions -- they must agree to fp32 rounding (both are fp32-class: 6 bf16 MFMAs per product)."""
+    from oracle import unet_ref as U
+    from osmosis_diffusion_code_amd.guided_diffusion.unet import create_model
+    kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
+              class_cond=False, use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4,
+              num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+              resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path="",
+              pretrain_model="osmosis")
+    cfg = U.UNetConfig.from_create_model_kwargs(**kw)
+    sd = U.seeded_state_dict(cfg, 1234)
+    g = torch.Generator().manual_seed(0)
+    x = 0.7 * torch.randn(1, 4, 256, 256, generator=g)
+    t = torch.tensor([37.0])
+    w = torch.randn(1, 8, 256, 256, generator=g)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OSM_WINOGRAD", flag)
+        m = create_model(**kw)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        xd = x.to(DEV).requires_grad_(True)
+        yd = m(xd, t.to(DEV))
+        (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+        outs[flag] = (yd.detach().cpu(), dxd.cpu())
+        del m
+        torch.cuda.empty_cache()
+    ey = relerr(outs["1"][0], outs["0"][0])
+    ed = relerr(outs["1"][1], outs["0"][1])
+    print("Winograd vs direct, full size: y", ey, "dx", ed)
+    assert ey < 2e-5 and ed < 2e-5
