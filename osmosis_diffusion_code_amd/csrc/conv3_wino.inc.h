@@ -37,7 +37,8 @@
 #define WN_VPM 5      // VALU instructions asked for after every MFMA of a region
 #endif
 #ifndef WN_ABL
-#define WN_ABL 0        // measurement builds (tools/wino_ablate.sh): 1 no activation loads, 2 no U loads
+#define WN_ABL 0        // measurement builds (tools/wino_ablate.sh): 1 no activation loads, 2 no U loads, 4 no epilogue,
+                        // 8 no slab loop, 16 epilogue without its global stores (results are then wrong, of course)
 #endif
 constexpr int WN_ROWP = 20;                  // 16-byte slots per staged row: [column parity 2][10 (9 used)]
 constexpr int WN_QP = 18 * WN_ROWP + 1;      // slots per channel-quad plane (+1: the 4 quads of a pixel hit 4 bank groups)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const act_t* __restr
         const bool ok = nok && xok;
         const int po = dy * p.W + dx;               // pixel offset inside the image
         if (partial) {
-          if (ok) *reinterpret_cast<float4*>(wbase + po * p.N + n) = v;
+          if (ok && !((WN_ABL & 16) && p.alpha != 12345.f)) *reinterpret_cast<float4*>(wbase + po * p.N + n) = v;
         } else {
           act_t* __restrict__ op = obase + po * (int)p.ldc + n;
           v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const act_t* __restr
 #if WN_NT_STORE && !OSM_ACT_IS_F16
           if (ok) __builtin_nontemporal_store(osm::floatx4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<osm::floatx4_t*>(op));
 #else
-          if (ok) osm::st4(op, v);
+          if (ok && !((WN_ABL & 16) && p.alpha != 12345.f)) osm::st4(op, v);     // 16: measurement build without the stores
 #endif
           if (stats && ok) {
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
