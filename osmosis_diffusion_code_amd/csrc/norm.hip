@@ -15,9 +15,15 @@ namespace {
 // Pixel rows per chunk (one workgroup).  Low-resolution layers (8x8 ... 32x32 with 512-2048 channels) are
 // latency-bound, not bandwidth-bound: a fixed 64-row chunk left them with 1-16 workgroups and 64 dependent
 // row iterations per thread (measured 80 us for a 262 KB tensor); chunks shrink so that >= ~64 workgroups exist.
+// (round 2: HW / 512 instead of HW / 256 -- 512 workgroups on a 128x128 tensor, 256 on 64x64 ... -- measured -8 % over the step's
+// GroupNorm kernels; HW / 384, / 768, / 1024 and caps of 32 / 48 / 128 rows were all worse)
+#ifndef GN_PPC_DIV
+#define GN_PPC_DIV 512
+#define GN_PPC_MAX 64
+#endif
 __host__ __device__ inline int gn_ppc(int HW) {
-  int p = HW / 256;
-  return p < 4 ? 4 : (p > 64 ? 64 : p);
+  int p = HW / GN_PPC_DIV;
+  return p < 4 ? 4 : (p > GN_PPC_MAX ? GN_PPC_MAX : p);
 }
 constexpr int NJMAX = 4;  // channel vectors per thread (C <= 4096)
 
