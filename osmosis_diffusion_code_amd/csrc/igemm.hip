@@ -711,8 +711,9 @@ extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize
   if (wfmt & OSM_WFMT_WINOGRAD) {   // workgroups of 16 x 16 pixels x 64 columns, 16-channel slabs, one workgroup per CU
     const long long tiles = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + 63) / 64);
     const int nslab = 2 * ((Cin + 31) / 32);
-    if (tiles >= 192) return 1;
-    long long s = (256 + tiles - 1) / tiles;
+    static const int wtarget = [] { const char* e = std::getenv("OSM_WINO_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    if (tiles >= (3 * wtarget) / 4) return 1;
+    long long s = (wtarget + tiles - 1) / tiles;
     if (s > nslab / 4) s = nslab / 4;
     return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
   }
