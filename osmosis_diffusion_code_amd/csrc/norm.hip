@@ -560,7 +560,12 @@ int check_common(const GNArgs& a, const char* who) {
   return OSM_OK;
 }
 
-constexpr int GN_FUSE_CHUNKS = 256;   // apply kernels re-combine up to this many chunk partials themselves
+// (round 2: 0 = never.  Re-combining the chunk partials in every apply workgroup cost more than the 6 us finalize launch it
+// saved: 4.39 -> 4.25 ms of GroupNorm per step; 128 / 256 / 512 / 1024 measured in that order of increasing cost)
+#ifndef GN_FUSE_CHUNKS_V
+#define GN_FUSE_CHUNKS_V 0
+#endif
+constexpr int GN_FUSE_CHUNKS = GN_FUSE_CHUNKS_V;   // apply kernels re-combine up to this many chunk partials themselves
 
 template <int MODE>
 int run_reduce(GNArgs& a, float* finalized, hipStream_t st, bool finalize = true) {
