@@ -1,0 +1,379 @@
+// Winograd F(2x2, 3x3), two waves per SIMD (included inside igemm.hip's anonymous namespace, after conv3_wino.inc.h).
+//
+// Same algorithm, weight image, workgroup tile (16 x 16 output pixels x 64 output channels, 16-channel slabs), LDS staging
+// layout and epilogue semantics as conv3_wino_kernel; what changes is WHO issues the instructions.  The 4-wave kernel runs one
+// wave per SIMD with 16 accumulators: per slab it issues 96 MFMAs next to ~650 VALU / LDS / memory instructions, and a single
+// wave can hide at most ~5 other instructions under one 32-cycle MFMA (MI355X_MICROARCH.md, "one wave per SIMD"), so the matrix
+// pipe sat at 41-45 % busy (profiles/r02_pmc_mfma_busy.json).  Here a workgroup has 8 waves -- two per SIMD, 8 accumulators
+// (128 AGPRs) each -- so the exact 3-plane split of one wave's V fragments issues while its partner's MFMAs occupy the matrix
+// pipe: the VALU and MFMA pipes of a SIMD run concurrently for different waves (tools/ubench/mfma_rate.hip).
+//
+//   wave (r, h): xi row r = wave & 3 of B^T d (two input rows of a tile, as before) and xi COLUMN PAIR h = wave >> 2:
+//          h = 0: V0 = t0 - t2, V1 = t1 + t2;   h = 1: V2 = t2 - t1, V3 = t1 - t3     (t = the wave's row of B^T d)
+//          for both 32-tile blocks and both 32-column tiles: acc[2 xi][2 tile blocks][2 column tiles].
+//   unit   = (local xi jj, tile block tb): 12 MFMAs (2 column tiles x 6 plane pairs) on one A fragment triple va; while they
+//          run, the NEXT unit's va is built (8 LDS reads, 24 FMAs, the 44-op split).  U fragments of a xi (24 registers) are
+//          loaded two units ahead into the registers the previous slab's same xi just released.
+//   out    the xi columns are now spread over the wave pair: h = 0 contributes (M0 + M1, M1), h = 1 (M2, -M2 - M3) to
+//          (s0, s1); all eight waves write their two partial column transforms to LDS (aliasing the staging buffers), and
+//          wave (oy, ox, column tile) sums 3 xi rows x 2 halves and stores output pixel (oy, ox) of every tile, 16 bytes a lane.
+#ifndef W8_ABL
+#define W8_ABL 0        // measurement builds (tools/wino8_ablate.sh; results are then wrong): 1 no activation loads, 2 no U loads,
+                        // 4 no epilogue, 8 no LDS reads in the V build, 16 no split, 32 MFMAs replaced by one VALU op each,
+                        // 64 activation loads re-read slab 0 (cache hits), 128 U loads re-read one 6 KB piece (cache hits)
+#endif
+#ifndef W8_LATE
+#define W8_LATE 0
+#endif
+constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
+
+template <int NP, bool GNF>
+__global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __restrict__ Aglob,
+                                                              const unsigned short* __restrict__ Uglob, IGemmParams p) {
+  // 128 KB: the two raw slabs (46 KB) during the slab loop, the 8-wave exchange buffer of the epilogue after it
+  __shared__ __attribute__((aligned(16))) float smem[8 * 2 * 2 * 16 * 64];
+  float4* raw = reinterpret_cast<float4*>(smem);
+  float* red = smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave & 3, wh = wave >> 2;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  // ---- XCD-aware tile mapping: identical to conv3_wino_kernel
+  const int nt = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int qq = nt >> 3, rr8 = nt & 7, xcd = bid & 7, idx8 = bid >> 3;
+  const int id = (xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq) + idx8;
+  const int grp_sz = p.nb1 * p.mtiles;
+  const int tile_n = (id / grp_sz) * p.nb1 + id % p.nb1, tile_m = (id % grp_sz) / p.nb1;
+  const int tpx = (p.W + 15) >> 4, tpy = (p.H + 15) >> 4;
+  const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
+  const int x0 = tx * 16, y0 = ty * 16;
+
+  const int ks = blockIdx.y;
+  const int nslab = p.ksteps;
+  const int per = (nslab + p.splitk - 1) / p.splitk;
+  const int kc0 = ks * per;
+  const int kc1 = min(nslab, kc0 + per);
+
+  // ---- raw staging coordinates: piece s = tid + 512 j -> channel quad tid & 3, halo pixel (tid >> 2) + 128 j
+  const int q4 = tid & 3;
+  const long long rowB = (long long)p.lda * ACT_B;
+  const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
+  unsigned voff[W8_NJ], woff[W8_NJ], vmask = 0;
+#pragma unroll
+  for (int j = 0; j < W8_NJ; ++j) {
+    const int pix = (tid >> 2) + 128 * j;
+    const int r = pix / 18, col = pix - r * 18;
+    const bool in = pix < 324;
+    woff[j] = (unsigned)(q4 * WN_QP + (in ? r * WN_ROWP + (col & 1) * 10 + (col >> 1) : 17 * WN_ROWP + 19));
+    const int y = y0 - 1 + r, x = x0 - 1 + col;
+    const bool ok = in && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
+    voff[j] = (W8_ABL & 256) ? (unsigned)((tid + 512 * j) * 16) : (unsigned)((long long)(yc * p.W + xc) * rowB);
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+
+  // ---- U fragments: image [plane][xi][slab][n/32][lane][8]; this wave reads xi = 4 wr + 2 wh + jj
+  const int jn0 = 2 * tile_n;
+  const unsigned u_lane = (unsigned)((jn0 * 64 + lane) * 16);
+  const unsigned u_nt = jn0 + 1 < p.nt32 ? 1024u : 0u;
+  const unsigned u_slab = (unsigned)p.nt32 * 1024u;
+  const unsigned u_xi = u_slab * (unsigned)nslab;
+  const unsigned u_plane = u_xi * 16u;
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(Uglob)), 0, 0x7fffffff, 0x00020000);
+
+  f32x16 acc[2][2][2];      // [local xi jj][tile block][column tile]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][a][b][e] = 0.f;
+
+  // ---- this wave's row of B^T d (as in the 4-wave kernel): t = x + sg y, rows (rx, ry) of the 4 x 4 tile
+  const int tyl = lr >> 3, txl = lr & 7;
+  const int rx = wr == 0 ? 0 : (wr == 2 ? 2 : 1), ry = wr == 2 ? 1 : (wr == 3 ? 3 : 2);
+  const float sg = wr == 1 ? 1.f : -1.f;
+  const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
+  const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
+
+  float4 ra[W8_NJ];
+  float4 gm, gs, gb;        // fused GroupNorm: mean | rstd * gamma | beta of this thread's channel quad
+  gm = gs = gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
+  uint4 uq[2][2][NP];       // [local xi][column tile][plane]
+  uint4 va[2][NP];          // A fragments, [unit parity][plane]
+
+#define OSM_W8_LOAD_RAW(cc_, j_)                                                           \
+  {                                                                                        \
+    const bool cok_ = (cc_) * 16 + 4 * q4 < p.K;                                           \
+    const unsigned d_ = (unsigned)(((cc_) * 16 + 4 * q4) * ACT_B);                         \
+    ra[j_] = (W8_ABL & 1) ? make_float4(1.f, 2.f, 3.f, (float)d_)                          \
+                          : osm::ld4(reinterpret_cast<const act_t*>(sbaseA + (voff[j_] + ((cok_ && !(W8_ABL & 64)) ? d_ : 0u)))); \
+  }
+#define OSM_W8_LOAD_TAB(cc_)                                                               \
+  if (GNF) {                                                                               \
+    const bool cok_ = (cc_) * 16 + 4 * q4 < p.K;                                           \
+    const float* gt_ = gtab + (cok_ ? (cc_) * 16 + 4 * q4 : 0);                            \
+    gm = *reinterpret_cast<const float4*>(gt_);                                            \
+    const float4 gr_ = *reinterpret_cast<const float4*>(gt_ + p.K);                        \
+    const float4 gg_ = *reinterpret_cast<const float4*>(gt_ + 2 * p.K);                    \
+    gs = make_float4(gr_.x * gg_.x, gr_.y * gg_.y, gr_.z * gg_.z, gr_.w * gg_.w);          \
+    gb = *reinterpret_cast<const float4*>(gt_ + 3 * p.K);                                  \
+  }
+#define OSM_W8_STORE_RAW(cc_, j_)                                                          \
+  {                                                                                        \
+    const unsigned okm_ = ((cc_) * 16 + 4 * q4 < p.K) ? vmask : 0u;                        \
+    float4 v = ra[j_];                                                                     \
+    if (W8_ABL & 512) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); v = make_float4(1.f, 2.f, 3.f, (float)(cc_)); } \
+    if (GNF) {                                                                             \
+      v.x = (v.x - gm.x) * gs.x + gb.x;                                                    \
+      v.y = (v.y - gm.y) * gs.y + gb.y;                                                    \
+      v.z = (v.z - gm.z) * gs.z + gb.z;                                                    \
+      v.w = (v.w - gm.w) * gs.w + gb.w;                                                    \
+      if (p.gn_silu) {                                                                     \
+        v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w); \
+      }                                                                                    \
+    }                                                                                      \
+    raw[((cc_) & 1) * (4 * WN_QP) + woff[j_]] = sel4((okm_ >> (j_)) & 1u, v);             \
+  }
+#define OSM_W8_LOAD_U(cc_, jj_)                                                            \
+  {                                                                                        \
+    const unsigned so_ = (W8_ABL & 128) ? (unsigned)((cc_) & 1) * 64u                      \
+                                        : (unsigned)(4 * wr + 2 * wh + (jj_)) * u_xi + (unsigned)(cc_) * u_slab; \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                          \
+      _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                    \
+        uq[jj_][b][q2] = (W8_ABL & 2) ? make_uint4(so_, u_lane, q2, b)                     \
+            : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(             \
+                  ursrc, (int)u_lane, (int)(so_ + (unsigned)q2 * u_plane + (unsigned)b * u_nt), 0)); \
+  }
+// A fragments of unit (local xi jj_, tile block tb_) from the raw slab at slot offset bo_: V = t[ca] + sb t[cb],
+// t[c] = x[c] + sg y[c] (column c of the tile = parity c & 1, slot txl + (c >> 1)), split into NP planes
+#define OSM_W8_BUILD(par_, ca_, cb_, sb_, tb_, bo_)                                        \
+  {                                                                                        \
+    uint2 vh_[2][NP];                                                                      \
+    _Pragma("unroll") for (int hq = 0; hq < 2; ++hq) {                                     \
+      const int oa_ = (bo_) + hq * WN_QP + 8 * (tb_) * WN_ROWP + ((ca_) & 1) * 10 + ((ca_) >> 1); \
+      const int ob_ = (bo_) + hq * WN_QP + 8 * (tb_) * WN_ROWP + ((cb_) & 1) * 10 + ((cb_) >> 1); \
+      osm::floatx4_t xa_, ya_, xb_, yb_;                                                   \
+      if (W8_ABL & 8) { xa_ = ya_ = xb_ = yb_ = osm::floatx4_t{(float)oa_, sg, (float)ob_, 1.f}; } \
+      else { xa_ = t_x[oa_]; ya_ = t_y[oa_]; xb_ = t_x[ob_]; yb_ = t_y[ob_]; }            \
+      float4 v_;                                                                           \
+      v_.x = fmaf(sg, ya_[0], xa_[0]) + (sb_) * fmaf(sg, yb_[0], xb_[0]);                  \
+      v_.y = fmaf(sg, ya_[1], xa_[1]) + (sb_) * fmaf(sg, yb_[1], xb_[1]);                  \
+      v_.z = fmaf(sg, ya_[2], xa_[2]) + (sb_) * fmaf(sg, yb_[2], xb_[2]);                  \
+      v_.w = fmaf(sg, ya_[3], xa_[3]) + (sb_) * fmaf(sg, yb_[3], xb_[3]);                  \
+      if (W8_ABL & 16) { _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                  \
+          vh_[hq][q2] = make_uint2(__float_as_uint(v_.x) + q2, __float_as_uint(v_.y) ^ __float_as_uint(v_.z) ^ __float_as_uint(v_.w)); } \
+      else split_planes<NP>(v_, vh_[hq]);                                                  \
+    }                                                                                      \
+    _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
+      va[par_][q2] = make_uint4(vh_[0][q2].x, vh_[0][q2].y, vh_[1][q2].x, vh_[1][q2].y);   \
+  }
+// the 12 MFMAs of unit (jj_, tb_): smallest plane-pair terms first
+#define OSM_W8_MMA(par_, jj_, tb_)                                                         \
+  _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
+    _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
+        if (W8_ABL & 32) acc[jj_][tb_][b][(pa * 3 + pb) & 15] += __uint_as_float((va[par_][pa].x ^ uq[jj_][b][pb].y) + (va[par_][pa].z ^ uq[jj_][b][pb].w)); \
+        else acc[jj_][tb_][b] = mma16<NP>(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);
+// nothing crosses a unit boundary (keeps the prefetch distance of the loads and the live ranges of va / uq as written)
+#define OSM_W8_FENCE()                                                                     \
+  asm volatile("" ::: "memory");                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one K loop per column pair: the (column, sign) constants of V differ, everything else is shared
+  auto slab_loop = [&](auto hc) __attribute__((always_inline)) {
+    constexpr int H = decltype(hc)::value;
+    // local xi 0: V = t[CA0] - t[CB0];  local xi 1: V = t[CA1] + SB1 t[CB1]
+    constexpr int CA0 = H ? 2 : 0, CB0 = H ? 1 : 2;
+    constexpr int CA1 = 1, CB1 = H ? 3 : 2;
+    constexpr float SB1 = H ? -1.f : 1.f;
+    const int k1 = min(kc0 + 1, kc1 - 1);
+    OSM_W8_LOAD_RAW(kc0, 0) OSM_W8_LOAD_RAW(kc0, 1) OSM_W8_LOAD_RAW(kc0, 2)
+    OSM_W8_LOAD_TAB(kc0)
+    OSM_W8_LOAD_U(kc0, 0)
+    OSM_W8_STORE_RAW(kc0, 0) OSM_W8_STORE_RAW(kc0, 1) OSM_W8_STORE_RAW(kc0, 2)
+    OSM_W8_LOAD_RAW(k1, 0) OSM_W8_LOAD_RAW(k1, 1) OSM_W8_LOAD_RAW(k1, 2)
+    OSM_W8_LOAD_TAB(k1)
+    __syncthreads();
+    OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, (kc0 & 1) * (4 * WN_QP))
+    OSM_W8_FENCE()
+    for (int c = kc0; c < kc1; ++c) {
+      const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
+      const int bo = (c & 1) * (4 * WN_QP), bn = ((c + 1) & 1) * (4 * WN_QP);
+      // unit 0 = (xi 0, block 0) | builds (xi 0, block 1); U of xi 1 for this slab
+      OSM_W8_LOAD_U(c, 1)
+#if !W8_LATE
+      OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
+#endif
+      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo)
+      OSM_W8_MMA(0, 0, 0)
+#if W8_LATE
+      __builtin_amdgcn_sched_barrier(0);
+      OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
+#endif
+      OSM_W8_FENCE()
+      // unit 1 = (xi 0, block 1) | builds (xi 1, block 0)
+#if !W8_LATE
+      OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
+#endif
+      OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo)
+      OSM_W8_MMA(1, 0, 1)
+#if W8_LATE
+      __builtin_amdgcn_sched_barrier(0);
+      OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
+#endif
+      OSM_W8_FENCE()
+      // unit 2 = (xi 1, block 0) | builds (xi 1, block 1); U of xi 0 for the next slab
+      OSM_W8_LOAD_U(c1, 0)
+#if !W8_LATE
+      OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
+#endif
+      OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo)
+      OSM_W8_MMA(0, 1, 0)
+#if W8_LATE
+      __builtin_amdgcn_sched_barrier(0);
+      OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
+#endif
+      OSM_W8_FENCE()
+      __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
+      // unit 3 = (xi 1, block 1) | builds (xi 0, block 0) of slab c + 1
+      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn)
+      OSM_W8_MMA(1, 1, 1)
+      OSM_W8_FENCE()
+    }
+  };
+  if (kc1 > kc0) {
+    if (wh == 0) slab_loop(std::integral_constant<int, 0>{});
+    else slab_loop(std::integral_constant<int, 1>{});
+  }
+#undef OSM_W8_LOAD_RAW
+#undef OSM_W8_LOAD_TAB
+#undef OSM_W8_STORE_RAW
+#undef OSM_W8_LOAD_U
+#undef OSM_W8_BUILD
+#undef OSM_W8_MMA
+#undef OSM_W8_FENCE
+
+  if ((W8_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
+  // ---- Y = A^T M A.  xi columns: s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 -> this wave's partials p0 | p1:
+  //   h = 0 (M0, M1): (M0 + M1, M1);   h = 1 (M2, M3): (M2, -(M2 + M3)).
+  // xi rows: Y[0][.] = s(0) + s(1) + s(2), Y[1][.] = s(1) - s(2) - s(3).  One tile block per round.
+  // red: [wave = 4 h + r][ox][column tile][e][lane = 32 lk + column]; finishing wave f = (oy, ox, column tile b).
+  const int oy = wave >> 2, ox = (wave >> 1) & 1, fb = wave & 1;
+  const bool partial = p.splitk > 1;
+  const long long pix0 = (long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox);
+  float* __restrict__ wbase = p.ws + ((long long)ks * p.M + pix0) * p.N;
+  act_t* __restrict__ obase = p.C + pix0 * p.ldc;
+  const act_t* __restrict__ rbase = (!partial && p.res) ? p.res + pix0 * p.ldr : nullptr;
+  const int c4 = 4 * (lane & 7), lk2 = (lane >> 3) & 1, e_lo = lane >> 4;
+  const int dx = 2 * (e_lo + 4 * lk2);
+  const bool xok = x0 + ox + dx < p.W;
+  const float* red_rd = red + ((ox * 2 + fb) * 16 + e_lo) * 64 + lk2 * 32 + c4;   // + ((wave' * 4) * 16 + 4 i) * 64
+  const bool stats = p.colsum != nullptr && !partial;
+  float st1[4], st2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) st1[k] = st2[k] = 0.f;
+  const act_t* __restrict__ sxbase = (stats && p.stat_mode == 2) ? p.stat_x + pix0 * p.ld_sx : nullptr;
+  const int n = (jn0 + fb) * 32 + c4;
+  const bool nok = n < p.N && (fb == 0 || u_nt != 0u);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!partial && p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+  StatCol sc[4] = {};
+  if (sxbase && nok) {
+    const float* tb = p.stat_table + (long long)img * 4 * p.N + n;
+    const float4 tm = *reinterpret_cast<const float4*>(tb), tr = *reinterpret_cast<const float4*>(tb + p.N);
+    const float4 tg = *reinterpret_cast<const float4*>(tb + 2 * p.N), tbb = *reinterpret_cast<const float4*>(tb + 3 * p.N);
+    sc[0] = StatCol{tm.x, tr.x, tg.x, tbb.x}; sc[1] = StatCol{tm.y, tr.y, tg.y, tbb.y};
+    sc[2] = StatCol{tm.z, tr.z, tg.z, tbb.z}; sc[3] = StatCol{tm.w, tr.w, tg.w, tbb.w};
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float m0 = acc[0][a][b][e], m1 = acc[1][a][b][e];
+        float p0, p1;
+        if (wh == 0) { p0 = m0 + m1; p1 = m1; } else { p0 = m0; p1 = -(m0 + m1); }      // wave-uniform
+        red[(((wave * 2 + 0) * 2 + b) * 16 + e) * 64 + lane] = p0;
+        red[(((wave * 2 + 1) * 2 + b) * 16 + e) * 64 + lane] = p1;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // e' = 4 i + e_lo: tile row 4 a + i of the patch
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float4 s = *reinterpret_cast<const float4*>(red_rd + (((h2 * 4 + oy + k) * 4) * 16 + 4 * i) * 64);
+          if (oy == 0 || k == 0) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+          else { v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w; }
+        }
+      const int dy = 8 * a + 2 * i;
+      if (y0 + oy + dy >= p.H) continue;          // wave-uniform
+      const bool ok = nok && xok;
+      const int po = dy * p.W + dx;
+      if (partial) {
+        if (ok) *reinterpret_cast<float4*>(wbase + po * p.N + n) = v;
+      } else {
+        act_t* __restrict__ op = obase + po * (int)p.ldc + n;
+        v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
+        if (rbase && ok) {
+          const float4 r = osm::ld4(rbase + po * (int)p.ldr + n);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (p.accumulate && ok) {
+          const float4 r = osm::ld4(op);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (ok) osm::st4(op, v);
+        if (stats && ok) {
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
+          stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, st1[0], st2[0]);
+          stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, st1[1], st2[1]);
+          stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, st1[2], st2[2]);
+          stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, st1[3], st2[3]);
+        }
+      }
+    }
+  }
+  if (stats) {       // workgroup-uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {          // lanes with the same (lane & 7) hold the same columns
+        st1[k] += __shfl_xor(st1[k], m, 64);
+        st2[k] += __shfl_xor(st2[k], m, 64);
+      }
+    }
+    __syncthreads();            // the last round's reads of red are over
+    if (lane < 8) {             // red: [wave][which sum][32 columns]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[(wave * 2 + 0) * 32 + 4 * lane + k] = st1[k];
+        red[(wave * 2 + 1) * 32 + 4 * lane + k] = st2[k];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {            // (column tile b, which sum, column): the four (oy, ox) waves of column tile b are 2 q + b
+      const int b = tid >> 6, w2 = (tid >> 5) & 1, col = tid & 31;
+      const int nn = (jn0 + b) * 32 + col;
+      if (nn < p.N && (b == 0 || u_nt != 0u)) {
+        const float v = (red[((0 + b) * 2 + w2) * 32 + col] + red[((2 + b) * 2 + w2) * 32 + col]) +
+                        (red[((4 + b) * 2 + w2) * 32 + col] + red[((6 + b) * 2 + w2) * 32 + col]);
+        p.colsum[(((long long)img * p.stat_chunks + (ty * tpx + tx)) * 2 + w2) * p.N + nn] = v;
+      }
+    }
+  }
+}

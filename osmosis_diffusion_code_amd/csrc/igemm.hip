@@ -26,6 +26,7 @@
 #include "osm_common.h"
 #include "mfma_split.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -467,6 +468,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 #include "igemm_bf16s.inc.h"
 #include "conv3_halo.inc.h"
 #include "conv3_wino.inc.h"
+#include "conv3_wino8.inc.h"
 #include "skinny.inc.h"
 
 // ---- small-M path (skinny.inc.h): eligibility and its split of K
@@ -554,8 +556,13 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     for (int g = 2; g <= ngrp; ++g) if (p.ntiles % g == 0) p.nb1 = g;
     const unsigned short* Up = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 gw(p.mtiles * p.ntiles, p.splitk, 1);
+    // OSM_WINO8=0: the one-wave-per-SIMD kernel of round 2 (conv3_wino.inc.h) instead of the 8-wave kernel (A/B measurements)
+    static const bool wino8 = [] { const char* e = std::getenv("OSM_WINO8"); return !(e && e[0] == '0'); }();
 #define OSM_WINO_LAUNCH(NP_)                                                                               \
-    if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<NP_, true>), gw, dim3(256), 0, st, p.A, Up, p);  \
+    if (wino8) {                                                                                           \
+      if (p.gn_table) hipLaunchKernelGGL((conv3_wino8_kernel<NP_, true>), gw, dim3(512), 0, st, p.A, Up, p);  \
+      else hipLaunchKernelGGL((conv3_wino8_kernel<NP_, false>), gw, dim3(512), 0, st, p.A, Up, p);         \
+    } else if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<NP_, true>), gw, dim3(256), 0, st, p.A, Up, p);  \
     else hipLaunchKernelGGL((conv3_wino_kernel<NP_, false>), gw, dim3(256), 0, st, p.A, Up, p);
 #ifdef OSM_ACT_F16
     OSM_WINO_LAUNCH(1)

@@ -256,6 +256,7 @@ class UNetEngine:
         self.side_streams = self.use_graph and os.environ.get("OSM_SIDE_STREAMS", "0") != "0"
         self.winograd_min_hw = int(os.environ.get("OSM_WINOGRAD_MIN_HW", "16"))   # smallest H, W served by the Winograd kernel
         fs = os.environ.get("OSM_FUSE_STATS", "fwd")
+        self.fuse_gn_wino = os.environ.get("OSM_FUSE_GN_WINO", "0") == "1"
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs == "all"
 
@@ -329,11 +330,30 @@ class UNetEngine:
                    **skw)
         return (cs, nch) if cs is not None else None
 
+    def _is_wino(self, cv: _Conv, hw, dgrad=False) -> bool:
+        H, W = hw
+        cin, cout = (cv.cout, cv.cin) if dgrad else (cv.cin, cv.cout)
+        return cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
+            bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
+
     def _gn_fusable(self, cv: _Conv, hw) -> bool:
         """GroupNorm apply inside the consuming 3x3 convolution: needs the halo-tile kernel (split-bf16 / fp16 weights,
-        W >= 16, H >= 8) on a tensor that is not better served by the one-launch low-resolution GroupNorm."""
+        W >= 16, H >= 8) on a tensor that is not better served by the one-launch low-resolution GroupNorm.
+        NOT where the Winograd kernel serves the layer (round 3): that kernel is bound by its non-MFMA instructions and
+        the power cap, every one of its Cout / 64 column tiles redoes the normalisation + SiLU of its input patch
+        (256^2 256 -> 256: 326 us fused vs 256 us plain; a separate apply pass costs ~30 us): OSM_FUSE_GN_WINO=1 restores it."""
         H, W = hw
-        return self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256
+        if not (self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256):
+            return False
+        return self.fuse_gn_wino or not self._is_wino(cv, hw)
+
+    def _gn_stats_from_conv(self, cv: _Conv, hw) -> bool:
+        """May the convolution that produces a tensor also emit the column sums for the GroupNorm `cv` reads it through?"""
+        H, W = hw
+        if not (self.fuse_stats and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256):
+            return False
+        # not fused: finalize + apply are two launches, the one-launch GroupNorm (H W <= 1024) is cheaper than that
+        return self._gn_fusable(cv, hw) or H * W > 1024
 
     def _gn_conv(self, x: Mat, norm: _Norm, st, cv: _Conv, y: Mat, hw, film=None, res: Optional[Mat] = None,
                  cs=None, table=None, stat=None):
@@ -355,7 +375,11 @@ class UNetEngine:
                 ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
             return self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True, stat=stat)
         a = self._scr("a", B * H * W, x.cols)
-        ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
+        if cs is not None:      # statistics from the producer's column sums, then the apply pass alone
+            ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
+            ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True)
+        else:
+            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
         return self._conv(a, cv, y, hw, res=res, stat=stat)
 
     # ------------------------------------------------------------------ ResBlock
@@ -384,7 +408,7 @@ class UNetEngine:
             h1 = self._buf(Mo, blk.cout)
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
             tab1 = None
-            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if fuse2 else None)
+            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None)
         else:
             ho, wo = H, W
             xs = x
@@ -399,7 +423,8 @@ class UNetEngine:
                 # (memory-bound 1x1 beside the MFMA-bound 3x3); joined before the second 3x3 adds it as its residual
                 with side_branch(1) if self.side_streams else contextlib.nullcontext():
                     self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
-            cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1, stat=("fwd",) if fuse2 else None)
+            cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
+                                stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         if blk.skip is not None:

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--winograd", action="store_true", help="Winograd F(2x2,3x3) image where the layer allows it")
     ap.add_argument("--dgrad", action="store_true", help="run the data-gradient image (Cout -> Cin)")
+    ap.add_argument("--gn", action="store_true", help="fused GroupNorm + SiLU of the input while staging (synthetic table)")
     a = ap.parse_args()
     shapes = a.shape or ["1,256,256,256,256,3", "1,128,128,512,512,3", "1,128,128,256,256,3", "1,64,64,512,512,3",
                          "1,32,32,512,512,3", "1,16,16,1024,1024,3", "1,8,8,1024,1024,3", "1,256,256,256,512,1"]
@@ -41,7 +42,11 @@ def main():
         wf, _ = (ops.pack_conv_weight_winograd(w, wfmt=wfmt & 3) if wino else ops.pack_conv_weight(w, wfmt=wfmt))
         sk = ops.conv_splitk(B, H, W, Cin, Cout, k, wfmt)
         ws = torch.empty(sk * M * Cout, device=dev) if sk > 1 else None
-        run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt)  # noqa: E731
+        tab = None
+        if a.gn:     # [B][4][Cin]: mean | rstd | gamma | beta
+            tab = torch.stack([0.1 * torch.randn(B, Cin, device=dev, generator=g), 1.0 + 0.1 * torch.rand(B, Cin, device=dev, generator=g),
+                               1.0 + 0.1 * torch.randn(B, Cin, device=dev, generator=g), 0.1 * torch.randn(B, Cin, device=dev, generator=g)], 1).contiguous()
+        run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt, gn_table=tab)  # noqa: E731
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -55,7 +60,10 @@ def main():
         fl = 2.0 * M * Cin * Cout * k * k
         msg = f"{a.mode + ('+wino' if wino else ''):12s} {s:28s} splitk={sk:2d}  {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s"
         if a.check:
-            ref = torch.nn.functional.conv2d(x.float().view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
+            xin = x.float().view(B, H * W, Cin)
+            if a.gn:
+                xin = torch.nn.functional.silu((xin - tab[:, 0:1]) * tab[:, 1:2] * tab[:, 2:3] + tab[:, 3:4])
+            ref = torch.nn.functional.conv2d(xin.view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
             err = float((y.float().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
             msg += f"  relerr {err:.2e}"
         print(msg, flush=True)

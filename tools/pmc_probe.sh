@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage: tools/pmc_probe.sh <out_dir> <probe args...>   -- several rocprofv3 --pmc passes over tools/conv_probe.py
 # (counters only: never combined with sys/hip/hsa traces)
-out=$1; shift
-mkdir -p "$out"
+out=$(readlink -f "$1" 2>/dev/null || echo "$1"); shift
+mkdir -p "$out"; out=$(readlink -f "$out")
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
