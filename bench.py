@@ -217,7 +217,8 @@ def roofline(model, args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
             pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
-                    "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1"}[args.conv_mode]
+                    "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1",
+                    "f16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]
             if wino_dominant:
                 pref = pref.replace("conv3_halo_bf16s_kernel", "conv3_wino_kernel")
             hit = [k for k in json.load(open(path))["kernels"]
@@ -243,6 +244,10 @@ def roofline(model, args):
         "bf16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
                    "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative): "
                    "peak = 2500 / 3; achieved counts ALGORITHMIC flops"),
+        "f16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
+                  "Winograd 3x3 layers: fp32 operands scaled into the fp16 range by powers of two and split into 2 IEEE-half terms "
+                  "(~22-bit operands), 3 fp16 MFMAs per product, fp32 accumulation (fp32-class accuracy, tests vs fp64); every "
+                  "other contraction stays bf16x6: peak = dense fp16 MFMA peak 2500 TFLOP/s / 3; achieved counts ALGORITHMIC flops"),
         "f16": ("conv3_halo_bf16s_kernel<1>", BF16_MFMA_PEAK_TFLOPS,
                 "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one v_mfma_f32_32x32x16_f16 "
                 "per product; peak = dense fp16 MFMA peak 2500 TFLOP/s"),
@@ -343,7 +348,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU (reference config: 1)")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps for cpu_baseline (0 = skip)")
-    ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "bf16x3", "f16"],
+    ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "f16x3"), choices=["f32", "bf16x6", "bf16x3", "f16", "f16x3"],
                     help="conv arithmetic: exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")

@@ -55,7 +55,9 @@ typedef struct osm_conv_desc {
   int wfmt;            /* weight image: 0 = fp32 [tap][Cout][Cin] (exact-f32 MFMA);
                           3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
                           (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16);
-                          1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file */
+                          1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file;
+                          4 | OSM_WFMT_WINOGRAD = "f16x3": two IEEE-half planes per operand, both operands scaled into the
+                          fp16 range by powers of two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs */
   const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
@@ -72,6 +74,8 @@ typedef struct osm_conv_desc {
   const float* stat_x;
   long long ld_sx;
   const float* stat_table;
+  const float* x_maxabs; /* wfmt 4 only ("f16x3" Winograd image): [B][OSM_MAXABS_PARTS] partial max |x| of the input from osm_maxabs --
+                          the kernel scales x into the fp16 range by a power of two and undoes it in its epilogue */
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
 
@@ -225,6 +229,13 @@ int osm_linear(const float* x, const float* W, const float* b, float* y, int B, 
 /* ------------------------------------------------------------------ layout / elementwise */
 int osm_nchw_to_nhwc(const float* x, float* y, long long ldy, int B, int C, int HW, void* stream);
 int osm_nhwc_to_nchw(const float* x, long long ldx, float* y, int B, int C, int HW, void* stream);
+/* per-image max |x| of [B][rows_per_img][C] (row stride ldx) as OSM_MAXABS_PARTS partial maxima per image:
+ * out[B][OSM_MAXABS_PARTS], every entry rewritten on every call (no clearing, no atomics); the consumer folds them.  Feeds
+ * osm_conv_desc::x_maxabs.  No reference counterpart: the f16x3 arithmetic needs the operand range (nn.py:22-32 conv_nd
+ * has fp32's exponent range). */
+#define OSM_MAXABS_PARTS 512
+int osm_maxabs_parts(void);
+int osm_maxabs(const float* x, long long ldx, int B, long long rows_per_img, int C, float* out, void* stream);
 int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long M, int C,
                int accumulate, void* stream);
 
@@ -312,6 +323,7 @@ typedef struct osm_conv_desc_h {
   const osm_half_t* stat_x;
   long long ld_sx;
   const float* stat_table;
+  const float* x_maxabs;  /* unused in this family (keeps the layout of osm_conv_desc) */
 } osm_conv_desc_h;
 int osm_conv2d_nhwc_h(const osm_conv_desc_h* d, void* stream);
 int osm_gn_stats_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps,

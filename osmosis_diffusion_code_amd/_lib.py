@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("ldx", C.c_longlong), ("ldy", C.c_longlong), ("ldr", C.c_longlong), ("wfmt", C.c_int),
                 ("gn_table", C.c_void_p), ("gn_silu", C.c_int),
                 ("colsum", C.c_void_p), ("stat_mode", C.c_int), ("stat_silu", C.c_int), ("stat_x", C.c_void_p),
-                ("ld_sx", C.c_longlong), ("stat_table", C.c_void_p)]
+                ("ld_sx", C.c_longlong), ("stat_table", C.c_void_p), ("x_maxabs", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -100,6 +100,8 @@ _SIGS = {
     "osm_nchw_to_nhwc": [_P, _P, _LL, _I, _I, _I, _P],
     "osm_nhwc_to_nchw": [_P, _LL, _P, _I, _I, _I, _P],
     "osm_copy2d": [_P, _LL, _P, _LL, _LL, _I, _I, _P],
+    "osm_maxabs": [_P, _LL, _I, _LL, _I, _P, _P],
+    "osm_maxabs_parts": [],
     "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "osm_phys_nblk": [_I],
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],

@@ -449,6 +449,36 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const act_t* __restr
 // MFMA-fragment order [plane][xi = 4 a + b][16-channel slab s][n/32 j][lane l][e]: n = 32 j + (l & 31),
 // k = 16 s + 8 (l >> 5) + e.  forward: n = Cout, k = Cin; data-gradient: n = Cin, k = Cout, taps flipped.
 // U is formed in double, rounded once to fp32, and that fp32 value is split exactly into the planes.
+// U = G g G^T of one (n, k, xi) in double
+__device__ __forceinline__ double wino_u(const float* __restrict__ w, int Cout, int Cin, int N, int K, int nn, int kk, int xi,
+                                         int dgrad) {
+  double u = 0.0;
+  if (nn < N && kk < K) {
+    const int co = dgrad ? kk : nn, ci = dgrad ? nn : kk;
+    const float* g = w + ((long long)co * Cin + ci) * 9;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int a = xi >> 2, b = xi & 3;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const float gv = dgrad ? g[(2 - r) * 3 + (2 - c)] : g[r * 3 + c];
+        u += G[a][r] * (double)gv * G[b][c];
+      }
+  }
+  return u;
+}
+// f16x3 image, pass 1: max |U| over the whole tensor, as the bit pattern of a non-negative float (atomicMax on uint)
+__global__ void wino_umax_kernel(const float* __restrict__ w, unsigned* __restrict__ umax, int Cout, int Cin, int dgrad) {
+  const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  const long long total = 16LL * N * K;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xi = (int)(i & 15);
+    const long long r = i >> 4;
+    m = fmaxf(m, fabsf((float)wino_u(w, Cout, Cin, N, K, (int)(r / K), (int)(r % K), xi, dgrad)));
+  }
+  m = osm::wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(umax, __float_as_uint(m));
+}
 __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
                                         int np, int dgrad) {
   const int N = dgrad ? Cin : Cout;
@@ -456,6 +486,15 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned sh
   const int nt32 = (N + 31) / 32;
   const int ksteps = 2 * ((K + 31) / 32);
   const long long per_plane = 16LL * ksteps * nt32 * 512;
+  // np = 4 (f16x3): two IEEE-half planes of U * 2^ew, 2^ew = the power of two that brings max |U| (left behind the planes
+  // by wino_umax_kernel) to [2^13, 2^14); the word is rewritten as that scale (a float) by the last statement
+  float wsc = 1.f;
+  if (np == 4) {
+    const float mx = __uint_as_float(*reinterpret_cast<const unsigned*>(out + 2 * per_plane + 2));   // copy made below
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 14 - e; }
+    wsc = ldexpf(1.f, e);
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_plane;
        i += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
@@ -467,21 +506,17 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned sh
     const int xi = (int)(rest / ksteps);
     const int nn = 32 * j + (l & 31);
     const int kk = 16 * s + 8 * (l >> 5) + e;
-    double u = 0.0;
-    if (nn < N && kk < K) {
-      const int co = dgrad ? kk : nn, ci = dgrad ? nn : kk;
-      const float* g = w + ((long long)co * Cin + ci) * 9;
-      const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-      const int a = xi >> 2, b = xi & 3;
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          const float gv = dgrad ? g[(2 - r) * 3 + (2 - c)] : g[r * 3 + c];
-          u += G[a][r] * (double)gv * G[b][c];
-        }
-    }
+    const double u = wino_u(w, Cout, Cin, N, K, nn, kk, xi, dgrad);
     float rr = (float)u;
     if (np == 1) {
       out[i] = __builtin_bit_cast(unsigned short, (_Float16)rr);
+      continue;
+    }
+    if (np == 4) {
+      rr *= wsc;
+      const _Float16 h0 = (_Float16)rr;
+      out[i] = __builtin_bit_cast(unsigned short, h0);
+      out[per_plane + i] = __builtin_bit_cast(unsigned short, (_Float16)(rr - (float)h0));
       continue;
     }
     for (int q2 = 0; q2 < np; ++q2) {
@@ -490,6 +525,14 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned sh
       rr -= (float)bb;
     }
   }
+}
+// f16x3 image: the scale word.  [0] = max |U| bits from pass 1 -> copied to [1] (read by the pack pass), then [0] = the scale
+__global__ void wino_scale_word_kernel(unsigned* __restrict__ word, int stage) {
+  if (stage == 0) { word[1] = word[0]; return; }
+  const float mx = __uint_as_float(word[1]);
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 14 - e; }
+  word[0] = __float_as_uint(ldexpf(1.f, e));
 }
 
 

@@ -27,7 +27,11 @@
 #endif
 constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
 
-template <int NP, bool GNF>
+// HP ("f16x3", NP = 2): the two planes of V and of U are IEEE halfs of the operands scaled into the fp16 range -- V by
+// 2^ex from the per-image max |x| the caller supplies (IGemmParams::xmax; |V| <= 4 max |x| -> 2^14), U by the power of two
+// stored behind its image (pack_weight_wino_kernel) -- three fp16 MFMAs per product, the result rescaled (exactly) in the
+// epilogue.
+template <int NP, bool GNF, bool HP = false>
 __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Uglob, IGemmParams p) {
   // 128 KB: the two raw slabs (46 KB) during the slab loop, the 8-wave exchange buffer of the epilogue after it
@@ -103,6 +107,24 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
   const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
 
+  // HP: x 2^ex brings the largest |x| of the image (512 partial maxima from osm_maxabs, as bit patterns) to [2^11, 2^12)
+  float xscale = 1.f, oscale = 1.f;
+  if (HP) {
+    unsigned mb = reinterpret_cast<const unsigned*>(p.xmax)[img * OSM_MAXABS_PARTS + tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mb = max(mb, red_u[q]);
+    __syncthreads();              // the staging stores that follow reuse smem
+    const float mx = __uint_as_float(mb);
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 12 - ex; }
+    xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
+    oscale = ldexpf(1.f, -ex) / p.wscale[0];
+  }
   float4 ra[W8_NJ];
   float4 gm, gs, gb;        // fused GroupNorm: mean | rstd * gamma | beta of this thread's channel quad
   gm = gs = gb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,6 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
         v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w); \
       }                                                                                    \
     }                                                                                      \
+    if (HP) { v.x *= xscale; v.y *= xscale; v.z *= xscale; v.w *= xscale; }                \
     raw[((cc_) & 1) * (4 * WN_QP) + woff[j_]] = sel4((okm_ >> (j_)) & 1u, v);             \
   }
 #define OSM_W8_LOAD_U(cc_, jj_)                                                            \
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       v_.w = fmaf(sg, ya_[3], xa_[3]) + (sb_) * fmaf(sg, yb_[3], xb_[3]);                  \
       if (W8_ABL & 16) { _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                  \
           vh_[hq][q2] = make_uint2(__float_as_uint(v_.x) + q2, __float_as_uint(v_.y) ^ __float_as_uint(v_.z) ^ __float_as_uint(v_.w)); } \
+      else if constexpr (HP) split_f16x2(v_, vh_[hq]);                                     \
       else split_planes<NP>(v_, vh_[hq]);                                                  \
     }                                                                                      \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
@@ -182,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
         if (W8_ABL & 32) acc[jj_][tb_][b][(pa * 3 + pb) & 15] += __uint_as_float((va[par_][pa].x ^ uq[jj_][b][pb].y) + (va[par_][pa].z ^ uq[jj_][b][pb].w)); \
+        else if constexpr (HP) acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]); \
         else acc[jj_][tb_][b] = mma16<NP>(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);
 // nothing crosses a unit boundary (keeps the prefetch distance of the loads and the live ranges of va / uq as written)
 #define OSM_W8_FENCE()                                                                     \
@@ -319,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
           if (oy == 0 || k == 0) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
           else { v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w; }
         }
+      if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
       const int dy = 8 * a + 2 * i;
       if (y0 + oy + dy >= p.H) continue;          // wave-uniform
       const bool ok = nok && xok;

@@ -379,6 +379,60 @@ extern "C" int OSM_FN(osm_copy2d)(const abi_act_t* x_, long long ldx, abi_act_t*
   return osm::check_launch("copy2d_kernel");
 }
 
+#ifndef OSM_ACT_F16
+// per-image max |x| of an [B][HW][C] activation tensor (row stride ldx) as OSM_MAXABS_PARTS partial maxima per image: block
+// (j, img) writes the bit pattern of its non-negative partial to out[img][j] (a NaN anywhere sets NaN bits, which compare
+// above every finite pattern: it poisons the scale like it would poison an fp32 convolution).  No atomics, no clearing:
+// every slot is written on every call; the consumer (osm_conv_desc::x_maxabs, f16x3 Winograd kernel) folds the partials.
+__global__ __launch_bounds__(512) void maxabs_kernel(const float* __restrict__ x, long long ldx, long long rows_per_img, int C4,
+                                                     unsigned* __restrict__ out) {
+  const int img = blockIdx.y;
+  const float* __restrict__ xb = x + (long long)img * rows_per_img * ldx;
+  const long long total = rows_per_img * C4;          // float4 vectors of this image
+  const bool dense = ldx == 4LL * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  float m = 0.f;
+  unsigned nanbits = 0;
+  auto take = [&](float4 v) {
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaNs ...
+    if (v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w) nanbits = 0x7fc00000u;      // ... so they are tracked apart
+  };
+  auto at = [&](long long i) -> float4 {
+    if (dense) return reinterpret_cast<const float4*>(xb)[i];
+    const long long r = i / C4;
+    return *reinterpret_cast<const float4*>(xb + r * ldx + (i - r * C4) * 4);
+  };
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < total; i += 8 * stride) {   // eight independent 16-byte loads in flight per thread
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = at(i + q * stride);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) take(v[q]);
+  }
+  for (; i < total; i += stride) take(at(i));
+  unsigned bits = __float_as_uint(m) | nanbits;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+  __shared__ unsigned wmax[8];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) bits = max(bits, wmax[q]);
+    out[(long long)img * gridDim.x + blockIdx.x] = bits;
+  }
+}
+extern "C" int osm_maxabs_parts(void) { return OSM_MAXABS_PARTS; }
+extern "C" int osm_maxabs(const float* x, long long ldx, int B, long long rows_per_img, int C, float* out, void* stream) {
+  OSM_REQUIRE(x && out && B > 0 && rows_per_img > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C && osm::aligned16(x),
+              "osm_maxabs: bad argument (C, ldx multiples of 4, 16-byte aligned x)");
+  hipLaunchKernelGGL(maxabs_kernel, dim3(OSM_MAXABS_PARTS, B), dim3(512), 0, (hipStream_t)stream, x, ldx, rows_per_img, C / 4,
+                     reinterpret_cast<unsigned*>(out));
+  return osm::check_launch("maxabs_kernel");
+}
+#endif
+
 #ifdef OSM_ACT_F16
 extern "C" int osm_half_to_f32(const osm_half_t* x, long long ldx, float* y, long long ldy, long long M, int C,
                                void* stream) {

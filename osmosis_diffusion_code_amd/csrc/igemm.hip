@@ -67,6 +67,8 @@ struct IGemmParams {
   const act_t* stat_x;
   long long ld_sx;
   const float* stat_table;   // mode 2: [B][4][N] mean | rstd | g | b (the table the forward convolution applied)
+  const float* xmax;         // f16x3 Winograd image: per-image max |x| of the input (osm_maxabs), [B]
+  const float* wscale;       // ... and the power of two its U planes were scaled by (stored behind the image)
 };
 
 // the contribution of one final output element v (already rounded to the storage type) to the two column sums
@@ -537,8 +539,10 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
   if (wfmt == 1) return osm::fail(OSM_ERR_UNSUPPORTED, "wfmt 1 (fp16 arithmetic) belongs to the fp16 family (osm_conv2d_nhwc_h)");
 #endif
   if (wino) {
-    if (!(taps == 9 && wfmt >= 1 && wfmt <= 3 && wino_shape_ok(p.H, p.W, p.K, p.N)))
-      return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 1 / 2 / 3, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
+    if (!(taps == 9 && wfmt >= 1 && wfmt <= 4 && wino_shape_ok(p.H, p.W, p.K, p.N)))
+      return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 1 / 2 / 3 / 4, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
+    if (wfmt == 4 && !p.xmax)
+      return osm::fail(OSM_ERR_INVALID, "the f16x3 Winograd image (wfmt 4) needs x_maxabs (osm_maxabs of the input)");
     if (!(p.ldc % 4 == 0 && osm::aligned_act4(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned_act4(p.res))) &&
           (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
       return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 4-element vectors: ldy, ldr multiples of 4, aligned y / res / bias");
@@ -565,9 +569,14 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     } else if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<NP_, true>), gw, dim3(256), 0, st, p.A, Up, p);  \
     else hipLaunchKernelGGL((conv3_wino_kernel<NP_, false>), gw, dim3(256), 0, st, p.A, Up, p);
 #ifdef OSM_ACT_F16
+    if (wfmt != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "fp16 family: Winograd image wfmt 1 only");
     OSM_WINO_LAUNCH(1)
 #else
-    if (wfmt == 3) { OSM_WINO_LAUNCH(3) } else { OSM_WINO_LAUNCH(2) }
+    if (wfmt == 4) {     // f16x3: two half planes behind a scale word
+      p.wscale = reinterpret_cast<const float*>(Up + 2LL * 16 * p.ksteps * p.nt32 * 512);
+      if (p.gn_table) hipLaunchKernelGGL((conv3_wino8_kernel<2, true, true>), gw, dim3(512), 0, st, p.A, Up, p);
+      else hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true>), gw, dim3(512), 0, st, p.A, Up, p);
+    } else if (wfmt == 3) { OSM_WINO_LAUNCH(3) } else { OSM_WINO_LAUNCH(2) }
 #endif
 #undef OSM_WINO_LAUNCH
   } else
@@ -750,23 +759,35 @@ extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int 
 
 // 1 when a layer may be given a Winograd weight image (OSM_WFMT_WINOGRAD): 3x3, stride 1, wfmt 2 / 3, fp32 family
 extern "C" int osm_conv_winograd_ok(int H, int W, int Cin, int Cout, int ksize, int wfmt) {
-  return ksize == 3 && wfmt >= 1 && wfmt <= 3 && wino_shape_ok(H, W, Cin, Cout) ? 1 : 0;
+  return ksize == 3 && wfmt >= 1 && wfmt <= 4 && wino_shape_ok(H, W, Cin, Cout) ? 1 : 0;
 }
 extern "C" long long osm_winograd_weight_elems(int Cout, int Cin, int wfmt, int dgrad) {
   const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-  return (long long)wfmt * 16 * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // bf16 (uint16) elements
+  const long long per_plane = 16LL * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // 16-bit elements
+  if (wfmt == 4) return 2 * per_plane + 8;      // f16x3: two half planes + 16 bytes holding the scale (one float)
+  return wfmt * per_plane;
 }
 extern "C" int osm_pack_conv_weight_winograd(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int wfmt,
                                              void* stream) {
   OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_winograd: null pointer");
-  OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_pack_conv_weight_winograd: wfmt must be 1 (fp16), 2 or 3 (bf16 planes)");
+  OSM_REQUIRE(wfmt >= 1 && wfmt <= 4, "osm_pack_conv_weight_winograd: wfmt must be 1 (fp16), 2 or 3 (bf16 planes), 4 (f16x3)");
   for (int dg = 0; dg < 2; ++dg) {
     unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
     if (!out) continue;
-    const long long per_plane = osm_winograd_weight_elems(Cout, Cin, wfmt, dg) / wfmt;
+    const long long per_plane = (osm_winograd_weight_elems(Cout, Cin, wfmt, dg) - (wfmt == 4 ? 8 : 0)) / (wfmt == 4 ? 2 : wfmt);
     int blocks = (int)((per_plane + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    if (wfmt == 4) {     // pass 1: max |U| (as uint bits) into the scale word behind the planes; pass 2 scales by it
+      unsigned* sw = reinterpret_cast<unsigned*>(out + 2 * per_plane);
+      hipError_t e = hipMemsetAsync(sw, 0, 16, (hipStream_t)stream);
+      if (e != hipSuccess) return osm::fail(OSM_ERR_LAUNCH, "osm_pack_conv_weight_winograd: memset failed");
+      hipLaunchKernelGGL(wino_umax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, sw, Cout, Cin, dg);
+      hipLaunchKernelGGL(wino_scale_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sw, 0);
+    }
     hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, wfmt, dg);
+    if (wfmt == 4)
+      hipLaunchKernelGGL(wino_scale_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                         reinterpret_cast<unsigned*>(out + 2 * per_plane), 1);
     int rc = osm::check_launch("pack_weight_wino_kernel");
     if (rc) return rc;
   }
@@ -811,10 +832,12 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
   }
   const bool wino = (d->wfmt & OSM_WFMT_WINOGRAD) != 0;
   const int wfmt = d->wfmt & ~OSM_WFMT_WINOGRAD;
-  OSM_REQUIRE(!wino || (d->ksize == 3 && wfmt >= 1 && wfmt <= 3),
-              "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 1 / 2 / 3");
+  OSM_REQUIRE(!wino || (d->ksize == 3 && wfmt >= 1 && wfmt <= 4),
+              "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 1 / 2 / 3 / 4");
+  p.xmax = d->x_maxabs;
   if (wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
-    OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3) or 3 (bf16x6)");
+    OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && wino),
+                "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3), 3 (bf16x6), or 4 (f16x3, Winograd image only)");
     p.nt32 = (d->Cout + 31) / 32;
     p.ksteps = 2 * ((d->Cin + 31) / 32);
   }

@@ -51,6 +51,35 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&pl)[NP]) {
   }
 }
 
+// "f16x3" arithmetic (round 3): an fp32 value PRE-SCALED into the fp16 range splits into two IEEE-half terms
+// a = h0 + h1 + O(2^-23 |a|) (11 + 11 significand bits, RNE), and a product is the three fp16 MFMAs h0g0 + h0g1 + h1g0:
+// half the matrix work of bf16x6 for ~22-bit operands.  The residual a - h0 is one v_fma_mix_f32 (the half operand is
+// read in place): 8 VALU for 4 values against 22 for three bf16 planes.
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {   // RNE, v_cvt_pk_f16_f32
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+__device__ __forceinline__ float sub_h_lo(unsigned h, float x) {       // x - (float)low half of h, exact
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float sub_h_hi(unsigned h, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ void split_f16x2(float4 x, uint2 (&pl)[2]) {
+  const unsigned a = cvt_pk_f16(x.x, x.y), b = cvt_pk_f16(x.z, x.w);
+  pl[0] = make_uint2(a, b);
+  pl[1] = make_uint2(cvt_pk_f16(sub_h_lo(a, x.x), sub_h_hi(a, x.y)), cvt_pk_f16(sub_h_lo(b, x.z), sub_h_hi(b, x.w)));
+}
+__device__ __forceinline__ f32x16 mma16h(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
 // 8 fp32 (two float4: elements 0-3, 4-7 of a fragment) -> NP 16-byte fragments
 template <int NP>
 __device__ __forceinline__ void split_frag8(float4 lo4, float4 hi4, uint4 (&pl)[NP]) {

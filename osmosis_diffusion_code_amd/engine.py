@@ -40,9 +40,13 @@ def _winograd_on() -> bool:
 
 class _Conv:
     def __init__(self, slot, dev, wfmt=0):
+        """wfmt: ops.WFMT code of the model's conv arithmetic.  "f16x3" (4) exists for Winograd images only: such a model keeps
+        bf16x6 (3) images for every layer / resolution the Winograd kernel does not serve."""
         w = slot.weight.detach().to(dev, torch.float32)
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.k = w.shape[2] if w.dim() == 4 else 1
+        self.wwfmt = wfmt                          # format of the Winograd-domain images
+        wfmt = 3 if wfmt == 4 else wfmt
         self.wfmt = wfmt
         self.wf, self.wd = ops.pack_conv_weight(w, wfmt=wfmt)
         # Winograd F(2x2, 3x3) images next to the direct ones (the layer picks per (H, W): 16 x 16 and larger)
@@ -52,7 +56,7 @@ class _Conv:
         if self.k == 3 and (wfmt in (2, 3) or (wfmt == 1 and os.environ.get("OSM_WINOGRAD_F16", "0") == "1")) \
                 and _winograd_on() and ops.conv_winograd_ok(16, 16, self.cin, self.cout, 3, wfmt) \
                 and ops.conv_winograd_ok(16, 16, self.cout, self.cin, 3, wfmt):
-            self.wwf, self.wwd = ops.pack_conv_weight_winograd(w, wfmt=wfmt)
+            self.wwf, self.wwd = ops.pack_conv_weight_winograd(w, wfmt=self.wwfmt)
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
 
 
@@ -310,9 +314,13 @@ class UNetEngine:
         cout = cv.cin if dgrad else cv.cout
         assert x.cols == cin and y.cols == cout and x.rows == M and y.rows == M, (x.cols, cin, y.cols, cout)
         wfmt, wimg = cv.wfmt, (cv.wd if dgrad else cv.wf)
+        xm = None
         if cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
                 ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt):
-            wfmt, wimg = cv.wfmt | ops.WINOGRAD, (cv.wwd if dgrad else cv.wwf)
+            wfmt, wimg = cv.wwfmt | ops.WINOGRAD, (cv.wwd if dgrad else cv.wwf)
+            if cv.wwfmt == 4:       # f16x3: the kernel scales its input into the fp16 range from the per-image max |x|
+                xm = self._xmax_slot(ws_slot)
+                ops.maxabs(x, self.B, xm)
         sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, wfmt, gn_table is not None)
         ws = None
         if sk > 1:
@@ -327,7 +335,7 @@ class UNetEngine:
                     skw = dict(colsum=cs, stat_mode=2, stat_x=stat[1], stat_table=stat[2], stat_silu=True)
         ops.conv2d(x, wimg, None if dgrad else cv.b, y, self.B, H, W, cv.k, res=res,
                    accumulate=accumulate, splitk=sk, splitk_ws=ws, wfmt=wfmt, gn_table=gn_table, gn_silu=gn_silu,
-                   **skw)
+                   x_maxabs=xm, **skw)
         return (cs, nch) if cs is not None else None
 
     def _is_wino(self, cv: _Conv, hw, dgrad=False) -> bool:
@@ -335,6 +343,10 @@ class UNetEngine:
         cin, cout = (cv.cout, cv.cin) if dgrad else (cv.cin, cv.cout)
         return cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
             bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
+
+    def _xmax_slot(self, key: str) -> torch.Tensor:
+        """[B][MAXABS_PARTS] partial max |x| of an f16x3 convolution's input (every entry is rewritten by ops.maxabs)."""
+        return self._scr_flat("xmax/" + key, self.B * ops.MAXABS_PARTS)
 
     def _gn_fusable(self, cv: _Conv, hw) -> bool:
         """GroupNorm apply inside the consuming 3x3 convolution: needs the halo-tile kernel (split-bf16 / fp16 weights,

@@ -156,7 +156,7 @@ class UNetModel(nn.Module):
         # "f16" = the reference's use_fp16 (unet.py:544,697-703,733): activations and conv weights in IEEE half, fp32
         # accumulation, GroupNorm / softmax / embeddings in fp32; parameters stay fp32 in the module (the half weight
         # images are made at pack time, like convert_module_to_f16 does in place)
-        self._fp32_conv_mode = os.environ.get("OSM_CONV_MODE", "bf16x6")
+        self._fp32_conv_mode = os.environ.get("OSM_CONV_MODE", "f16x3")
         self.conv_mode = "f16" if use_fp16 else self._fp32_conv_mode
 
     # ------------------------------------------------------------------ parameters

@@ -60,7 +60,7 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
            splitk: int = 1, splitk_ws: Optional[torch.Tensor] = None, wfmt: int = 0,
            gn_table: Optional[torch.Tensor] = None, gn_silu: bool = True,
            colsum: Optional[torch.Tensor] = None, stat_mode: int = 0, stat_x: Optional[Mat] = None,
-           stat_table: Optional[torch.Tensor] = None, stat_silu: bool = True):
+           stat_table: Optional[torch.Tensor] = None, stat_silu: bool = True, x_maxabs: Optional[torch.Tensor] = None):
     """colsum (+ stat_*): optional per-column sums of the result for the GroupNorm that follows (stat_mode 1) or whose
     backward consumes the result (stat_mode 2: stat_x = that GroupNorm's input, stat_table = its per-channel table)."""
     d = ConvDesc()
@@ -76,17 +76,28 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
     d.colsum, d.stat_mode, d.stat_silu = ptr(colsum), int(stat_mode), int(stat_silu)
     d.stat_x, d.ld_sx = (stat_x.p, stat_x.ld) if stat_x is not None else (None, 0)
     d.stat_table = ptr(stat_table)
+    d.x_maxabs = ptr(x_maxabs)
     fam = _same_family(x.t, y.t, res.t if res is not None else None, stat_x.t if stat_x is not None else None)
     if (fam == "_h") != ((wfmt & ~WINOGRAD) == 1):
         raise _lib.OsmosisHipError("fp16 activations go with the fp16 weight image (wfmt 1), fp32 with 0 / 2 / 3")
     call("osm_conv2d_nhwc" + fam, C.byref(d), _s(),
          keep=(x.t, w_packed, bias, y.t, res.t if res else None, splitk_ws, gn_table, colsum,
-               stat_x.t if stat_x is not None else None, stat_table))
+               stat_x.t if stat_x is not None else None, stat_table, x_maxabs))
+
+
+MAXABS_PARTS = 512     # OSM_MAXABS_PARTS
+
+
+def maxabs(x: Mat, B: int, out: torch.Tensor):
+    """out[b][:] = MAXABS_PARTS partial maxima of |x| over image b of an [B * rows][C] fp32 matrix (device-side; no host
+    sync, no clearing needed); conv2d(x_maxabs=out) folds them."""
+    assert out.numel() >= B * MAXABS_PARTS
+    call("osm_maxabs", x.p, x.ld, B, x.rows // B, x.cols, ptr(out), _s(), keep=(x.t, out))
 
 
 # conv arithmetic modes: weight-image format code of the C ABI
 # "f16": activations AND weights in IEEE half, fp32 accumulation (the reference's use_fp16): fp16-storage family
-WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}
+WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}   # 4: Winograd images only
 WINOGRAD = 0x10   # OSM_WFMT_WINOGRAD: the weight image is in the Winograd F(2x2, 3x3) domain (pack_conv_weight_winograd)
 
 

@@ -67,7 +67,7 @@ def make_sampler(gd):
                                   dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
 
 
-@pytest.mark.parametrize("conv_mode", ["f32", "bf16x6"])
+@pytest.mark.parametrize("conv_mode", ["f32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("opname", list(OPERATORS))
 def test_fused_loop_matches_reference_trace(pkg, opname, conv_mode):
     unet, gd, M, CM = pkg

@@ -90,7 +90,7 @@ def test_full_size_unet_256_vs_oracle(create_model):
     xr = x.clone().requires_grad_(True)
     yr = U.unet_forward(sd, cfg, xr, t)
     (dxr,) = torch.autograd.grad((yr * w).sum(), xr)
-    for mode in ("f32", "bf16x6"):
+    for mode in ("f32", "bf16x6", "f16x3"):
         m.conv_mode = mode
         xd = x.to(DEV).requires_grad_(True)
         yd = m(xd, t.to(DEV))
@@ -109,7 +109,7 @@ def test_cpu_model_refuses_to_run(create_model):
         m(torch.zeros(1, 4, 32, 32), torch.zeros(1))
 
 
-@pytest.mark.parametrize("mode,tol_y,tol_dx", [("bf16x6", 2e-5, 2e-5), ("bf16x3", 2e-3, 2e-3)])
+@pytest.mark.parametrize("mode,tol_y,tol_dx", [("bf16x6", 2e-5, 2e-5), ("f16x3", 2e-5, 2e-5), ("bf16x3", 2e-3, 2e-3)])
 def test_tiny_unet_split_bf16_modes(create_model, mode, tol_y, tol_dx):
     """Split-bf16 conv arithmetic vs the reference golden (same vectors as the exact-f32 test)."""
     g = dict(np.load(os.path.join(GOLD, "tiny_unet.npz")))

@@ -37,16 +37,20 @@ def main():
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, device=dev, generator=g)
         y = torch.empty(M, Cout, device=dev, dtype=adt)
-        wino = a.winograd and ops.conv_winograd_ok(H, W, Cin, Cout, k, ops.WFMT[a.mode])
+        wino = (a.winograd or a.mode == "f16x3") and ops.conv_winograd_ok(H, W, Cin, Cout, k, ops.WFMT[a.mode])
         wfmt = ops.WFMT[a.mode] | (ops.WINOGRAD if wino else 0)
-        wf, _ = (ops.pack_conv_weight_winograd(w, wfmt=wfmt & 3) if wino else ops.pack_conv_weight(w, wfmt=wfmt))
+        wf, _ = (ops.pack_conv_weight_winograd(w, wfmt=wfmt & 7) if wino else ops.pack_conv_weight(w, wfmt=wfmt))
+        xm = None
+        if a.mode == "f16x3":
+            xm = torch.empty(B * ops.MAXABS_PARTS, device=dev)
+            ops.maxabs(ops.Mat.of(x), B, xm)
         sk = ops.conv_splitk(B, H, W, Cin, Cout, k, wfmt)
         ws = torch.empty(sk * M * Cout, device=dev) if sk > 1 else None
         tab = None
         if a.gn:     # [B][4][Cin]: mean | rstd | gamma | beta
             tab = torch.stack([0.1 * torch.randn(B, Cin, device=dev, generator=g), 1.0 + 0.1 * torch.rand(B, Cin, device=dev, generator=g),
                                1.0 + 0.1 * torch.randn(B, Cin, device=dev, generator=g), 0.1 * torch.randn(B, Cin, device=dev, generator=g)], 1).contiguous()
-        run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt, gn_table=tab)  # noqa: E731
+        run = lambda: ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt, gn_table=tab, x_maxabs=xm)  # noqa: E731
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -64,8 +68,17 @@ def main():
             if a.gn:
                 xin = torch.nn.functional.silu((xin - tab[:, 0:1]) * tab[:, 1:2] * tab[:, 2:3] + tab[:, 3:4])
             ref = torch.nn.functional.conv2d(xin.view(B, H, W, Cin).permute(0, 3, 1, 2), w, b, padding=k // 2)
-            err = float((y.float().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
+            ref = torch.nn.functional.conv2d(xin.double().view(B, H, W, Cin).permute(0, 3, 1, 2), w.double(), b.double(), padding=k // 2)
+            err = float((y.double().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
             msg += f"  relerr {err:.2e}"
+        if a.mode == "f16x3" and wino:
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(a.iters):
+                ops.maxabs(ops.Mat.of(x), B, xm)
+            e1.record()
+            torch.cuda.synchronize()
+            msg += f"  (+ maxabs {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us)"
         print(msg, flush=True)
 
 
