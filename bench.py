@@ -69,13 +69,34 @@ def seeded_weights(model, seed=1234):
     model.reset_parameters(seed)
 
 
-def run_gpu(args, rank, world, dev):
+# the two other single-GPU configurations BASELINE.json names, timed in the same run (a few steps each) and reported under
+# "secondary" of the one JSON line: config 3 = osmosis_simulation_sample_config.yaml as one batch of 8; config 5 =
+# osmosis_haze_sample_config.yaml as BASELINE.json quotes it (batch 32, 250-step respacing, use_fp16)
+SECONDARY = [
+    dict(workload="config 3: osmosis_simulation_sample_config.yaml, B=8 underwater_physical, 1000-step DDPM + guidance, fp32 storage",
+         batch=8, unet=dict(), diffusion=dict(), dtype="f32",
+         operator=("underwater_physical", dict(optimizer="sgd", depth_type="original", value="1.4,1.4,1", phi_ab="1.1,0.95,0.95",
+                                               phi_ab_eta="1e-5", phi_ab_learn_flag=True, phi_inf="0.2,0.4,0.7",
+                                               phi_inf_eta="1e-5", phi_inf_learn_flag=True)),
+         cond=dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1", scale="4,4,4,1",
+                   gradient_x_prev=True, gradient_clip="True,0.001"), aux={"val_loss": 40}),
+    dict(workload="config 5: osmosis_haze_sample_config.yaml, B=32 haze_physical, 250-step respaced DDPM + guidance, use_fp16",
+         batch=32, unet=dict(use_fp16=True), diffusion=dict(timestep_respacing="250"), dtype="f16",
+         operator=("haze_physical", dict(optimizer="sgd", depth_type="gamma", value="1.4,1.4,1", phi_ab="1.0", phi_ab_eta="1e-5",
+                                         phi_ab_learn_flag=True, phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5",
+                                         phi_inf_learn_flag=True)),
+         cond=dict(COND), aux=dict(AUX)),
+]
+
+
+def build_case(args, dev, batch, unet_kw=None, diffusion_kw=None, operator=None, cond_kw=None, aux=None, conv_mode=None):
+    """(model, sampler, conditioner) of one configuration; the headline run is build_case(args, dev, args.batch)."""
     from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
     from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
     from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
     from osmosis_diffusion_code_amd.guided_diffusion import unet
 
-    kw = dict(UNET_KW)
+    kw = dict(UNET_KW, **(unet_kw or {}))
     if args.tiny:
         kw.update(num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
                   num_head_channels=16)
@@ -85,12 +106,19 @@ def run_gpu(args, rank, world, dev):
         model = unet.create_model(**kw)
     seeded_weights(model)
     model = model.to(dev).eval()
-    model.conv_mode = args.conv_mode
-    B, S = args.batch, args.image_size
-    sampler = gd.create_sampler(**DIFFUSION)
-    op = M.get_operator("underwater_physical_revised", device=dev, batch_size=B, **OPERATOR)
-    cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **COND, **PATTERN, aux_loss=AUX)
-    x_T, y = synthetic_inputs(shard(world, rank, world)[0], B, S)
+    if conv_mode is not None and not kw.get("use_fp16"):
+        model.conv_mode = conv_mode
+    sampler = gd.create_sampler(**dict(DIFFUSION, **(diffusion_kw or {})))
+    opname, opkw = operator or ("underwater_physical_revised", OPERATOR)
+    op = M.get_operator(opname, device=dev, batch_size=batch, **opkw)
+    cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **(cond_kw or COND), **PATTERN,
+                                      aux_loss=aux if aux is not None else AUX)
+    return model, sampler, cond
+
+
+def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warmup, world=1):
+    """`warmup` untimed + `steps` timed guided steps; returns (seconds of the timed steps, outputs finite?)."""
+    x_T, y = synthetic_inputs(image_index, batch, args.image_size)
     x_T, y = x_T.to(dev), y.to(dev)
     T = sampler.num_timesteps
     # Timed window inside the phi-update regime (t <= 0.7 T), started at t = 0.3 T from a bounded x_t: the seeded
@@ -106,26 +134,73 @@ def run_gpu(args, rank, world, dev):
                                      sample_pattern=PATTERN, index_range=(start, start - n_steps + 1),
                                      reference_rng_order=False)
 
-    if args.warmup > 0:
-        run(args.warmup, first)
+    if warmup > 0:
+        run(warmup, first)
     import torch.distributed as dist
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = run(args.steps, first - args.warmup)
+    out = run(steps, first - warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    return dt, bool(torch.isfinite(out[0]).all())
+
+
+def run_gpu(args, rank, world, dev):
+    model, sampler, cond = build_case(args, dev, args.batch, conv_mode=args.conv_mode)
+    dt, finite = timed_steps(args, dev, model, sampler, cond, args.batch, shard(world, rank, world)[0], args.steps,
+                             args.warmup, world)
     from osmosis_diffusion_code_amd.sharding import max_over_ranks
     dt = max_over_ranks(dt, device=dev)
-    finite = bool(torch.isfinite(out[0]).all())
     return model, dt, finite
 
 
-def roofline(model, args):
-    """HIP-event timing of every launch of one guided step's UNet plans; 3x3 conv = dominant kernel."""
+def run_secondary(args, dev):
+    """Configs 3 and 5 on this GPU, a few steps each: image-steps/s of the whole guided step + the 3x3-conv class."""
+    out = []
+    for c in SECONDARY:
+        try:
+            model, sampler, cond = build_case(args, dev, c["batch"], c["unet"], c["diffusion"], c["operator"], c["cond"],
+                                              c["aux"], conv_mode=args.conv_mode)
+            steps, warmup = args.secondary_steps, 1
+            dt, finite = timed_steps(args, dev, model, sampler, cond, c["batch"], 7, steps, warmup)
+            a2 = argparse.Namespace(**dict(vars(args), batch=c["batch"], conv_mode=model.conv_mode, dump_layers=""))
+            rl, br = roofline(model, a2, reps=1)
+            out.append({"workload": c["workload"], "images_per_gpu": c["batch"], "dtype": c["dtype"],
+                        "conv_arithmetic": model.conv_mode, "steps": steps, "warmup": warmup,
+                        "ms_per_step": round(1e3 * dt / steps, 2),
+                        "image_steps_per_s": round(c["batch"] * steps / dt, 2), "finite_outputs": finite,
+                        "roofline_kernel": rl["kernel"], "roofline_frac": rl["frac"], "roofline_achieved_tflops": rl["achieved"],
+                        "kernel_breakdown_ms_per_step": {k: round(v["ms_per_step"], 2) for k, v in br.items() if not k.startswith("_")}})
+            del model, sampler, cond
+            torch.cuda.empty_cache()
+        except Exception as e:      # a secondary line must never cost the headline number
+            out.append({"workload": c["workload"], "error": f"{type(e).__name__}: {e}"[:300]})
+    return out
+
+
+CONV_KINDS = {0: "f32", 1: "igemm", 2: "direct", 3: "direct8", 4: "direct", 5: "winograd"}   # osm_conv_kernel_kind
+# dominant-kernel facts per (class, arithmetic): kernel name (as rocprofv3 prints it), MFMAs per product
+KERNELS = {
+    ("conv3x3_winograd", "f16x3"): ("conv3_wino8_kernel<2,*,true>", 3, "f16"),
+    ("conv3x3_winograd", "bf16x6"): ("conv3_wino8_kernel<3,*,false>", 6, "bf16"),
+    ("conv3x3_winograd", "bf16x3"): ("conv3_wino8_kernel<2,*,false>", 3, "bf16"),
+    ("conv3x3_winograd", "f16"): ("conv3_wino8_kernel<1,*,false>", 1, "f16"),
+    ("conv3x3_direct", "f16x3"): ("conv3_halo_bf16s_kernel<3,*>", 6, "bf16"),
+    ("conv3x3_direct", "bf16x6"): ("conv3_halo_bf16s_kernel<3,*>", 6, "bf16"),
+    ("conv3x3_direct", "bf16x3"): ("conv3_halo_bf16s_kernel<2,*>", 3, "bf16"),
+    ("conv3x3_direct", "f16"): ("conv3_halo_bf16s_kernel<1,*>", 1, "f16"),
+    ("conv3x3_f32", "f32"): ("igemm_f32_kernel<9,false>", 0, "f32"),
+}
+
+
+def roofline(model, args, reps=3):
+    """HIP-event timing of every launch of one guided step's UNet plans, classified by the kernel the library really
+    launches for each call (osm_conv_kernel_kind).  The roofline object is for the class that takes the most time."""
+    from osmosis_diffusion_code_amd import ops as _ops
     B, S = args.batch, args.image_size
     eng = model.engine(B, S, S)
 
@@ -137,19 +212,15 @@ def roofline(model, args):
             fl = 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * d.ksize * d.ksize
             shape = (d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.splitk)
             per_shape.setdefault(shape, [0.0, 0, fl])
-            # layers with <= 256 pixel rows (8x8, 16x16 at batch 1) run the small-M weight-streaming kernel (3x3 and 1x1)
-            small_m = (args.conv_mode != "f32" and d.B * d.H * d.W <= int(os.environ.get("OSM_SKINNY_MAXM", "256"))
-                       and d.Cin % 32 == 0 and not d.gn_table)
-            if small_m:
-                return ("conv_small_m", fl, shape)
+            kind = CONV_KINDS[_ops.query("osm_conv_kernel_kind", d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.wfmt)]
             if d.ksize != 3:
-                return ("conv1x1", fl, shape)
-            # split-bf16 modes: layers with W >= 16 run the halo-tile kernel (the dominant one), the 8x8
-            # layers the tap-chunked kernel
-            halo = args.conv_mode != "f32" and d.W >= 16 and d.H >= 8
-            if d.wfmt & 0x10:            # OSM_WFMT_WINOGRAD: the F(2x2, 3x3) kernel (executes 16/36 of the algorithmic flops)
-                wino_shapes.add(shape)
-            return ("conv3x3" if halo or args.conv_mode == "f32" else "conv3x3_8x8", fl, shape)
+                tag = "conv1x1" if kind != "f32" else "conv1x1_f32"
+            else:
+                tag = {"winograd": "conv3x3_winograd", "direct": "conv3x3_direct", "direct8": "conv3x3_8x8",
+                       "igemm": "conv3x3_tapchunked", "f32": "conv3x3_f32"}[kind]
+            return (tag, fl, shape)
+        if name == "osm_maxabs":
+            return ("maxabs", 0.0, None)
         if name == "osm_gemm":
             d = a[0]._obj
             fl = 2.0 * d.M * d.N * d.K * d.nb1 * d.nb2
@@ -184,14 +255,14 @@ def roofline(model, args):
 
     agg = {}
     per_shape = {}
-    wino_shapes = set()
-    reps = 3
+    shape_tag = {}
     for _ in range(reps):
         for plan in (eng._fwd_plan, eng._bwd_plan):
             for (tag, fl, shape), ms in plan.replay_timed(select):
                 if shape is not None:
                     per_shape[shape][0] += ms
                     per_shape[shape][1] += 1
+                    shape_tag[shape] = tag
                 a = agg.setdefault(tag, [0.0, 0.0, 0])
                 a[0] += ms
                 a[1] += fl
@@ -199,68 +270,65 @@ def roofline(model, args):
     out = {k: {"ms_per_step": v[0] / reps, "gflop_per_step": v[1] / reps / 1e9, "launches_per_step": v[2] // reps}
            for k, v in agg.items()}
     if args.dump_layers:
-        rows = [{"B,H,W,Cin,Cout,k,splitk": list(k), "launches_per_step": v[1] // reps, "ms_per_launch": v[0] / v[1],
-                 "tflops": v[2] / (v[0] / v[1]) / 1e9} for k, v in per_shape.items()]   # GN rows: "tflops" = TB/s
+        rows = [{"B,H,W,Cin,Cout,k,splitk": list(k), "class": shape_tag.get(k), "launches_per_step": v[1] // reps,
+                 "ms_per_launch": v[0] / v[1], "tflops": v[2] / (v[0] / v[1]) / 1e9} for k, v in per_shape.items()]   # GN rows: "tflops" = TB/s
         rows.sort(key=lambda r: -r["ms_per_launch"] * r["launches_per_step"])
         with open(args.dump_layers, "w") as f:
             json.dump(rows, f, indent=0)
-    c = out["conv3x3"]
+    # the levels at <= 32 x 32 pixels (weight-stream / launch bound: < 3 % of the flops): their convolutions' share of the step
+    conv_shapes = {k: v for k, v in per_shape.items() if len(k) == 7 and isinstance(k[0], int)}
+    lowres_ms = sum(v[0] for k, v in conv_shapes.items() if k[1] <= 32) / reps
+    out["_lowres"] = {"convs_le_32x32_ms_per_step": round(lowres_ms, 3),
+                      "launches_per_step": sum(v[1] for k, v in conv_shapes.items() if k[1] <= 32) // reps}
+
+    conv3 = {k: v for k, v in out.items() if k.startswith("conv3x3")}
+    dom = max(conv3, key=lambda k: conv3[k]["ms_per_step"])
+    c = out[dom]
     achieved = c["gflop_per_step"] / c["ms_per_step"]  # GFLOP/ms == TFLOP/s
-    # share of the 3x3 class served by the Winograd kernel (time, algorithmic flops)
-    w_ms = sum(per_shape[k][0] for k in wino_shapes) / reps
-    w_gf = sum(per_shape[k][2] * per_shape[k][1] for k in wino_shapes) / reps / 1e9
-    wino_dominant = w_ms > 0.5 * c["ms_per_step"]
-    # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py); null when none is committed.
+    kname, nmfma, mtype = KERNELS.get((dom, args.conv_mode), (dom, 6, "bf16"))
+    wino = dom == "conv3x3_winograd"
+    if nmfma == 0:
+        peak, note = FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"
+    else:
+        peak = BF16_MFMA_PEAK_TFLOPS / nmfma
+        note = {("f16", 3): "fp32 operands scaled into the fp16 range by powers of two and split into 2 IEEE-half terms (~22-bit "
+                            "operands), 3 fp16 MFMAs per product, fp32 accumulation (fp32-class accuracy: tests vs fp64 hold it to "
+                            "the same 4e-6 as bf16x6)",
+                ("bf16", 6): "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per fp32 product (fp32-class accuracy)",
+                ("bf16", 3): "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative)",
+                ("f16", 1): "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one fp16 MFMA per product",
+                }.get((mtype, nmfma), "") + f": peak = dense {mtype} MFMA peak 2500 TFLOP/s / {nmfma}; achieved counts ALGORITHMIC flops"
+    extra = {}
+    if wino:
+        note += ("; the Winograd F(2x2,3x3) kernel EXECUTES 16/36 of the algorithmic multiply-adds: `achieved` stays algorithmic "
+                 "(what a direct convolution would have to do), `executed_tflops` is what the matrix cores did")
+        executed = achieved * 16.0 / 36.0
+        extra = {"executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4)}
+    extra["share_of_3x3_time"] = round(c["ms_per_step"] / sum(v["ms_per_step"] for v in conv3.values()), 4)
+    # HBM bytes per launch of the dominant kernel RELAYED from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, tools/pmc_summary.py): a builder-side measurement, not something this run observed
     traffic, traffic_src = None, None
     import glob
+    pref = kname.split("<")[0]
+    targs = kname.split("<")[1].rstrip(">").split(",") if "<" in kname else []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))[-1:]:
         try:
-            pref = {"f32": "igemm_f32_kernel<9,false", "bf16x6": "conv3_halo_bf16s_kernel<3",
-                    "bf16x3": "conv3_halo_bf16s_kernel<2", "f16": "conv3_halo_bf16s_kernel<1",
-                    "f16x3": "conv3_halo_bf16s_kernel<2"}[args.conv_mode]
-            if wino_dominant:
-                pref = pref.replace("conv3_halo_bf16s_kernel", "conv3_wino_kernel")
-            hit = [k for k in json.load(open(path))["kernels"]
-                   if k["kernel"].replace(" ", "").startswith(pref)
-                   and (args.conv_mode == "f32" or wino_dominant        # template <NP, GN, PW, BR, PH>: PW = 16 patches
-                        or (k["kernel"].replace(" ", "").split("<")[1].rstrip(">").split(",") + ["", "", ""])[2] == "16")]
+            def match(k):
+                kn = k["kernel"].replace(" ", "")
+                if not kn.startswith(pref + "<"):
+                    return False
+                ka = kn.split("<")[1].rstrip(">").split(",")
+                return all(t == "*" or (i < len(ka) and ka[i] == t) for i, t in enumerate(targs))
+            hit = [k for k in json.load(open(path))["kernels"] if match(k)]
             if hit:   # launch-weighted mean over the template instances of the dominant kernel
                 traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in hit) / sum(k["launches"] for k in hit))
                 traffic_src = os.path.relpath(path, ROOT)
         except Exception:
             pass
-    convs3 = {k: v for k, v in per_shape.items()
-              if len(k) == 7 and k[5] == 3 and (args.conv_mode == "f32" or (k[2] >= 16 and k[1] >= 8 and
-                                                 k[0] * k[1] * k[2] > int(os.environ.get("OSM_SKINNY_MAXM", "256"))))}
+    dshapes = {k: v for k, v in per_shape.items() if shape_tag.get(k) == dom}
     esz = 2.0 if args.conv_mode == "f16" else 4.0
     alg_bytes = sum(esz * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
-                    for k, v in convs3.items()) / max(1, sum(v[1] for v in convs3.values()))
-    kname, peak, note = {
-        "f32": ("igemm_f32_kernel<9,false>", FP32_MFMA_PEAK_TFLOPS, "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
-        "bf16x6": ("conv3_halo_bf16s_kernel<3>", BF16_MFMA_PEAK_TFLOPS / 6.0,
-                   "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per fp32 product (fp32-class accuracy): "
-                   "peak = dense bf16 MFMA peak 2500 TFLOP/s / 6; achieved counts ALGORITHMIC flops"),
-        "bf16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
-                   "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative): "
-                   "peak = 2500 / 3; achieved counts ALGORITHMIC flops"),
-        "f16x3": ("conv3_halo_bf16s_kernel<2>", BF16_MFMA_PEAK_TFLOPS / 3.0,
-                  "Winograd 3x3 layers: fp32 operands scaled into the fp16 range by powers of two and split into 2 IEEE-half terms "
-                  "(~22-bit operands), 3 fp16 MFMAs per product, fp32 accumulation (fp32-class accuracy, tests vs fp64); every "
-                  "other contraction stays bf16x6: peak = dense fp16 MFMA peak 2500 TFLOP/s / 3; achieved counts ALGORITHMIC flops"),
-        "f16": ("conv3_halo_bf16s_kernel<1>", BF16_MFMA_PEAK_TFLOPS,
-                "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one v_mfma_f32_32x32x16_f16 "
-                "per product; peak = dense fp16 MFMA peak 2500 TFLOP/s"),
-    }[args.conv_mode]
-    extra = {}
-    if wino_dominant:
-        kname = kname.replace("conv3_halo_bf16s_kernel", "conv3_wino_kernel")
-        note += ("; " + f"{100.0 * w_ms / c['ms_per_step']:.0f} % of the 3x3 time ({100.0 * w_gf / c['gflop_per_step']:.0f} % of its flops) runs "
-                 "the Winograd F(2x2,3x3) kernel, which EXECUTES 16/36 of the algorithmic multiply-adds: `achieved` stays "
-                 "algorithmic (what a direct convolution would have to do), `executed_tflops` is what the matrix cores did")
-        executed = (c["gflop_per_step"] - w_gf * (1.0 - 16.0 / 36.0)) / c["ms_per_step"]
-        extra = {"winograd_share_of_time": round(w_ms / c["ms_per_step"], 4), "executed_tflops": round(executed, 2),
-                 "executed_frac": round(executed / peak, 4)}
+                    for k, v in dshapes.items()) / max(1, sum(v[1] for v in dshapes.values()))
     att = {k: out[k] for k in ("attention_core", "attn_gemm", "softmax") if k in out}
     if att:
         ams = sum(v["ms_per_step"] for v in att.values())
@@ -271,19 +339,22 @@ def roofline(model, args):
             "ms_per_step": round(ams, 3), "achieved_tflops": round(agf / max(ams, 1e-9), 2),
             "peak_tflops": round(peak_att, 1), "mfma_util": round(agf / max(ams, 1e-9) / peak_att, 4),
             "note": "algorithmic flops / HIP-event time of the launches / (dense bf16 MFMA peak / 6: bf16x6 arithmetic); "
-                    "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound"}
-    return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "arithmetic": note,
+                    "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound; the counter-based "
+                    "matrix-pipe busy fraction of these kernels is in profiles/r03_pmc_mfma_busy.json"}
+    lt = c["ms_per_step"] / c["launches_per_step"]
+    return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "class": dom, "arithmetic": note,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), **extra,
             "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # 157.3 TF: the exact-fp32 MFMA / vector peak
             "traffic": traffic, "traffic_source": traffic_src,
-            # achieved HBM GB/s of the conv kernel (north_star asks for it; the kernel is MFMA-bound, not HBM-bound):
-            # measured PMC bytes and algorithmic bytes, each / the live HIP-event launch time
-            "hbm_gbps": None if traffic is None else round(traffic / (c["ms_per_step"] / c["launches_per_step"]) / 1e6, 1),
-            "algorithmic_gbps": round(alg_bytes / (c["ms_per_step"] / c["launches_per_step"]) / 1e6, 1),
+            "traffic_measured_in": None if traffic is None else "builder profile (committed PMC summary), relayed -- not observed by this run",
+            # achieved HBM GB/s of the conv kernel (north_star asks for it; the kernel is MFMA / power bound, not HBM-bound):
+            # relayed PMC bytes and algorithmic bytes, each / the live HIP-event launch time
+            "hbm_gbps": None if traffic is None else round(traffic / lt / 1e6, 1),
+            "algorithmic_gbps": round(alg_bytes / lt / 1e6, 1),
             "algorithmic_bytes_per_launch_avg": round(alg_bytes),
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
-            "avg_launch_ms": c["ms_per_step"] / c["launches_per_step"],
+            "avg_launch_ms": lt, "avg_launch_ms_is": "HIP events around one osm_conv2d_nhwc call (kernel + split-K combine where there is one)",
             "launches_per_step": c["launches_per_step"]}, out
 
 
@@ -349,9 +420,12 @@ def main():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--conv-mode", default=os.environ.get("OSM_CONV_MODE", "f16x3"), choices=["f32", "bf16x6", "bf16x3", "f16", "f16x3"],
-                    help="conv arithmetic: exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
+                    help="conv arithmetic: f16x3 (default: Winograd 3x3 layers on 3 fp16 MFMAs per product, the rest bf16x6), "
+                         "exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
+    ap.add_argument("--secondary-steps", type=int, default=3,
+                    help="timed steps of each secondary configuration (BASELINE configs 3 and 5; N = 1 only; 0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -404,9 +478,15 @@ def main():
         if att:
             line["attention"] = att
             line["attention_mfma_util"] = att["mfma_util"]
+        line["lowres_levels"] = breakdown.pop("_lowres", None)
         line["kernel_breakdown_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in breakdown.items()}
         line["achieved_tflops_whole_step"] = round(
             sum(v["gflop_per_step"] for v in breakdown.values()) / (1e3 * dt / args.steps), 2)
+        if world == 1 and args.secondary_steps > 0 and not args.tiny:
+            del model
+            model = None
+            torch.cuda.empty_cache()
+            line["secondary"] = run_secondary(args, dev)
         if world == 1 and args.cpu_steps > 0:
             del model
             line["cpu_baseline"] = cpu_baseline(args)

@@ -126,9 +126,12 @@ int osm_gemm(const osm_gemm_desc* d, void* stream);
 /* suggested split-K factor for a (M,N,K,taps) contraction with `nbatch` batches (1 = none) */
 int osm_splitk_hint(int M, int N, int K, int taps, int nbatch);
 /* the split-K factor osm_conv2d_nhwc(_h) should be given for a layer (pass it as desc.splitk with a workspace of
- * splitk*B*H*W*Cout floats): layers with few pixel rows (<= 256: the 8x8 / 16x16 levels at batch 1) run a
- * weight-streaming kernel that splits K over the 4 waves of a workgroup first, so they need fewer partials. */
+ * splitk*B*H*W*Cout floats): aims at ~one workgroup per CU of the kernel that layer runs. */
 int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int has_gn_table);
+/* which kernel osm_conv2d_nhwc(_h) launches for a layer (measurement tooling: bench.py classifies its HIP-event times by
+ * it): 0 exact-fp32 MFMA implicit GEMM, 1 split-plane implicit GEMM (1x1 and tap-chunked 3x3), 2 halo-tile 3x3 on 8 x 16
+ * patches, 3 halo-tile 3x3 on 8 x 8 patches, 4 narrow-N halo-tile 3x3, 5 Winograd F(2x2, 3x3) */
+int osm_conv_kernel_kind(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt);
 /* chunks per image of osm_conv_desc.colsum for a layer run with `splitk` (0: no column sums from that layer) */
 int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int splitk, int has_gn_table);
 

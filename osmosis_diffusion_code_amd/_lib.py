@@ -102,6 +102,7 @@ _SIGS = {
     "osm_copy2d": [_P, _LL, _P, _LL, _LL, _I, _I, _P],
     "osm_maxabs": [_P, _LL, _I, _LL, _I, _P, _P],
     "osm_maxabs_parts": [],
+    "osm_conv_kernel_kind": [_I, _I, _I, _I, _I, _I, _I],
     "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "osm_phys_nblk": [_I],
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
@@ -169,10 +170,8 @@ class Recorder:
         return False
 
     def replay(self):
-        """Launch by launch on the stream the calls were recorded on (side-branch tags are ignored: one stream)."""
+        """Launch by launch on the stream the calls were recorded on."""
         for c in self.calls:
-            if c[0] is JOIN:
-                continue
             fn, args = c[0], c[1]
             rc = fn(*args)
             if rc != 0:
@@ -180,37 +179,18 @@ class Recorder:
 
     def to_graph(self):
         """Capture the recorded launches into a hipGraph (torch.cuda.CUDAGraph).  Every recorded call ends
-        with its stream argument, which is re-targeted to the capture stream -- or, for calls recorded inside
-        `side_branch(k)`, to side stream k, forked from the capture stream at the branch's first call and joined back at
-        its `join(k)` marker: independent branches (a ResBlock's 1x1 skip convolution next to its 3x3 chain) become
-        parallel paths of the graph."""
+        with its stream argument, which is re-targeted to the capture stream."""
         g = torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
-        sides, open_ = {}, set()
         with torch.cuda.graph(g, stream=cap):
             cs = torch.cuda.current_stream()
             for c in self.calls:
-                if c[0] is JOIN:
-                    if c[1] in open_:
-                        cs.wait_stream(sides[c[1]])
-                        open_.discard(c[1])
-                    continue
                 fn, args = c[0], c[1]
-                k = c[2] if len(c) > 2 else None
-                if k is None:
-                    st = cs
-                else:
-                    st = sides.setdefault(k, torch.cuda.Stream())
-                    if k not in open_:
-                        st.wait_stream(cs)       # fork: everything recorded so far precedes the branch
-                        open_.add(k)
-                rc = fn(*args[:-1], st.cuda_stream)
+                rc = fn(*args[:-1], cs.cuda_stream)
                 if rc != 0:
                     raise OsmosisHipError(f"{fn.__name__} failed during capture ({rc}): "
                                           f"{load().osm_last_error().decode()}")
-            for k in list(open_):                # a capture must end with every forked stream joined
-                cs.wait_stream(sides[k])
         return g
 
     def replay_timed(self, select):
@@ -218,8 +198,6 @@ class Recorder:
         the kernels run on).  `select(fn_name, args)` returns a tag or None.  Returns [(tag, ms)]."""
         marks = []
         for c in self.calls:
-            if c[0] is JOIN:
-                continue
             fn, args = c[0], c[1]
             tag = select(fn.__name__, args)
             if tag is None:
@@ -235,41 +213,13 @@ class Recorder:
         return [(tag, e0.elapsed_time(e1)) for tag, e0, e1 in marks]
 
     def __len__(self):
-        return sum(1 for c in self.calls if c[0] is not JOIN)
+        return len(self.calls)
 
 
 class _State(threading.local):
     def __init__(self):
         self.recorders: List[Recorder] = []
         self.stream: Optional[int] = None
-        self.side: Optional[int] = None
-
-
-JOIN = object()     # marker in Recorder.calls: (JOIN, k)
-
-
-class side_branch:
-    """Calls made inside `with side_branch(k):` are independent of the main-stream calls that follow them until
-    `join(k)`: when the recording is captured as a graph they run on side stream k (a parallel path).  While recording
-    (and in launch-by-launch replay) they simply run in program order on the one stream."""
-
-    def __init__(self, k: int):
-        self.k = k
-
-    def __enter__(self):
-        self.prev = _state.side
-        _state.side = self.k
-        return self
-
-    def __exit__(self, *exc):
-        _state.side = self.prev
-        return False
-
-
-def join(k: int):
-    """Everything recorded after this point may depend on the calls of side branch k."""
-    for r in _state.recorders:
-        r.calls.append((JOIN, k))
 
 
 _state = _State()
@@ -289,7 +239,7 @@ def call(name: str, *args, keep=()):
     if rc != 0:
         raise OsmosisHipError(f"{name} failed ({rc}): {lib.osm_last_error().decode()}")
     for r in _state.recorders:
-        r.calls.append((fn, args) if _state.side is None else (fn, args, _state.side))
+        r.calls.append((fn, args))
         r.keep.extend(keep)
         r.keep.extend(a for a in args if isinstance(a, C.Structure) or hasattr(a, "_obj"))
 

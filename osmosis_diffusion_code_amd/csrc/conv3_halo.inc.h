@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
   constexpr int B_RING = BR, B_DIST = BR - 1;
-  static_assert(PH == 8 || (PH == 16 && PW == 16), "patches are 8 x 8, 8 x 16 or 16 x 16");
+  static_assert(PH == 8, "patches are 8 x 8 or 8 x 16 (the 16 x 16 variant of round 2 lost everywhere but one layer and was removed)");
   static_assert(!NARROW || (PW == 16 && PH == 8), "the narrow variant works on 8 x 16 patches");
   using GEO = HaloGeom<PW, PH>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
@@ -208,35 +208,6 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
             for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)
               acc[cnt & 1] = mma16<NP>(fx[0][pa], bq[s % B_RING][pb], acc[cnt & 1]);
         }
-      } else if constexpr (PH == 16) {
-        // 256-row patch: four pairs of row blocks per (tap, k16) step; fx serves pairs 0 and 2, fy pairs 1 and 3
-#define OSM_T_READ(f_, s_, pr_)                                                             \
-        {                                                                                   \
-          const int t_ = (s_) >> 1, kk_ = (s_) & 1;                                         \
-          const int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;              \
-          _Pragma("unroll") for (int t = 0; t < 2; ++t)                                     \
-            _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                               \
-              f_[t][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE +             \
-                                                          (2 * (pr_) + t) * RB_STRIDE + off_); \
-        }
-        OSM_T_READ(fx, 0, 0)
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-          OSM_H_LOAD_B((s + B_DIST) % B_RING, (s + B_DIST < 18 ? c : cn), (s + B_DIST) % 18);
-          OSM_T_READ(fy, s, 1)
-          OSM_H_MMA(fx, s % B_RING, 0)
-          __builtin_amdgcn_sched_barrier(0);
-          OSM_T_READ(fx, s, 2)
-          OSM_H_MMA(fy, s % B_RING, 1)
-          __builtin_amdgcn_sched_barrier(0);
-          OSM_T_READ(fy, s, 3)
-          OSM_H_MMA(fx, s % B_RING, 2)
-          __builtin_amdgcn_sched_barrier(0);
-          if (s + 1 < 18) OSM_T_READ(fx, s + 1, 0)
-          OSM_H_MMA(fy, s % B_RING, 3)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#undef OSM_T_READ
       } else if constexpr (PW == 16) {
         OSM_H_READ(fx, 0)
 #define OSM_H_STEP(s_)                                                                     \

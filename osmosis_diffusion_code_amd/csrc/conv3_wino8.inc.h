@@ -1,12 +1,13 @@
-// Winograd F(2x2, 3x3), two waves per SIMD (included inside igemm.hip's anonymous namespace, after conv3_wino.inc.h).
+// Winograd F(2x2, 3x3) convolution kernel, two waves per SIMD (included inside igemm.hip's anonymous namespace, after
+// conv3_wino.inc.h, which has the algorithm, the staging layout and the weight packing).
 //
-// Same algorithm, weight image, workgroup tile (16 x 16 output pixels x 64 output channels, 16-channel slabs), LDS staging
-// layout and epilogue semantics as conv3_wino_kernel; what changes is WHO issues the instructions.  The 4-wave kernel runs one
-// wave per SIMD with 16 accumulators: per slab it issues 96 MFMAs next to ~650 VALU / LDS / memory instructions, and a single
-// wave can hide at most ~5 other instructions under one 32-cycle MFMA (MI355X_MICROARCH.md, "one wave per SIMD"), so the matrix
-// pipe sat at 41-45 % busy (profiles/r02_pmc_mfma_busy.json).  Here a workgroup has 8 waves -- two per SIMD, 8 accumulators
-// (128 AGPRs) each -- so the exact 3-plane split of one wave's V fragments issues while its partner's MFMAs occupy the matrix
-// pipe: the VALU and MFMA pipes of a SIMD run concurrently for different waves (tools/ubench/mfma_rate.hip).
+// Workgroup = 16 x 16 output pixels (8 x 8 tiles = two 32-tile blocks) x 64 output channels (two 32-column tiles), 16 input
+// channels per slab, 8 waves x 8 accumulators.  The 18 x 18 x 16-channel halo lands once per slab as raw fp32 in LDS
+// (double-buffered, one barrier per slab); every wave forms the V fragments it multiplies IN the registers that feed the MFMA
+// (lane = (tile, channel half) is the lane that holds that row of the A operand), U fragments come straight from L2 into
+// registers two units ahead.  Round 2's kernel ran one wave per SIMD with 16 accumulators and a hand-interleaved instruction
+// stream; with two waves per SIMD the compiler-scheduled stream below reaches the same time (profiles/r03_wino_power.txt: both
+// draw ~1300 W and sit at the clock the power manager grants), in a third of the code.
 //
 //   wave (r, h): xi row r = wave & 3 of B^T d (two input rows of a tile, as before) and xi COLUMN PAIR h = wave >> 2:
 //          h = 0: V0 = t0 - t2, V1 = t1 + t2;   h = 1: V2 = t2 - t1, V3 = t1 - t3     (t = the wave's row of B^T d)
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const int wr = wave & 3, wh = wave >> 2;
   const int lr = lane & 31, lk = lane >> 5;
 
-  // ---- XCD-aware tile mapping: identical to conv3_wino_kernel
+  // ---- XCD-aware tile mapping.  Workgroups that share an XCD (a contiguous id range) run in step; ids enumerate
+  // (column-tile group, M-tile, column tile within the group): the p.nb1 column tiles of a group work on the SAME input
+  // patch at the same time, so the patch comes from HBM once and from the XCD's L2 p.nb1 - 1 times.
   const int nt = p.mtiles * p.ntiles;
   const int bid = blockIdx.x;
   const int qq = nt >> 3, rr8 = nt & 7, xcd = bid & 7, idx8 = bid >> 3;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][a][b][e] = 0.f;
 
-  // ---- this wave's row of B^T d (as in the 4-wave kernel): t = x + sg y, rows (rx, ry) of the 4 x 4 tile
+  // ---- this wave's row of B^T d:  t = x + sg y  with (x, y) = input rows (0, 2) | (1, 2) | (2, 1) | (1, 3) of the 4 x 4
+  // tile and sg = -1 | +1 | -1 | -1.  Lane = tile (lr >> 3, lr & 7) of a 32-tile block, channel half lk.
   const int tyl = lr >> 3, txl = lr & 7;
   const int rx = wr == 0 ? 0 : (wr == 2 ? 2 : 1), ry = wr == 2 ? 1 : (wr == 3 ? 3 : 2);
   const float sg = wr == 1 ? 1.f : -1.f;

@@ -471,48 +471,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 #include "conv3_halo.inc.h"
 #include "conv3_wino.inc.h"
 #include "conv3_wino8.inc.h"
-#include "skinny.inc.h"
-
-// ---- small-M path (skinny.inc.h): eligibility and its split of K
-// OSM_SKINNY_MAXM: largest M (pixel rows) served by the small-M kernel.  Default 0 = OFF: measured on MI355X (round 2,
-// profiles/r02_small_m_ab.txt) it LOSES to the tiled kernels on every 3x3 layer (8x8 1024->1024: 30 vs 24 us; 16x16:
-// 64 vs 38 us) and ties on 8x8 1x1 layers: every wave gathers its own A fragments (32-byte pieces of 32 different
-// pixel rows per load instruction, ~32 cache lines each), which saturates the CU's vector-memory path long before the
-// weight stream saturates HBM; the tiled kernels stage A once per workgroup through LDS with full-line loads.
-int skinny_max_m() {
-  static const int v = [] {
-    const char* e = std::getenv("OSM_SKINNY_MAXM");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-// OSM_TALL_MINM: from this many pixel rows on, 3x3 layers with W, H >= 16 use 16 x 16 patches (256 GEMM rows per wave)
-// instead of 8 x 16; 0 = never.
-int tall_min_m() {
-  static const int v = [] {
-    const char* e = std::getenv("OSM_TALL_MINM");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-bool tall_ok(int M, int H, int W) { return tall_min_m() > 0 && M >= tall_min_m() && H >= 16 && W >= 16; }
-
-bool skinny_ok(int M, int K, int wfmt, bool gn_table) {
-  return wfmt != 0 && !gn_table && K % 32 == 0 && M <= skinny_max_m();
-}
-int skinny_rb(int M) { return M <= 64 ? 2 : (M <= 128 ? 4 : 8); }
-// grid.y of the small-M kernel (K is cut 4 * grid.y ways: 4 waves per workgroup): ~4 waves per CU, >= 4 k16-steps each
-int skinny_gridy(int M, int N, int K, int taps) {
-  const int rb = skinny_rb(M);
-  const int tiles = ((N + 31) / 32) * ((M + rb * 32 - 1) / (rb * 32));
-  const int nsteps = taps * 2 * ((K + 31) / 32);
-  int nsplit = (1024 + tiles - 1) / tiles;
-  if (nsplit > nsteps / 4) nsplit = nsteps / 4;
-  int gy = (nsplit + 3) / 4;
-  if (gy < 1) gy = 1;
-  if (gy > 16) gy = 16;
-  return gy;
-}
 
 // OSM_CONV_HALO=0 selects the tap-chunked kernel for 3x3 layers too (A/B measurements only)
 bool halo_enabled() {
@@ -560,14 +518,9 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     for (int g = 2; g <= ngrp; ++g) if (p.ntiles % g == 0) p.nb1 = g;
     const unsigned short* Up = reinterpret_cast<const unsigned short*>(p.Bm);
     const dim3 gw(p.mtiles * p.ntiles, p.splitk, 1);
-    // OSM_WINO8=0: the one-wave-per-SIMD kernel of round 2 (conv3_wino.inc.h) instead of the 8-wave kernel (A/B measurements)
-    static const bool wino8 = [] { const char* e = std::getenv("OSM_WINO8"); return !(e && e[0] == '0'); }();
 #define OSM_WINO_LAUNCH(NP_)                                                                               \
-    if (wino8) {                                                                                           \
-      if (p.gn_table) hipLaunchKernelGGL((conv3_wino8_kernel<NP_, true>), gw, dim3(512), 0, st, p.A, Up, p);  \
-      else hipLaunchKernelGGL((conv3_wino8_kernel<NP_, false>), gw, dim3(512), 0, st, p.A, Up, p);         \
-    } else if (p.gn_table) hipLaunchKernelGGL((conv3_wino_kernel<NP_, true>), gw, dim3(256), 0, st, p.A, Up, p);  \
-    else hipLaunchKernelGGL((conv3_wino_kernel<NP_, false>), gw, dim3(256), 0, st, p.A, Up, p);
+    if (p.gn_table) hipLaunchKernelGGL((conv3_wino8_kernel<NP_, true>), gw, dim3(512), 0, st, p.A, Up, p);  \
+    else hipLaunchKernelGGL((conv3_wino8_kernel<NP_, false>), gw, dim3(512), 0, st, p.A, Up, p);
 #ifdef OSM_ACT_F16
     if (wfmt != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "fp16 family: Winograd image wfmt 1 only");
     OSM_WINO_LAUNCH(1)
@@ -582,56 +535,29 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
   } else
   {
   const bool halo_path = wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled();
-  if (p.colsum && (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) || wfmt == 0 || !(halo_path || p.splitk > 1)))
+  if (p.colsum && (wfmt == 0 || !(halo_path || p.splitk > 1)))
     return osm::fail(OSM_ERR_UNSUPPORTED, "column sums are produced by the halo-tile kernel or the split-K combine only "
                                           "(ask osm_conv_stat_chunks first)");
-  if (skinny_ok(p.M, p.K, wfmt, p.gn_table != nullptr) && p.nbatch == 1) {
-    // small-M kernel: weight streaming, K split over the 4 waves of a workgroup (and over grid.y = p.splitk)
-    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
-    const int rb = skinny_rb(p.M);
-    const int nsteps = taps * p.ksteps;
-    if (p.splitk * 4 > nsteps) p.splitk = nsteps / 4 > 0 ? nsteps / 4 : 1;
-    const dim3 g3(p.nt32, p.splitk, (p.M + rb * 32 - 1) / (rb * 32));
-#define OSM_SK_LAUNCH(NP_, RB_, T_) hipLaunchKernelGGL((skinny_kernel<NP_, RB_, T_>), g3, dim3(256), 0, st, p.A, Bp, p)
-#define OSM_SK_PICK(NP_)                                                                                   \
-    if (taps == 9) { if (rb == 2) OSM_SK_LAUNCH(NP_, 2, 9); else if (rb == 4) OSM_SK_LAUNCH(NP_, 4, 9); else OSM_SK_LAUNCH(NP_, 8, 9); } \
-    else           { if (rb == 2) OSM_SK_LAUNCH(NP_, 2, 1); else if (rb == 4) OSM_SK_LAUNCH(NP_, 4, 1); else OSM_SK_LAUNCH(NP_, 8, 1); }
-#ifdef OSM_ACT_F16
-    OSM_SK_PICK(1)
-#else
-    if (wfmt == 3) { OSM_SK_PICK(3) } else { OSM_SK_PICK(2) }
-#endif
-#undef OSM_SK_PICK
-#undef OSM_SK_LAUNCH
-  } else if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
+  if (wfmt != 0 && taps == 9 && p.W >= 8 && p.H >= 8 && halo_enabled()) {
     // halo-tile kernel: M-tiles are 8 x 16 (W >= 16) or 8 x 8 pixel patches, K is consumed in 32-channel slabs of all 9 taps
     const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.Bm);
     const bool wide = p.W >= 16;
-    const bool tall = tall_ok(p.M, p.H, p.W);
     const int nimg = p.M / (p.H * p.W);
-    p.mtiles = nimg * ((p.H + (tall ? 15 : 7)) / (tall ? 16 : 8)) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
+    p.mtiles = nimg * ((p.H + 7) / 8) * (wide ? (p.W + 15) / 16 : (p.W + 7) / 8);
     p.nchunks = (p.K + BK - 1) / BK;
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     p.stat_chunks = p.mtiles / nimg;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
     if (wfmt < 1 || wfmt > 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
-    // deeper weight-fragment rings where the weight stream sets the pace (few pixel rows per weight byte)
-    static const int ring16 = [] { const char* e = std::getenv("OSM_BRING16"); return e ? atoi(e) : 3; }();
-    static const int ring8 = [] { const char* e = std::getenv("OSM_BRING8"); return e ? atoi(e) : 3; }();
-    const bool deep16 = ring16 == 6 && p.M <= 4096, deep8 = ring8 == 9;
     // <= 32 output columns (head / stem data-gradient): the waves split the row blocks instead of the column tiles
     static const bool narrow_on = [] { const char* e = std::getenv("OSM_NARROW"); return !(e && e[0] == '0'); }();
-    const bool narrow = narrow_on && wide && !tall && p.N <= 32 && !p.colsum;
+    const bool narrow = narrow_on && wide && p.N <= 32 && !p.colsum;
 #define OSM_HALO_LAUNCH(NP_, GN_, PW_, BR_) \
     hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, GN_, PW_, BR_>), g2, dim3(256), 0, st, p.A, Bp, p)
 #define OSM_HALO_PICK(NP_)                                                                                  \
     if (narrow) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 8, true>), g2, dim3(256), 0, st, p.A, Bp, p); \
                   else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, false, 16, 3, 8, true>), g2, dim3(256), 0, st, p.A, Bp, p); }       \
-    else if (tall) { if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, true, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); \
-                else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<NP_, false, 16, 3, 16>), g2, dim3(256), 0, st, p.A, Bp, p); }       \
-    else if (wide && deep16) { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 6); else OSM_HALO_LAUNCH(NP_, false, 16, 6); } \
     else if (wide)      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 3); else OSM_HALO_LAUNCH(NP_, false, 16, 3); } \
-    else if (deep8)     { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 9);  else OSM_HALO_LAUNCH(NP_, false, 8, 9); }  \
     else                { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 3);  else OSM_HALO_LAUNCH(NP_, false, 8, 3); }
 #ifdef OSM_ACT_F16
     OSM_HALO_PICK(1)
@@ -733,27 +659,37 @@ extern "C" int osm_conv_splitk(int B, int H, int W, int Cin, int Cout, int ksize
     if (s > nslab / 4) s = nslab / 4;
     return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
   }
-  if (skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return skinny_gridy(M, Cout, Cin, ksize * ksize);
   return osm_splitk_hint(M, Cout, Cin, ksize * ksize, 1);
+}
+extern "C" int osm_conv_kernel_kind(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt) {
+  (void)B;
+  if (wfmt & OSM_WFMT_WINOGRAD) return 5;
+  if (wfmt == 0) return 0;
+  if (ksize == 3 && W >= 8 && H >= 8 && halo_enabled()) {
+    static const bool narrow_on = [] { const char* e = std::getenv("OSM_NARROW"); return !(e && e[0] == '0'); }();
+    if (W >= 16) return (narrow_on && Cout <= 32) ? 4 : 2;
+    return 3;
+  }
+  return 1;
 }
 // chunks per image of the column sums a layer can emit (osm_conv_desc.colsum), 0 = that layer's kernel cannot
 extern "C" int osm_conv_stat_chunks(int B, int H, int W, int Cin, int Cout, int ksize, int wfmt, int splitk,
                                     int has_gn_table) {
-  const int M = B * H * W;
+  (void)B; (void)has_gn_table;
   if (wfmt & OSM_WFMT_WINOGRAD) {
     const int nslab = 2 * ((Cin + 31) / 32);
     if (splitk > nslab) splitk = nslab;
     if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
     return ((H + 15) / 16) * ((W + 15) / 16);   // the kernel's epilogue: one chunk per 16 x 16 patch
   }
-  if (wfmt == 0 || skinny_ok(M, Cin, wfmt, has_gn_table != 0)) return 0;
+  if (wfmt == 0) return 0;
   const bool halo = ksize == 3 && W >= 8 && H >= 8 && halo_enabled();
   // the split launch() will really use: it is clamped to the number of K chunks (32-channel slabs of the halo kernel /
   // 32-channel chunks per tap of the tap-chunked kernel)
   const int nchunks = (halo ? 1 : ksize * ksize) * ((Cin + BK - 1) / BK);
   if (splitk > nchunks) splitk = nchunks;
   if (splitk > 1) return (Cout % 4 == 0 && (H * W) % 8 == 0) ? H * W / 8 : 0;
-  if (halo) return ((H + (tall_ok(M, H, W) ? 15 : 7)) / (tall_ok(M, H, W) ? 16 : 8)) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
+  if (halo) return ((H + 7) / 8) * (W >= 16 ? (W + 15) / 16 : (W + 7) / 8);
   return 0;
 }
 

@@ -27,7 +27,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import OsmosisHipError, Recorder, current_stream_ptr, join, side_branch
+from ._lib import OsmosisHipError, Recorder, current_stream_ptr
 from .ops import Mat
 
 G = 32  # GroupNorm32 groups (nn.py:93-100)
@@ -254,10 +254,6 @@ class UNetEngine:
         # the forward statistics of a ResBlock's second GroupNorm come from its first convolution; "all": also the two
         # backward reductions, from the data-gradient convolutions (measured a net loss: the epilogue must re-read the
         # GroupNorm input with 4-byte accesses: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1); "0": neither
-        # independent branches (a ResBlock's 1x1 skip convolution, forward and data-gradient) as parallel graph paths.
-        # OFF by default: measured 31.98 vs 31.54 ms / step -- the memory-bound 1x1 next to the power-limited 3x3 slows
-        # the 3x3 by more than it hides (OSM_SIDE_STREAMS=1 to enable)
-        self.side_streams = self.use_graph and os.environ.get("OSM_SIDE_STREAMS", "0") != "0"
         self.winograd_min_hw = int(os.environ.get("OSM_WINOGRAD_MIN_HW", "16"))   # smallest H, W served by the Winograd kernel
         fs = os.environ.get("OSM_FUSE_STATS", "fwd")
         self.fuse_gn_wino = os.environ.get("OSM_FUSE_GN_WINO", "0") == "1"
@@ -431,16 +427,12 @@ class UNetEngine:
             # reductions into their epilogues with them (see _res_bwd)
             tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._gn_fusable(blk.c1, hw)) else None
             if blk.skip is not None:
-                # the 1x1 skip convolution depends on x only: a parallel path of the graph next to GN -> conv3x3 -> GN
-                # (memory-bound 1x1 beside the MFMA-bound 3x3); joined before the second 3x3 adds it as its residual
-                with side_branch(1) if self.side_streams else contextlib.nullcontext():
-                    self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
+                self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
                                 stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         if blk.skip is not None:
-            join(1)
             res = dst
         else:
             res = xs
@@ -455,9 +447,8 @@ class UNetEngine:
         H, W = s["hw"]
         ho, wo = s["hwo"]
         M, Mo = B * H * W, B * ho * wo
-        if blk.skip is not None:      # skip-path gradient: independent of the main chain until the final GroupNorm apply
-            with side_branch(1) if self.side_streams else contextlib.nullcontext():
-                self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2")
+        if blk.skip is not None:      # skip-path gradient
+            self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2")
         dh2 = self._scr("a", Mo, blk.cout)
         # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
         # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
@@ -497,7 +488,6 @@ class UNetEngine:
             add = t
             add2 = dx_dst if accumulate else None
         elif blk.skip is not None:
-            join(1)
             add = dx_dst
         else:
             add = dy
