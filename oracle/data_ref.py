@@ -3,31 +3,33 @@
   ToTensor (uint8 HWC / 255 -> CHW float32), Resize(256) = bilinear interpolation with half-pixel centres
   (src = (dst + 0.5) * in/out - 0.5, clamped at 0; no antialiasing), smaller edge -> 256 and the longer edge
   int(256 * long / short), CenterCrop (offset round((H - h) / 2)), Normalize ((x - 0.5) / 0.5).
-Pinned by tests/golden/resize_chain.npz (oracle/tools/gen_resize_golden.py): the output of the ATen interpolate call
-torchvision 0.14.x makes for tensor inputs.  torchvision itself is not installed in the build container, so the
-pin is at that operator, not at the torchvision wrapper.
+`dtype=np.float64` evaluates the same published formula in double: that evaluation -- independent of torch -- generates
+tests/golden/resize_chain.npz (oracle/tools/gen_resize_golden.py), to which the product chain, a direct ATen
+`interpolate(..., "bilinear", align_corners=False, antialias=False)` call and the fp32 evaluation below are all held.
+torchvision itself is not installed in the build container: the torchvision-0.14.1 wrapper stays un-pinned.
 """
 import numpy as np
 
 
-def to_tensor(hwc_uint8):
+def to_tensor(hwc_uint8, dtype=np.float32):
     a = np.asarray(hwc_uint8)
     if a.ndim == 2:
         a = a[:, :, None]
-    return (a.astype(np.float32) / np.float32(255)).transpose(2, 0, 1)
+    return (a.astype(dtype) / dtype(255)).transpose(2, 0, 1)
 
 
-def _axis_weights(n_in, n_out):
-    scale = np.float32(n_in) / np.float32(n_out)
-    src = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+def _axis_weights(n_in, n_out, dtype=np.float32):
+    scale = dtype(n_in) / dtype(n_out)
+    src = (np.arange(n_out, dtype=dtype) + dtype(0.5)) * scale - dtype(0.5)
     src = np.maximum(src, 0)
     i0 = np.minimum(np.floor(src).astype(np.int64), n_in - 1)
     i1 = np.minimum(i0 + 1, n_in - 1)
-    w1 = (src - i0.astype(np.float32)).astype(np.float32)
-    return i0, i1, np.float32(1) - w1, w1
+    w1 = (src - i0.astype(dtype)).astype(dtype)
+    return i0, i1, dtype(1) - w1, w1
 
 
 def resize_short(chw, size):
+    dtype = chw.dtype.type
     c, h, w = chw.shape
     if w <= h:
         nw, nh = size, int(size * h / w)
@@ -35,10 +37,10 @@ def resize_short(chw, size):
         nh, nw = size, int(size * w / h)
     if (nh, nw) == (h, w):
         return chw
-    y0, y1, wy0, wy1 = _axis_weights(h, nh)
-    x0, x1, wx0, wx1 = _axis_weights(w, nw)
+    y0, y1, wy0, wy1 = _axis_weights(h, nh, dtype)
+    x0, x1, wx0, wx1 = _axis_weights(w, nw, dtype)
     rows = chw[:, y0, :] * wy0[None, :, None] + chw[:, y1, :] * wy1[None, :, None]
-    return (rows[:, :, x0] * wx0[None, None, :] + rows[:, :, x1] * wx1[None, None, :]).astype(np.float32)
+    return (rows[:, :, x0] * wx0[None, None, :] + rows[:, :, x1] * wx1[None, None, :]).astype(dtype)
 
 
 def center_crop(chw, th, tw):
@@ -47,6 +49,6 @@ def center_crop(chw, th, tw):
     return chw[:, top:top + th, left:left + tw]
 
 
-def transform(hwc_uint8, size=256):
-    x = center_crop(resize_short(to_tensor(hwc_uint8), size), size, size)
-    return (x - np.float32(0.5)) / np.float32(0.5)
+def transform(hwc_uint8, size=256, dtype=np.float32):
+    x = center_crop(resize_short(to_tensor(hwc_uint8, dtype), size), size, size)
+    return (x - dtype(0.5)) / dtype(0.5)

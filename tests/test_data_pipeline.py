@@ -1,8 +1,9 @@
 """datasets + transform chain of the reference driver (host side, CPU tests).
-The Resize step is pinned by tests/golden/resize_chain.npz: the output of the ATen call torchvision 0.14.x makes for
-tensor inputs (`interpolate(..., mode="bilinear", align_corners=False, antialias=False)`, generated by
-oracle/tools/gen_resize_golden.py), held against BOTH the product code and the independent numpy restatement
-(oracle/data_ref.py).  torchvision itself is not installed here, so the chain is pinned at that operator."""
+The Resize step is pinned by tests/golden/resize_chain.npz, which round 3 generates WITHOUT torch: the float64 evaluation of
+the published half-pixel bilinear formula (oracle/data_ref.py, oracle/tools/gen_resize_golden.py).  Held to it: the product
+chain (osmosis_utils/data.py), a direct ATen `interpolate(..., "bilinear", align_corners=False, antialias=False)` call -- the
+operator torchvision 0.14.x dispatches to for tensor inputs -- and the fp32 numpy evaluation.  torchvision itself is not
+installed here: the wrapper stays un-pinned."""
 import os
 
 import numpy as np
@@ -35,21 +36,44 @@ def test_transform_chain_matches_oracle(h, w):
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "resize_chain.npz")
 
 
+def _aten_chain(img_u8_hwc, size):
+    """The ATen call torchvision 0.14.x makes for tensor inputs, then CenterCrop / Normalize -- written against torch
+    directly, not through the product code."""
+    import torch.nn.functional as F
+    x = torch.from_numpy(img_u8_hwc).permute(2, 0, 1).to(torch.float32).div(255)
+    h, w = x.shape[-2:]
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long_ / short)
+    nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+    if (nh, nw) != (h, w):
+        x = F.interpolate(x[None], size=[nh, nw], mode="bilinear", align_corners=False, antialias=False)[0]
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    x = x[:, top:top + size, left:left + size]
+    return (x - 0.5) / 0.5
+
+
 @pytest.mark.parametrize("k", range(6))
 def test_transform_chain_matches_golden(k):
-    """Product chain and numpy oracle vs the committed ATen-generated vectors (sizes 32 and 256)."""
+    """Product chain, a direct ATen interpolate call and the fp32 numpy oracle vs the committed float64 vectors (sizes 32
+    and 256).  Tolerance 2e-4: the fp32 source coordinate (dst + 0.5) * in/out - 0.5 is rounded at magnitudes up to 512
+    (1 ulp = 6e-5 -> a weight moves by 6e-5 -> <= 1.2e-4 after Normalize); the float64 golden has no such rounding."""
     g = np.load(GOLD)
+    assert "no torch" in str(g["generator"])
     img = g[f"img_{k}"]
+    tol = 2e-4
     got32 = D.default_transform(32)(Image.fromarray(img)).numpy()
-    assert np.array_equal(got32, g[f"out32_{k}"])                     # same operator, same arguments: bit-exact
-    assert np.allclose(DR.transform(img, 32), g[f"out32_{k}"], atol=2e-4)
+    aten32 = _aten_chain(img, 32).numpy()
+    assert np.array_equal(got32, aten32)                              # the product IS that operator call: bit-exact
+    for name, v in (("product", got32), ("aten", aten32), ("numpy fp32", DR.transform(img, 32))):
+        assert np.allclose(v, g[f"out32_{k}"], atol=tol), (name, float(np.abs(v - g[f"out32_{k}"]).max()))
     got = D.default_transform(256)(Image.fromarray(img))
+    aten = _aten_chain(img, 256)
     assert list(got.shape) == list(g[f"out256_shape_{k}"]) == [3, 256, 256]
-    assert np.array_equal(got[:, 112:144, 112:144].numpy(), g[f"out256_win_{k}"])
-    assert abs(float(got.double().sum()) - float(g[f"out256_sum_{k}"])) < 1e-6 * 3 * 256 * 256
+    assert torch.equal(got, aten)
     want = DR.transform(img, 256)
-    assert np.allclose(want[:, 112:144, 112:144], g[f"out256_win_{k}"], atol=2e-4)
-    assert abs(float(want.astype(np.float64).sum()) - float(g[f"out256_sum_{k}"])) < 2e-4 * 3 * 256 * 256
+    for name, v in (("product", got.numpy()), ("numpy fp32", want)):
+        assert np.allclose(v[:, 112:144, 112:144], g[f"out256_win_{k}"], atol=tol), name
+        assert abs(float(v.astype(np.float64).sum()) - float(g[f"out256_sum_{k}"])) < tol * 3 * 256 * 256, name
 
 
 def test_resize_rule_and_center_crop_offsets():
@@ -95,3 +119,64 @@ def test_images_folder_and_gt_datasets(tmp_path):
     assert np.allclose(g_dep.numpy(), want, atol=2e-4)
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)))
     assert batch[0].shape == (2, 3, 32, 32) and list(batch[1]) == ["s2.png", "s10.png"]
+
+
+@pytest.mark.gpu
+def test_image_file_to_restored_image_end_to_end(tmp_path):
+    """A seeded NON-SQUARE PNG on disk -> ImagesFolder -> ToTensor / Resize(64) / CenterCrop / Normalize -> restore_image
+    (3 guided steps on the HIP path) must equal the same call on the tensor the numpy restatement of the chain builds from
+    the decoded pixels (oracle/data_ref.py): the file -> tensor -> device -> sampler path of the reference driver
+    (osmosis_sampling.py:46-62, 117-232; osmosis_utils/data.py:15-36) has no step the tensor-level tests skip."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as UR
+    from osmosis_diffusion_code_amd import sampling
+    from osmosis_diffusion_code_amd.guided_diffusion import unet
+    dev = "cuda:0"
+    rng = np.random.default_rng(5)
+    h, w = 83, 131
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.clip(120 + 90 * np.sin(yy[..., None] / 11.0 + np.arange(3)) * np.cos(xx[..., None] / 7.0)
+                  + rng.integers(-15, 16, size=(h, w, 3)), 0, 255).astype(np.uint8)
+    os.makedirs(tmp_path / "in")
+    Image.fromarray(img).save(tmp_path / "in" / "scene_7.png")
+    Image.fromarray(img[::-1].copy()).save(tmp_path / "in" / "scene_10.png")
+    ds = D.ImagesFolder(str(tmp_path / "in"), D.default_transform(64))
+    assert [ds[i][1] for i in range(len(ds))] == ["scene_7.png", "scene_10.png"]      # natural order
+    ref_file, name = ds[0]
+    ref_np = torch.from_numpy(DR.transform(img, 64))
+    assert ref_file.shape == (3, 64, 64) and float((ref_file - ref_np).abs().max()) < 2e-4
+
+    kw = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+              num_head_channels=16, num_heads=4, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+              pretrain_model="osmosis")
+    ucfg = UR.UNetConfig.from_create_model_kwargs(**kw)
+    model = unet.create_model(**kw)
+    model.load_state_dict(UR.seeded_state_dict(ucfg, 1234), strict=True)
+    model = model.to(dev).eval()
+    pattern = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0, n_iter=20,
+                   start_guidance=1, stop_guidance=0)
+    cfg = dict(
+        measurement=dict(operator=dict(name="underwater_physical_revised", optimizer="sgd", depth_type="gamma",
+                                       value="1.4,1.4,1", phi_a="1.1,0.95,0.95", phi_a_eta="1e-5", phi_a_learn_flag=True,
+                                       phi_b="0.95, 0.8, 0.8", phi_b_eta="1e-5", phi_b_learn_flag=True,
+                                       phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5", phi_inf_learn_flag=True),
+                         noise=dict(name="clean")),
+        conditioning=dict(method="osmosis", params=dict(loss_function="norm", loss_weight="depth",
+                                                        weight_function="gamma,1.4,1.4,1", scale="7,7,7,0.9",
+                                                        gradient_x_prev=True, gradient_clip="True,0.005")),
+        sample_pattern=pattern, aux_loss=dict(aux_loss={"avrg_loss": 0.5, "val_loss": 20}),
+        diffusion=dict(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                       model_var_type="learned_range", dynamic_threshold=False, clip_denoised=False,
+                       rescale_timesteps=False, timestep_respacing="100"),
+        unet_model=dict(pretrain_model="osmosis"), manual_seed=3, degamma_input=False, rgb_guidance=False)
+    a = sampling.restore_image(model, ref_file[None].to(dev), cfg, index_range=(2, 0))[0]
+    b = sampling.restore_image(model, ref_np[None].to(dev), cfg, index_range=(2, 0))[0]
+    assert torch.isfinite(a["pred_xstart"]).all()
+    # the two inputs differ by <= 2e-4 (fp32 vs float64-free numpy evaluation of the resize); three guided steps keep that scale
+    for key in ("sample", "pred_xstart", "rgb_01_clip", "degraded"):
+        assert float((a[key] - b[key]).abs().max()) < 1e-3, key
+    assert abs(a["norm_loss_final"] - b["norm_loss_final"]) < 5e-3
+    # and the file path is deterministic: a second pass over the dataset gives the identical result
+    c = sampling.restore_image(model, ds[0][0][None].to(dev), cfg, index_range=(2, 0))[0]
+    assert torch.equal(a["pred_xstart"], c["pred_xstart"])
