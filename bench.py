@@ -127,6 +127,7 @@ def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warm
     # this only keeps the reported outputs finite.
     first = min(int(0.3 * T) - 1, T - 1)
     x_T = 0.5 * x_T
+    torch.manual_seed(4242 + image_index)       # the per-step noise of this image's chain (device generator)
 
     def run(n_steps, start):
         return sampler.p_sample_loop(model=model, x_start=x_T, measurement=y, measurement_cond_fn=cond.conditioning,
@@ -146,6 +147,13 @@ def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warm
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dump = os.environ.get("OSM_BENCH_DUMP")     # tests: per-rank checksum of the final x_t (which image, what came out)
+    if dump:
+        import hashlib
+        x = out[0].detach().cpu().contiguous()
+        with open(os.path.join(dump, f"rank{int(os.environ.get('RANK', '0'))}_of_{world}.json"), "w") as f:
+            json.dump({"image_index": image_index, "sha1": hashlib.sha1(x.numpy().tobytes()).hexdigest(),
+                       "abs_sum": float(x.double().abs().sum()), "finite": bool(torch.isfinite(x).all())}, f)
     return dt, bool(torch.isfinite(out[0]).all())
 
 

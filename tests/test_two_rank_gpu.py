@@ -1,6 +1,7 @@
-"""SURVEY.md section 4 tier 5 / section 8e on the HIP path: the same per-image result on 1 rank and on 2 ranks.
-Two processes (gloo rendezvous on 127.0.0.1, both on cuda:0 -- the box has one GPU) each restore images[rank::2]
-with the fused HIP sampler; the parent restores all four images in one process and compares bit for bit."""
+"""SURVEY.md section 4 tier 5 / section 8e on the HIP path: the same per-image result on 1 rank, on 2 ranks and on 8 ranks
+(the world size of the driver's scaling run).  W processes (gloo rendezvous on 127.0.0.1, all on cuda:0 -- the box has one
+GPU) each restore images[rank::W] with the fused HIP sampler; the parent restores all images in one process and compares
+bit for bit."""
 import os
 import socket
 import subprocess
@@ -20,30 +21,29 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("batch_size", [1, 2])
-def test_two_ranks_equal_one_rank(tmp_path, batch_size):
+@pytest.mark.parametrize("world,batch_size,n_images", [(2, 1, 4), (2, 2, 4), (8, 1, 8)])
+def test_ranks_equal_one_rank(tmp_path, world, batch_size, n_images):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import two_rank_worker as W
-    world = 2
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(tmp_path),
-                                       str(batch_size)], env=env))
+                                       str(batch_size), str(n_images)], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     one = tmp_path / "single"
     one.mkdir()
-    W.run(0, 1, str(one), batch_size=1)
+    W.run(0, 1, str(one), batch_size=1, n_images=n_images)
     ref = dict(np.load(one / "rank0.npz"))
-    assert len(ref) == 12
+    assert len(ref) == 3 * n_images
     seen = set()
     for r in range(world):
         got = dict(np.load(tmp_path / f"rank{r}.npz"))
-        assert sorted(int(k.split("_")[-1]) for k in got if k.startswith("x0_")) == list(range(4))[r::world]
+        assert sorted(int(k.split("_")[-1]) for k in got if k.startswith("x0_")) == list(range(n_images))[r::world]
         for k, v in got.items():
             assert np.isfinite(v).all()
             if batch_size == 1:
@@ -53,4 +53,4 @@ def test_two_ranks_equal_one_rank(tmp_path, batch_size):
             seen.add(k)
     assert seen == set(ref)
     g = np.load(tmp_path / "gathered.npz")
-    assert g["losses"].shape == (4,) and np.isfinite(g["losses"]).all() and float(g["tmax"]) == 2.0
+    assert g["losses"].shape == (n_images,) and np.isfinite(g["losses"]).all() and float(g["tmax"]) == float(world)
