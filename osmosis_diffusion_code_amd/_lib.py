@@ -59,7 +59,7 @@ class PhysDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("depth_type", C.c_int), ("dval", C.c_float * 3),
                 ("weight_type", C.c_int), ("wdepth_type", C.c_int), ("wval", C.c_float * 3),
                 ("loss_type", C.c_int), ("gamma_avrg", C.c_float), ("gamma_val", C.c_float),
-                ("eta", C.c_float * 3), ("B", C.c_int), ("HW", C.c_int)]
+                ("eta", C.c_float * 3), ("B", C.c_int), ("HW", C.c_int), ("optimizer", C.c_int)]
 
 
 # name -> argtypes (restype is int unless listed in _SPECIAL)
@@ -106,7 +106,7 @@ _SIGS = {
     "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "osm_phys_nblk": [_I],
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
-    "osm_phys_finalize": [C.POINTER(PhysDesc), _P, _P, _P, _I, _P, _P],
+    "osm_phys_finalize": [C.POINTER(PhysDesc), _P, _P, _P, _I, _P, _P, _P],
     "osm_phys_grad": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P, _P],
     "osm_posterior_bwd": [_P, _P, _P, _I, _I, _P],
     "osm_guide_update": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void phys_reduce_kernel(osm_phys_desc ds, cons
 
 __global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__ part, float* __restrict__ red,
                                      float* __restrict__ phi, int do_update, float* __restrict__ loss_out,
-                                     int nblk) {
+                                     float* __restrict__ opt_state, int nblk) {
   __shared__ double tot[NRED];
   const int b = blockIdx.x;
   if (threadIdx.x < NRED) {
@@ -132,20 +132,47 @@ __global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__
     if (loss_out) loss_out[b] = (float)L;
     if (do_update) {
       float* ph = phi + b * 9;
+      // gradient of every live parameter (as the reference's autograd leaves have it), then the optimizer step
+      float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float lr[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int live = 0;                      // bit i: phi[i] is a parameter of this operator
       if (ds.kind == 0) {
         for (int c = 0; c < 3; ++c) {
-          ph[c] -= ds.eta[0] * (float)(tot[1 + c] * gscale);
-          ph[3 + c] -= ds.eta[1] * (float)(tot[4 + c] * gscale);
+          g[c] = (float)(tot[1 + c] * gscale); lr[c] = ds.eta[0];
+          g[3 + c] = (float)(tot[4 + c] * gscale); lr[3 + c] = ds.eta[1];
         }
+        live = 0x3f;
       } else if (ds.kind == 1) {
-        for (int c = 0; c < 3; ++c) ph[c] -= ds.eta[0] * (float)((tot[1 + c] + tot[4 + c]) * gscale);
+        for (int c = 0; c < 3; ++c) { g[c] = (float)((tot[1 + c] + tot[4 + c]) * gscale); lr[c] = ds.eta[0]; }
+        live = 0x7;
       } else {
-        double g = 0.0;
-        for (int c = 0; c < 3; ++c) g += tot[1 + c] + tot[4 + c];
-        const float nv = ph[0] - ds.eta[0] * (float)(g * gscale);
-        ph[0] = ph[1] = ph[2] = nv;
+        double gs = 0.0;
+        for (int c = 0; c < 3; ++c) gs += tot[1 + c] + tot[4 + c];
+        g[0] = (float)(gs * gscale); lr[0] = ds.eta[0];
+        live = 0x1;
       }
-      for (int c = 0; c < 3; ++c) ph[6 + c] -= ds.eta[2] * (float)(tot[7 + c] * gscale);
+      for (int c = 0; c < 3; ++c) { g[6 + c] = (float)(tot[7 + c] * gscale); lr[6 + c] = ds.eta[2]; }
+      live |= 0x1c0;
+      if (ds.optimizer == 1) {          // torch.optim.Adam (single-tensor path, fp32 state, amsgrad off)
+        float* st = opt_state + b * 20;
+        const float step = st[18] + 1.f;
+        st[18] = step;
+        const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+        const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+        const float bc2_sqrt = (float)sqrt(bc2);
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;      // learn_flag False: no gradient, the optimizer skips it
+          const float m = st[i] + (g[i] - st[i]) * (float)(1.0 - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+          const float v = st[9 + i] * (float)b2 + (float)(1.0 - b2) * g[i] * g[i];  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+          st[i] = m; st[9 + i] = v;
+          const float denom = sqrtf(v) / bc2_sqrt + (float)eps;
+          ph[i] += (float)(-(double)lr[i] / bc1) * (m / denom);                   // param.addcdiv_(exp_avg, denom, value=-step_size)
+        }
+      } else {
+        for (int i = 0; i < 9; ++i)
+          if ((live >> i) & 1) ph[i] -= lr[i] * g[i];
+      }
+      if (ds.kind == 2) ph[1] = ph[2] = ph[0];
     }
   }
 }
@@ -309,12 +336,14 @@ extern "C" int osm_phys_reduce(const osm_phys_desc* d, const float* x0, const fl
 }
 
 extern "C" int osm_phys_finalize(const osm_phys_desc* d, const float* part, float* red, float* phi,
-                                 int do_update, float* loss_out, void* stream) {
+                                 int do_update, float* loss_out, float* opt_state, void* stream) {
   int rc = check_desc(d, "osm_phys_finalize");
   if (rc) return rc;
   OSM_REQUIRE(part && red && phi, "osm_phys_finalize: null pointer");
+  OSM_REQUIRE(d->optimizer == 0 || d->optimizer == 1, "osm_phys_finalize: optimizer must be 0 (sgd / GD) or 1 (adam)");
+  OSM_REQUIRE(!(d->optimizer == 1 && do_update) || opt_state, "osm_phys_finalize: the Adam step needs opt_state [B][20]");
   hipLaunchKernelGGL(phys_finalize_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, *d, part, red, phi,
-                     do_update, loss_out, osm_phys_nblk(d->HW));
+                     do_update, loss_out, opt_state, osm_phys_nblk(d->HW));
   return osm::check_launch("phys_finalize_kernel");
 }
 

@@ -545,7 +545,11 @@ class UNetEngine:
         # 64-wide heads (every block of the 256-channel model): flash-style core on the matrix cores
         # (OSM_ATTN_FLASH=0: the round-1 paths -- FMA core at T = 64, GEMM pipeline above; =256: flash from T = 256 only)
         fl = os.environ.get("OSM_ATTN_FLASH", "1")
-        flash = fl != "0" and ops.attn_flash_supported(T, ch) and T >= (int(fl) if fl not in ("0", "1") else 64)
+        try:
+            fl_min = int(fl) if fl not in ("0", "1") else 64
+        except ValueError:          # "on", "all", ...: flash wherever it is supported
+            fl_min = 64
+        flash = fl != "0" and ops.attn_flash_supported(T, ch) and T >= fl_min
         mode = os.environ.get("OSM_ATTN_FUSED", "64")
         fused = (not flash) and ops.attn_small_supported(T, ch) and (mode == "all" or (mode != "0" and T <= 64))
         P = PT = lse = None

@@ -142,11 +142,15 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         coefs = self.aux_loss.kernel_coefficients() if self.aux_loss is not None else {"gamma_avrg": 0.0, "gamma_val": 0.0}
         d.gamma_avrg, d.gamma_val = coefs["gamma_avrg"], coefs["gamma_val"]
         d.B, d.HW = B, HW
+        d.optimizer = 1 if getattr(op, "optimizer", "") == "adam" else 0
         nblk = ops.phys_nblk(HW)
         st = {"key": (B, HW, str(device)), "desc": d,
               "part": torch.empty(B * nblk * 16, device=device, dtype=torch.float32),
               "red": torch.zeros(B * 16, device=device, dtype=torch.float32),
               "loss": torch.zeros(B, device=device, dtype=torch.float32),
+              # Adam moments + step of the operator's phi (torch.optim state lives with the optimizer = with the operator,
+              # which the driver rebuilds per image: osmosis_sampling.py:142-155)
+              "opt": torch.zeros(op.phi.shape[0], 20, device=device, dtype=torch.float32) if d.optimizer == 1 else None,
               "g": torch.empty(B, 4, HW, device=device, dtype=torch.float32)}
         self._state = st
         return st
@@ -160,7 +164,7 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         if y.shape[0] != B or y.shape[1] != 3 or x0.shape[1] != 4:
             raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
         st = self._prepare(B, HW, x0.device)
-        d, part, red, loss = st["desc"], st["part"], st["red"], st["loss"]
+        d, part, red, loss, opt = st["desc"], st["part"], st["red"], st["loss"], st["opt"]
         if loss_out is not None:
             loss = loss_out
         phi = self.operator.phi if phi is None else phi
@@ -177,10 +181,20 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
                 ops.phys_finalize(d, part, red, phi, False, loss)
                 ops.phys_grad(d, x0c, yc, phi, red, g)
                 if not freeze_phi:
-                    ops.phys_finalize(d, part, red, phi, True, None)
+                    ops.phys_finalize(d, part, red, phi, True, None, opt_state=self._opt_rows(opt, phi))
             else:
-                ops.phys_finalize(d, part, red, phi, True, loss)
+                ops.phys_finalize(d, part, red, phi, True, loss, opt_state=self._opt_rows(opt, phi))
         return g.view(x0.shape), loss
+
+    def _opt_rows(self, opt, phi):
+        """The optimizer-state rows that belong to the phi rows in hand (a chunk of the operator's [B][9] block)."""
+        if opt is None:
+            return None
+        full = self.operator.phi
+        if phi.data_ptr() == full.data_ptr() and phi.shape[0] == full.shape[0]:
+            return opt
+        r0 = (phi.data_ptr() - full.data_ptr()) // (9 * 4)
+        return opt[r0:r0 + phi.shape[0]]
 
     def aux_values(self):
         """{'avrg_loss': [B], 'val_loss': [B]} from the last reduction (device tensors, no sync)."""

@@ -315,7 +315,8 @@ class GaussianDiffusion:
         for i, t in enumerate(tiles):
             r, c = divmod(i, ncol)
             grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + c * (w + pad): pad + c * (w + pad) + w] = t
-        arr = (grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy()
+        # the reference writes this grid through tvtf.to_pil_image (:330-333), which TRUNCATES: pic.mul(255).byte()
+        arr = grid.clamp(0, 1).mul(255).permute(1, 2, 0).to(torch.uint8).numpy()
         path = os.path.join(save_grids_path, f"{original_file_name}_process.png")
         Image.fromarray(arr).save(path)
         return path

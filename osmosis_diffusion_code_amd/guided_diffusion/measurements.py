@@ -7,7 +7,8 @@ Reference semantics kept:
     per image) and sets `operator.__name__ = name`; unknown / duplicate names raise NameError.
   * phi values arrive as strings ("1.1,0.95,0.95"), etas as strings or floats ("1e-5"),
     `phi_*_learn_flag=False` freezes a variable (eta 0)            (measurements.py:213-249)
-  * plain SGD `phi <- phi - eta * dL/dphi` (`optimizer: sgd`, or the 'GD' branch: same math)
+  * plain SGD `phi <- phi - eta * dL/dphi` (`optimizer: sgd`, or the 'GD' branch: same math), or `optimizer: adam`
+    (torch.optim.Adam defaults, lr = eta per parameter group, state per operator instance = per image): both on device
     (measurements.py:266-303).  Other torch optimisers are not part of the HIP path.
 
 Device state: `phi` is ONE fp32 device tensor [B][9] = phi_a[3] | phi_b[3] | phi_inf[3]
@@ -104,10 +105,10 @@ def _vec(s, n=3):
 
 def _check_optimizer(name):
     n = (name or "").lower()
-    if n in ("", "gd", "sgd"):
+    if n in ("", "gd", "sgd", "adam"):
         return n
-    if n in ("adam", "rmsprop", "adagrad", "adadelta", "adamw", "sparseadam", "adamax", "asgd", "lbfgs", "rprop"):
-        raise NotImplementedError(f"optimizer '{name}' is not available on the HIP path (plain SGD/GD only)")
+    if n in ("rmsprop", "adagrad", "adadelta", "adamw", "sparseadam", "adamax", "asgd", "lbfgs", "rprop"):
+        raise NotImplementedError(f"optimizer '{name}' is not available on the HIP path (GD, SGD and Adam only)")
     raise ValueError(f"Optimizer '{name}' is not supported.")
 
 

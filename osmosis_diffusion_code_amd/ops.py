@@ -350,9 +350,9 @@ def phys_reduce(desc: PhysDesc, x0, y, phi, part):
     call("osm_phys_reduce", C.byref(desc), ptr(x0), ptr(y), ptr(phi), ptr(part), _s(), keep=(desc, x0, y, phi, part))
 
 
-def phys_finalize(desc: PhysDesc, part, red, phi, do_update, loss_out):
-    call("osm_phys_finalize", C.byref(desc), ptr(part), ptr(red), ptr(phi), int(do_update), ptr(loss_out), _s(),
-         keep=(desc, part, red, phi, loss_out))
+def phys_finalize(desc: PhysDesc, part, red, phi, do_update, loss_out, opt_state=None):
+    call("osm_phys_finalize", C.byref(desc), ptr(part), ptr(red), ptr(phi), int(do_update), ptr(loss_out), ptr(opt_state), _s(),
+         keep=(part, red, phi, loss_out, opt_state))
 
 
 def phys_grad(desc: PhysDesc, x0, y, phi, red, g):

@@ -86,7 +86,7 @@ def depth_color(post):
 
 
 def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, same_seed_per_image=False,
-                  **loop_kwargs):
+                  postprocess_batch=True, **loop_kwargs):
     """One image through the reference's per-image sequence: fresh operator / noiser / conditioning method /
     sampler (:142-155), y = noiser(ref) (+ degamma), manual_seed + x_T ~ N(0, I) per global iteration
     (:191-196), guided p_sample_loop, post-processing.  Returns a list with one dict per global iteration.
@@ -94,7 +94,8 @@ def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, sa
     `ref_img` may carry B > 1 images: one batch of independent chains.  With `same_seed_per_image` every image of
     the batch starts from the SAME x_T and receives the SAME per-step noise -- exactly what B separate calls (each
     re-seeded with `manual_seed`, as the reference driver does per image) would draw -- so an image's result does not
-    depend on how images are grouped into batches or spread over ranks."""
+    depend on how images are grouped into batches or spread over ranks.  `postprocess_batch=False` skips the
+    reference's image-0-only post-processing (a caller that post-processes every image of the batch itself)."""
     device = device if device is not None else ref_img.device
     measure, cond_cfg = cfg["measurement"], cfg["conditioning"]
     op_cfg = dict(measure["operator"])
@@ -140,7 +141,11 @@ def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, sa
                             "measurement": y_n.detach().cpu()})
             continue
         sample, variable_dict, loss, out_xstart = ret
-        post = postprocess(out_xstart, variable_dict, ref_img, measure["operator"], loss)
+        if postprocess_batch:
+            post = postprocess(out_xstart, variable_dict, ref_img, measure["operator"], loss)
+        else:
+            post = dict(phi={k: v.detach().cpu() for k, v in variable_dict.items()},
+                        loss=None if loss is None else np.asarray(loss))
         post.update(sample=sample.detach().cpu(), pred_xstart=out_xstart, measurement=y_n.detach().cpu())
         results.append(post)
     return results
@@ -172,7 +177,7 @@ def restore_images(model, images, cfg, rank=0, world=1, device=None, gt_rgb=None
         else:
             ref = torch.cat([images[i] for i in idxs], 0)
             full = restore_image(model, ref, cfg, device=device, image_idx=idxs[0], same_seed_per_image=True,
-                                 **loop_kwargs)[-1]
+                                 postprocess_batch=False, **loop_kwargs)[-1]
             if "pred_xstart" in full:
                 res = postprocess_each(full["pred_xstart"], full["phi"], ref, cfg["measurement"]["operator"], full["loss"])
                 for b, r in enumerate(res):

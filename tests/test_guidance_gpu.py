@@ -93,6 +93,54 @@ def test_physics_loss_grad_and_phi_sgd(mods, opname, loss_function):
     assert float((gx0.cpu() - ref_g).abs().max()) < 2e-5 * scale + 1e-9
 
 
+@pytest.mark.parametrize("opname", list(OPS))
+def test_physics_phi_adam(mods, opname):
+    """`optimizer: adam` (utils.py:494-499 -> torch.optim.Adam with its defaults, one parameter group per phi with lr = eta,
+    measurements.py:132-136): 20 inner iterations on device vs torch.optim.Adam stepping the oracle's parameters, twice in a
+    row (the optimizer state -- moments and step count -- carries over from one guided step to the next)."""
+    ops, M, CM = mods
+    okw, ckw = OPS[opname]
+    H = W = 24
+    g = torch.Generator().manual_seed(12)
+    x0 = 0.6 * torch.randn(1, 4, H, W, generator=g)       # B = 1: the reference's norm loss is joint over a batch (SURVEY F1)
+    y = torch.rand(1, 3, H, W, generator=g) * 1.6 - 0.8
+    eta = {"phi_a": 2e-3, "phi_b": 1e-3, "phi_ab": 2e-3, "phi_inf": 5e-4}
+    op = D.PhysOperator(opname, batch_size=1, **{**okw, **{k + "_eta": v for k, v in eta.items()}})
+    guide = D.OsmosisGuidance(op, n_iter=20, loss_function="norm", **ckw)
+    op.set_requires_grad(True)
+    opt = torch.optim.Adam([{"params": op.phi[n], "lr": eta[n]} for n in op.names])
+    oper = M.get_operator(opname, device=DEV, batch_size=1,
+                          **{**okw, **{k + "_eta": v for k, v in eta.items() if k == "phi_inf" or k in okw}}, optimizer="adam")
+    cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), loss_function="norm",
+                                      loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                                      scale=ckw["scale"], gradient_x_prev=True, gradient_clip=ckw["gradient_clip"],
+                                      n_iter=20, aux_loss=ckw["aux"], pattern="pcgs")
+    for rnd in range(2):
+        xr = (x0 * (1.0 - 0.1 * rnd)).requires_grad_(True)
+        for it in range(20):
+            sep, loss = guide.loss(xr, y)
+            total = loss + D.aux_loss(xr, guide.aux)
+            opt.zero_grad()
+            total.backward(inputs=([xr] if it == 19 else []) + list(op.phi.values()))
+            opt.step()
+        gx0, sep_loss = cond.loss_grad_x0(xr.detach().to(DEV), y.to(DEV), freeze_phi=False)
+        assert np.allclose(sep_loss.cpu().numpy(), sep, rtol=2e-5), (rnd, sep_loss, sep)
+        for n, v in oper.variables().items():
+            assert torch.allclose(v.cpu(), op.phi[n].detach(), atol=5e-6), (rnd, n, v.cpu().flatten(), op.phi[n].flatten())
+        scale = float(xr.grad.abs().max())
+        assert float((gx0.cpu() - xr.grad).abs().max()) < 2e-5 * scale + 1e-9
+    assert float((oper.variables()["phi_inf"].cpu() - torch.tensor([float(u) for u in okw["phi_inf"].split(",")])[None, :, None, None]).abs().max()) > 5e-3
+
+
+def test_unsupported_optimizers_are_refused(mods):
+    ops, M, CM = mods
+    okw, _ = OPS["haze_physical"]
+    with pytest.raises(NotImplementedError):
+        M.get_operator("haze_physical", device=DEV, batch_size=1, **okw, optimizer="rmsprop")
+    with pytest.raises(ValueError):
+        M.get_operator("haze_physical", device=DEV, batch_size=1, **okw, optimizer="nonsense")
+
+
 def test_guide_update_kernel(mods):
     ops, _, _ = mods
     g = torch.Generator().manual_seed(4)
