@@ -280,7 +280,8 @@ def test_process_grid_layout(tmp_path):
     im = np.asarray(Image.open(path))
     assert im.shape == (2 * (16 + 2) + 2, 3 * (12 + 2) + 2, 3)
     assert (im[:2] == 0).all() and (im[:, :2] == 0).all()          # padding
-    want = (torch.clamp(0.5 * (recs[1][1][0, 0:3] + 1), 0, 1).mul(255).add(0.5).clamp(0, 255)).to(torch.uint8)
+    # tvtf.to_pil_image (the reference's writer, gaussian_diffusion.py:332) truncates: pic.mul(255).byte()
+    want = torch.clamp(0.5 * (recs[1][1][0, 0:3] + 1), 0, 1).mul(255).to(torch.uint8)
     assert np.array_equal(im[2:18, 2 + 14:2 + 14 + 12], want.permute(1, 2, 0).numpy())
     assert GaussianDiffusion._save_process_grid(recs, None, "x") is None
 
