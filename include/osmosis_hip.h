@@ -179,11 +179,14 @@ int osm_gn_stats(const float* x, long long ldx, int B, int HW, int C, int G, flo
                  float* part, float* stats, void* stream);
 int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,
-                 long long ldfilm, int silu, void* stream);
+                 long long ldfilm, int silu, float* maxabs_out, void* stream);
+/* maxabs_out (here and in osm_gn_fwd / osm_gn_bwd / osm_gn_bwd_apply; NULL = off): the pass that writes the output also
+ * leaves its per-image partial max |out| in the osm_maxabs format [B][OSM_MAXABS_PARTS] -- the f16x3 convolution that reads
+ * the tensor next then needs no osm_maxabs pass.  Requires osm_gn_nchunk(HW) <= OSM_MAXABS_PARTS. */
 /* stats + apply in one call (one launch for HW <= 256); `stats` is written (kept for the backward). */
 int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
                float* part, float* stats, const float* gamma, const float* beta, const float* film,
-               long long ldfilm, int silu, void* stream);
+               long long ldfilm, int silu, float* maxabs_out, void* stream);
 /* Statistics only + the per-channel table a convolution applies itself (osm_conv_desc.gn_table):
  * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
@@ -199,13 +202,13 @@ int osm_gn_finalize_cols(const float* colsum, int nchunk, int B, int HW, int C, 
 int osm_gn_bwd_apply(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                      const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                      const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
-                     long long ldfilm, int silu, void* stream);
+                     long long ldfilm, int silu, float* maxabs_out, void* stream);
 /* dx = dGN(dy) (+ addend) (+ addend2).  part: workspace as above.  An addend may alias dx (in-place accumulation: the
  * residual / concat gradients of the UNet are added here instead of in a pass of their own). */
 int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                const float* stats, const float* gamma, const float* beta, const float* film,
-               long long ldfilm, int silu, float* part, float* gstats, void* stream);
+               long long ldfilm, int silu, float* part, float* gstats, float* maxabs_out, void* stream);
 
 /* ------------------------------------------------------------------ resampling (unet.py:186, 215)
  * y[B][H/2][W/2][C] = scale * sum_{2x2} x   (avg-pool: scale=0.25; upsample-backward: scale=1)
@@ -236,7 +239,7 @@ int osm_nhwc_to_nchw(const float* x, long long ldx, float* y, int B, int C, int 
  * out[B][OSM_MAXABS_PARTS], every entry rewritten on every call (no clearing, no atomics); the consumer folds them.  Feeds
  * osm_conv_desc::x_maxabs.  No reference counterpart: the f16x3 arithmetic needs the operand range (nn.py:22-32 conv_nd
  * has fp32's exponent range). */
-#define OSM_MAXABS_PARTS 512
+#define OSM_MAXABS_PARTS 1024
 int osm_maxabs_parts(void);
 int osm_maxabs(const float* x, long long ldx, int B, long long rows_per_img, int C, float* out, void* stream);
 int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long M, int C,
@@ -337,21 +340,21 @@ int osm_gn_stats_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int
                    float* part, float* stats, void* stream);
 int osm_gn_apply_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G,
                    const float* stats, const float* gamma, const float* beta, const float* film,
-                   long long ldfilm, int silu, void* stream);
+                   long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
 int osm_gn_fwd_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G, float eps,
                  float* part, float* stats, const float* gamma, const float* beta, const float* film,
-                 long long ldfilm, int silu, void* stream);
+                 long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
 int osm_gn_prep_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
                   const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
                   void* stream);
 int osm_gn_bwd_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
                  const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,
-                 long long ldfilm, int silu, float* part, float* gstats, void* stream);
+                 long long ldfilm, int silu, float* part, float* gstats, float* maxabs_out /* must be NULL */, void* stream);
 int osm_gn_bwd_apply_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
                        const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                        const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
-                       long long ldfilm, int silu, void* stream);
+                       long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
 int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,

@@ -78,7 +78,7 @@ _SIGS = {
     "osm_pack_conv_weight_winograd": [_P, _P, _P, _I, _I, _I, _P],
     "osm_conv_stat_chunks": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
     "osm_gn_finalize_cols": [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _LL, _P, _P],
-    "osm_gn_bwd_apply": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _P, _LL, _I, _P],
+    "osm_gn_bwd_apply": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _P, _LL, _I, _P, _P],
     "osm_attn_small_supported": [_I, _I],
     "osm_attn_flash_supported": [_I, _I],
     "osm_attn_flash_fwd": [C.POINTER(AttnDesc), _P, _P],
@@ -87,10 +87,10 @@ _SIGS = {
     "osm_attn_small_bwd": [C.POINTER(AttnDesc), _P],
     "osm_gn_nchunk": [_I],
     "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
-    "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P],
-    "osm_gn_fwd": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _I, _P],
+    "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P],
+    "osm_gn_fwd": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _I, _P, _P],
     "osm_gn_prep": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _P, _P],
-    "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P],
+    "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
     "osm_pool2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_upsample2x": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_softmax_rows": [_P, _P, _P, _I, _I, _P],

@@ -111,10 +111,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
   const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
 
-  // HP: x 2^ex brings the largest |x| of the image (512 partial maxima from osm_maxabs, as bit patterns) to [2^11, 2^12)
+  // HP: x 2^ex brings the largest |x| of the image (OSM_MAXABS_PARTS partial maxima, as bit patterns) to [2^11, 2^12)
   float xscale = 1.f, oscale = 1.f;
   if (HP) {
-    unsigned mb = reinterpret_cast<const unsigned*>(p.xmax)[img * OSM_MAXABS_PARTS + tid];
+    static_assert(OSM_MAXABS_PARTS == 1024, "two partial maxima per thread");
+    const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)img * OSM_MAXABS_PARTS;
+    unsigned mb = max(xm[tid], xm[tid + 512]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
     unsigned* red_u = reinterpret_cast<unsigned*>(smem);

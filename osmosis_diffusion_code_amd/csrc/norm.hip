@@ -40,6 +40,8 @@ struct GNArgs {
   act_t* out;
   float* part;
   float* fin;           // finalized statistics written by the one-launch kernel / the fused apply prologue
+  unsigned* maxabs;     // optional [B][OSM_MAXABS_PARTS] partial max |out| (bit patterns), the contract of osm_maxabs: the
+                        // f16x3 convolution that reads `out` next needs its range and this pass holds every value
   double n;             // elements per group
   int fuse;             // apply kernels: combine the chunk partials in the prologue (no finalize launch)
   long long ldx, lddy, ldo, ldadd, ldadd2, ldf;
@@ -52,6 +54,22 @@ __device__ __forceinline__ void gn_fwd_elem(float x, float mean, float rstd, flo
   xh = (x - mean) * rstd;
   z = xh * ga + be;
   if (film) z = z * (1.0f + sc) + sh;
+}
+
+// workgroup `wg` of `nwg` (<= OSM_MAXABS_PARTS) publishes its partial max |out| of image b: slot wg, and zeros in the slots no
+// workgroup owns (every slot is rewritten on every call: no clearing, no atomics).  Called by ALL threads of the workgroup.
+__device__ __forceinline__ void gn_publish_max(unsigned* __restrict__ maxabs, int b, int wg, int nwg, float m, unsigned nanbits) {
+  __shared__ unsigned wmax[4];
+  unsigned bits = __float_as_uint(m) | nanbits;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bits = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    unsigned* sl = maxabs + (long long)b * OSM_MAXABS_PARTS;
+    for (int s2 = wg; s2 < OSM_MAXABS_PARTS; s2 += nwg) sl[s2] = s2 == wg ? bits : 0u;
+  }
 }
 
 // MODE 0: sums of (x, x^2).   MODE 1: sums of (dxh, dxh*xh) for the backward.
@@ -336,14 +354,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
     }
     __syncthreads();
   }
-  if (tr >= rowT) return;
+  const bool live = tr < rowT;
   const int p0 = chunk * a.ppc;
   const int p1 = min(a.HW, p0 + a.ppc);
   const bool film = a.film != nullptr;
+  float omax = 0.f;
+  unsigned onan = 0u;
 #pragma unroll
   for (int j = 0; j < NJMAX; ++j) {
     const int v = tc + colT * j;
-    if (j >= nj || v >= vpr) break;
+    if (!live || j >= nj || v >= vpr) break;
     const int c = v * VEC;
     const int g = c / a.gs;
     const float mean = (MODE == 0 && a.fuse) ? sst[2 * g] : a.stats[(b * a.G + g) * 2];
@@ -398,6 +418,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
           if (ap || ap2) r += av[e];
           ov[e] = r;
         }
+        if (a.maxabs) {      // of the value as stored
+          const float sv = (float)(act_t)ov[e];
+          omax = fmaxf(omax, fabsf(sv));
+          if (sv != sv) onan = 0x7fc00000u;
+        }
       }
       osm::stv<VEC>(op, ov);
       xp += sx;
@@ -409,6 +434,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
       }
     }
   }
+  if (a.maxabs) gn_publish_max(a.maxabs, b, chunk, gridDim.x, omax, onan);
 }
 
 // Low-resolution tensors (HW <= 256: 8x8 and 16x16) are a few hundred KB: three launches (reduce, finalize,
@@ -499,13 +525,15 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
     bc[1] = o1;
   }
   __syncthreads();
-  if (!live || !a.out) return;
+  if (!a.out) return;
   const float q0 = bc[0], q1 = bc[1];
   if (MODE == 0) {
     mean = q0;
     rstd = q1;
   }
-  for (int p = tp; p < a.HW; p += ppi) {
+  float omax = 0.f;
+  unsigned onan = 0u;
+  for (int p = tp; live && p < a.HW; p += ppi) {
     const float4 t = osm::ld4(a.x + (row0 + p) * a.ldx + c);
     const float xv[4] = {t.x, t.y, t.z, t.w};
     float ov[4];
@@ -538,8 +566,17 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
         ov[e] = rstd * (dxh - q0 - xh * q1) + av[e];
       }
     }
+    if (a.maxabs) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = (float)(act_t)ov[e];
+        omax = fmaxf(omax, fabsf(sv));
+        if (sv != sv) onan = 0x7fc00000u;
+      }
+    }
     osm::st4(a.out + (row0 + p) * a.ldo + c, make_float4(ov[0], ov[1], ov[2], ov[3]));
   }
+  if (a.maxabs) gn_publish_max(a.maxabs, b, g, gridDim.x, omax, onan);
 }
 
 constexpr int GN_SMALL_HW = 256;   // measured: 32 x 32 tensors are faster on the chunked three-launch path
@@ -622,6 +659,15 @@ int run_small(GNArgs& a, float* finalized, hipStream_t st) {
 extern "C" int osm_gn_nchunk(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
 #endif
 static int gn_nchunk_of(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
+// maxabs_out of the apply entry points: [B][OSM_MAXABS_PARTS] partial max |out| (fp32 family; the grid must fit the slots)
+static int set_maxabs(GNArgs& a, float* maxabs_out, const char* who) {
+  if (!maxabs_out) return OSM_OK;
+  OSM_REQUIRE(!OSM_ACT_IS_F16, "%s: maxabs_out belongs to the fp32 family", who);
+  OSM_REQUIRE(gn_nchunk_of(a.HW) <= OSM_MAXABS_PARTS && a.G <= OSM_MAXABS_PARTS,
+              "%s: maxabs_out needs osm_gn_nchunk(HW) <= OSM_MAXABS_PARTS (use osm_maxabs)", who);
+  a.maxabs = reinterpret_cast<unsigned*>(maxabs_out);
+  return OSM_OK;
+}
 
 extern "C" int OSM_FN(osm_gn_stats)(const abi_act_t* x, long long ldx, int B, int HW, int C, int G, float eps,
                             float* part, float* stats, void* stream) {
@@ -652,7 +698,7 @@ extern "C" int OSM_FN(osm_gn_prep)(const abi_act_t* x, long long ldx, int B, int
 
 extern "C" int OSM_FN(osm_gn_apply)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C,
                             int G, const float* stats, const float* gamma, const float* beta,
-                            const float* film, long long ldfilm, int silu, void* stream) {
+                            const float* film, long long ldfilm, int silu, float* maxabs_out, void* stream) {
   OSM_REQUIRE(x && y && stats && gamma && beta, "osm_gn_apply: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_apply: ldfilm smaller than 2*C");
   GNArgs a{};
@@ -660,6 +706,7 @@ extern "C" int OSM_FN(osm_gn_apply)(const abi_act_t* x, long long ldx, abi_act_t
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_apply");
   if (rc) return rc;
+  if ((rc = set_maxabs(a, maxabs_out, "osm_gn_apply"))) return rc;
   return run_apply<0>(a, (hipStream_t)stream);
 }
 
@@ -687,7 +734,8 @@ extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const
                                         abi_act_t* dx, long long lddx, const abi_act_t* addend, long long ldadd,
                                         const abi_act_t* addend2, long long ldadd2, int B,
                                         int HW, int C, int G, const float* stats, const float* gstats, const float* gamma,
-                                        const float* beta, const float* film, long long ldfilm, int silu, void* stream) {
+                                        const float* beta, const float* film, long long ldfilm, int silu,
+                                        float* maxabs_out, void* stream) {
   OSM_REQUIRE(x && dy && dx && stats && gstats && gamma && beta, "osm_gn_bwd_apply: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd_apply: ldfilm smaller than 2*C");
   GNArgs a{};
@@ -698,6 +746,7 @@ extern "C" int OSM_FN(osm_gn_bwd_apply)(const abi_act_t* x, long long ldx, const
   a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_bwd_apply");
   if (rc) return rc;
+  if ((rc = set_maxabs(a, maxabs_out, "osm_gn_bwd_apply"))) return rc;
   a.fuse = 0;
   return run_apply<1>(a, (hipStream_t)stream);
 }
@@ -706,7 +755,7 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
                           long long lddx, const abi_act_t* addend, long long ldadd, const abi_act_t* addend2, long long ldadd2,
                           int B, int HW, int C, int G,
                           const float* stats, const float* gamma, const float* beta, const float* film,
-                          long long ldfilm, int silu, float* part, float* gstats, void* stream) {
+                          long long ldfilm, int silu, float* part, float* gstats, float* maxabs_out, void* stream) {
   OSM_REQUIRE(x && dy && dx && stats && gamma && beta && part && gstats, "osm_gn_bwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd: ldfilm smaller than 2*C");
   GNArgs a{};
@@ -716,6 +765,7 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
   a.film = film; a.ldf = ldfilm; a.silu = silu; a.part = part;
   int rc = check_common(a, "osm_gn_bwd");
   if (rc) return rc;
+  if ((rc = set_maxabs(a, maxabs_out, "osm_gn_bwd"))) return rc;
   if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = gstats;
@@ -726,7 +776,7 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
 
 extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C, int G,
                           float eps, float* part, float* stats, const float* gamma, const float* beta,
-                          const float* film, long long ldfilm, int silu, void* stream) {
+                          const float* film, long long ldfilm, int silu, float* maxabs_out, void* stream) {
   OSM_REQUIRE(x && y && part && stats && gamma && beta, "osm_gn_fwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_fwd: ldfilm smaller than 2*C");
   GNArgs a{};
@@ -734,6 +784,7 @@ extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* 
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
   int rc = check_common(a, "osm_gn_fwd");
   if (rc) return rc;
+  if ((rc = set_maxabs(a, maxabs_out, "osm_gn_fwd"))) return rc;
   if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = stats;

@@ -299,11 +299,13 @@ class UNetEngine:
         return t[:n]
 
     def _conv(self, x: Mat, cv: _Conv, y: Mat, hw: Tuple[int, int], dgrad=False, res: Optional[Mat] = None,
-              accumulate=False, gn_table=None, gn_silu=True, stat=None, ws_slot="splitk"):
+              accumulate=False, gn_table=None, gn_silu=True, stat=None, ws_slot="splitk", xmax=None):
         """stat: None, ("fwd",) -- also emit the per-column (sum, sum of squares) of y for the GroupNorm that reads it --
         or ("bwd", x_gn, table) -- y is the gradient w.r.t. SiLU(GN(x_gn)): emit that GroupNorm's two backward
         reductions.  Returns (colsum, chunks per image) when the layer's kernel produced them, else None (the caller
-        then runs the GroupNorm's own reduction pass)."""
+        then runs the GroupNorm's own reduction pass).
+        xmax: [B][MAXABS_PARTS] partial max |x| the PRODUCER of x left behind (a bound is enough: the pooled / upsampled copy
+        of a tensor may use the tensor's); None: an f16x3 layer runs ops.maxabs over x itself."""
         H, W = hw
         M = self.B * H * W
         cin = cv.cout if dgrad else cv.cin
@@ -315,8 +317,10 @@ class UNetEngine:
                 ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt):
             wfmt, wimg = cv.wwfmt | ops.WINOGRAD, (cv.wwd if dgrad else cv.wwf)
             if cv.wwfmt == 4:       # f16x3: the kernel scales its input into the fp16 range from the per-image max |x|
-                xm = self._xmax_slot(ws_slot)
-                ops.maxabs(x, self.B, xm)
+                xm = xmax
+                if xm is None:
+                    xm = self._xmax_slot(ws_slot)
+                    ops.maxabs(x, self.B, xm)
         sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, wfmt, gn_table is not None)
         ws = None
         if sk > 1:
@@ -341,8 +345,17 @@ class UNetEngine:
             bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
 
     def _xmax_slot(self, key: str) -> torch.Tensor:
-        """[B][MAXABS_PARTS] partial max |x| of an f16x3 convolution's input (every entry is rewritten by ops.maxabs)."""
+        """[B][MAXABS_PARTS] partial max |x| of an f16x3 convolution's input (every entry is rewritten by its producer)."""
         return self._scr_flat("xmax/" + key, self.B * ops.MAXABS_PARTS)
+
+    def _xmax_from_gn(self, cv: _Conv, hw_conv, hw_gn, key: str, dgrad=False):
+        """The slot a GroupNorm pass should fill with max |output| because the f16x3 convolution `cv` (at resolution hw_conv)
+        reads that output next; None when the layer is not f16x3 or the GroupNorm grid does not fit the slots."""
+        if cv.wwfmt != 4 or not self._is_wino(cv, hw_conv, dgrad=dgrad):
+            return None
+        if ops.gn_nchunk(hw_gn[0] * hw_gn[1]) > ops.MAXABS_PARTS:
+            return None
+        return self._xmax_slot(key)
 
     def _gn_fusable(self, cv: _Conv, hw) -> bool:
         """GroupNorm apply inside the consuming 3x3 convolution: needs the halo-tile kernel (split-bf16 / fp16 weights,
@@ -383,12 +396,13 @@ class UNetEngine:
                 ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
             return self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True, stat=stat)
         a = self._scr("a", B * H * W, x.cols)
+        xm = self._xmax_from_gn(cv, hw, hw, "gn")
         if cs is not None:      # statistics from the producer's column sums, then the apply pass alone
             ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
-            ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True)
+            ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
         else:
-            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True)
-        return self._conv(a, cv, y, hw, res=res, stat=stat)
+            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
+        return self._conv(a, cv, y, hw, res=res, stat=stat, xmax=xm)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):
@@ -399,7 +413,9 @@ class UNetEngine:
         st1 = self._small(B * G * 2)
         if blk.up or blk.down:
             a1 = self._scr("a", M, blk.cin)
-            ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True)
+            hwo = (2 * H, 2 * W) if blk.up else (H // 2, W // 2)
+            xm1 = self._xmax_from_gn(blk.c1, hwo, hw, "gn")      # max |pool(a)|, max |upsample(a)| <= max |a|
+            ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True, maxabs=xm1)
             if blk.up:
                 ho, wo = 2 * H, 2 * W
                 a1r = self._scr("b", B * ho * wo, blk.cin)
@@ -416,7 +432,8 @@ class UNetEngine:
             h1 = self._buf(Mo, blk.cout)
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
             tab1 = None
-            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None)
+            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None,
+                             xmax=xm1)
         else:
             ho, wo = H, W
             xs = x
@@ -457,16 +474,17 @@ class UNetEngine:
                         stat=("bwd", s["h1"], s["tab2"]) if s["tab2"] is not None else None)
         dh1 = self._scr("b", Mo, blk.cout)
         gst = self._small(B * G * 2)
+        xmh = self._xmax_from_gn(blk.c1, (ho, wo), (ho, wo), "gnb", dgrad=True)
         if cs is not None:
             ops.gn_finalize_cols(cs[0], cs[1], B, ho * wo, blk.cout, G, gst, mode=1)
             ops.gn_bwd_apply(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], gst, blk.n2.g, blk.n2.b, film=s["film"],
-                             silu=True)
+                             silu=True, maxabs=xmh)
         else:
             ops.gn_bwd(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], blk.n2.g, blk.n2.b, self.gn_part, gst,
-                       film=s["film"], silu=True)
+                       film=s["film"], silu=True, maxabs=xmh)
         da1r = self._scr("a", Mo, blk.cin)
         cs1 = self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True,
-                         stat=("bwd", s["x"], s["tab1"]) if s["tab1"] is not None else None)
+                         stat=("bwd", s["x"], s["tab1"]) if s["tab1"] is not None else None, xmax=xmh)
         if blk.up:      # forward: nearest 2x upsample  -> backward: 2x2 sum
             da1 = self._scr("b", M, blk.cin)
             ops.pool2x2(da1r, da1, B, ho, wo, 1.0)

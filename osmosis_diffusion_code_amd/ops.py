@@ -85,7 +85,7 @@ def conv2d(x: Mat, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Mat,
                stat_x.t if stat_x is not None else None, stat_table, x_maxabs))
 
 
-MAXABS_PARTS = 512     # OSM_MAXABS_PARTS
+MAXABS_PARTS = 1024    # OSM_MAXABS_PARTS
 
 
 def maxabs(x: Mat, B: int, out: torch.Tensor):
@@ -228,13 +228,15 @@ def gn_finalize_cols(colsum, nchunk, B, HW, C, G, stats, mode=0, gamma=None, bet
 
 
 def gn_bwd_apply(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gstats, gamma, beta, film=None, silu=True,
-                 addend: Optional[Mat] = None, addend2: Optional[Mat] = None):
+                 addend: Optional[Mat] = None, addend2: Optional[Mat] = None, maxabs: Optional[torch.Tensor] = None):
+    """maxabs (here and in gn_apply / gn_fwd / gn_bwd): [B][MAXABS_PARTS] -- the pass also leaves the per-image partial max of
+    |output| there (the ops.maxabs format), for the f16x3 convolution that reads the output next."""
     fp, ldf = _film(film)
     fam = _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None, addend2.t if addend2 is not None else None)
     call("osm_gn_bwd_apply" + fam, x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, *_addends(addend, addend2),
-         B, HW, x.cols, G, ptr(stats), ptr(gstats), ptr(gamma), ptr(beta), fp, ldf, int(silu), _s(),
+         B, HW, x.cols, G, ptr(stats), ptr(gstats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(maxabs), _s(),
          keep=(x.t, dy.t, dx.t, addend.t if addend else None, addend2.t if addend2 else None, stats, gstats, gamma, beta,
-               film))
+               film, maxabs))
 
 
 def gn_nchunk(HW: int) -> int:
@@ -252,17 +254,18 @@ def _film(film):
     return ptr(film), (film.stride(0) if film.shape[0] > 1 else film.shape[1])
 
 
-def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=None, silu=True):
+def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=None, silu=True, maxabs=None):
     fp, ldf = _film(film)
     call("osm_gn_apply" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
-         int(silu), _s(), keep=(x.t, y.t, stats, gamma, beta, film))
+         int(silu), ptr(maxabs), _s(), keep=(x.t, y.t, stats, gamma, beta, film, maxabs))
 
 
-def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, film=None, silu=True, eps: float = 1e-5):
+def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, film=None, silu=True, eps: float = 1e-5,
+           maxabs=None):
     """statistics (written to `stats`) + normalise/FiLM/SiLU; a single launch for HW <= 1024."""
     fp, ldf = _film(film)
     call("osm_gn_fwd" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
-         fp, ldf, int(silu), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film))
+         fp, ldf, int(silu), ptr(maxabs), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film, maxabs))
 
 
 def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5):
@@ -279,14 +282,14 @@ def _addends(addend, addend2):
 
 
 def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, part, gstats,
-           film=None, silu=True, addend: Optional[Mat] = None, addend2: Optional[Mat] = None):
+           film=None, silu=True, addend: Optional[Mat] = None, addend2: Optional[Mat] = None, maxabs=None):
     """dx = dGN(dy) (+ addend) (+ addend2); an addend may be dx itself (accumulate in place)."""
     fp, ldf = _film(film)
     fam = _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None, addend2.t if addend2 is not None else None)
     call("osm_gn_bwd" + fam, x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, *_addends(addend, addend2),
-         B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(part), ptr(gstats), _s(),
+         B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(part), ptr(gstats), ptr(maxabs), _s(),
          keep=(x.t, dy.t, dx.t, addend.t if addend else None, addend2.t if addend2 else None, stats, gamma, beta, film,
-               part, gstats))
+               part, gstats, maxabs))
 
 
 def pool2x2(x: Mat, y: Mat, B, H, W, scale=0.25):

@@ -187,6 +187,29 @@ def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
     got3 = acc3.cpu().reshape(B, HW, C).permute(0, 2, 1)
     assert float((got3 - (dxr - add + add2)).abs().max()) < 5e-5 * max(1.0, float(dxr.abs().max()))
 
+    # maxabs side output (round 3): every pass that writes a tensor can leave the per-image partial max |output| in the
+    # ops.maxabs format (the f16x3 convolution that reads the tensor next needs its range): exact, every slot rewritten
+    P = ops.MAXABS_PARTS
+
+    def check(parts, out):
+        got_m = parts.view(B, P).max(1).values
+        assert torch.equal(got_m, out.abs().view(B, HW * C).amax(1)), (got_m, out.abs().view(B, HW * C).amax(1))
+
+    for fn in ("apply", "fwd", "bwd", "bwd_apply"):
+        parts = torch.full((B * P,), float("nan"), device=DEV)
+        o = torch.empty(B * HW, C, device=DEV)
+        if fn == "apply":
+            ops.gn_apply(xm, ops.Mat.of(o), B, HW, G, stats, gd, bd, film=ed, silu=silu, maxabs=parts)
+        elif fn == "fwd":
+            ops.gn_fwd(xm, ops.Mat.of(o), B, HW, G, part, stats2, gd, bd, film=ed, silu=silu, maxabs=parts)
+        elif fn == "bwd":
+            ops.gn_bwd(xm, ops.Mat.of(nhwc(dy)), ops.Mat.of(o), B, HW, G, stats, gd, bd, part, gstats, film=ed, silu=silu,
+                       addend=ops.Mat.of(nhwc(add)), maxabs=parts)
+        else:
+            ops.gn_bwd_apply(xm, ops.Mat.of(nhwc(dy)), ops.Mat.of(o), B, HW, G, stats, gstats, gd, bd, film=ed, silu=silu,
+                             addend=ops.Mat.of(nhwc(add)), maxabs=parts)
+        check(parts, o)
+
 
 def test_pool_upsample(ops):
     g = torch.Generator().manual_seed(5)
