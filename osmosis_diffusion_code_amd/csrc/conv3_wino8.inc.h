@@ -23,6 +23,9 @@
                         // 4 no epilogue, 8 no LDS reads in the V build, 16 no split, 32 MFMAs replaced by one VALU op each,
                         // 64 activation loads re-read slab 0 (cache hits), 128 U loads re-read one 6 KB piece (cache hits)
 #endif
+#ifndef W8_TSHARE
+#define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
+#endif
 #ifndef W8_LATE
 #define W8_LATE 0
 #endif
@@ -131,12 +134,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
     oscale = ldexpf(1.f, -ex) / p.wscale[0];
   }
+  float mscale[W8_NJ];
+#pragma unroll
+  for (int j = 0; j < W8_NJ; ++j) mscale[j] = ((vmask >> j) & 1u) ? xscale : 0.f;
   float4 ra[W8_NJ];
   float4 gm, gs, gb;        // fused GroupNorm: mean | rstd * gamma | beta of this thread's channel quad
   gm = gs = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
   uint4 uq[2][2][NP];       // [local xi][column tile][plane]
   uint4 va[2][NP];          // A fragments, [unit parity][plane]
+  float4 ts[2][2];          // the t column both xi of this wave use, [tile block][channel quad] (W8_TSHARE)
 
 #define OSM_W8_LOAD_RAW(cc_, j_)                                                           \
   {                                                                                        \
@@ -169,7 +176,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
         v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w); \
       }                                                                                    \
     }                                                                                      \
-    if (HP) { v.x *= xscale; v.y *= xscale; v.z *= xscale; v.w *= xscale; }                \
+    if (HP) {   /* the scale doubles as the padding mask (0 outside the image); channels past K meet zero weights */ \
+      v.x *= mscale[j_]; v.y *= mscale[j_]; v.z *= mscale[j_]; v.w *= mscale[j_];          \
+      raw[((cc_) & 1) * (4 * WN_QP) + woff[j_]] = v;                                       \
+    } else                                                                                 \
     raw[((cc_) & 1) * (4 * WN_QP) + woff[j_]] = sel4((okm_ >> (j_)) & 1u, v);             \
   }
 #define OSM_W8_LOAD_U(cc_, jj_)                                                            \
@@ -183,21 +193,32 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
                   ursrc, (int)u_lane, (int)(so_ + (unsigned)q2 * u_plane + (unsigned)b * u_nt), 0)); \
   }
 // A fragments of unit (local xi jj_, tile block tb_) from the raw slab at slot offset bo_: V = t[ca] + sb t[cb],
-// t[c] = x[c] + sg y[c] (column c of the tile = parity c & 1, slot txl + (c >> 1)), split into NP planes
-#define OSM_W8_BUILD(par_, ca_, cb_, sb_, tb_, bo_)                                        \
+// t[c] = x[c] + sg y[c] (column c of the tile = parity c & 1, slot txl + (c >> 1)), split into NP planes.
+// The two xi of a wave share one t column (h = 0: t2, h = 1: t1): the FIRST build of a tile block (local xi 0, where the
+// shared column is the `cb` operand) keeps it in ts[tb], the second takes it from there -- keep_ 1: save t[cb] to ts[tb_];
+// use_ 1: t[cb] comes from ts[tb_], 2: t[ca] comes from ts[tb_] (no LDS reads / FMAs for that column).
+#define OSM_W8_BUILD(par_, ca_, cb_, sb_, tb_, bo_, keep_, use_)                           \
   {                                                                                        \
     uint2 vh_[2][NP];                                                                      \
     _Pragma("unroll") for (int hq = 0; hq < 2; ++hq) {                                     \
       const int oa_ = (bo_) + hq * WN_QP + 8 * (tb_) * WN_ROWP + ((ca_) & 1) * 10 + ((ca_) >> 1); \
       const int ob_ = (bo_) + hq * WN_QP + 8 * (tb_) * WN_ROWP + ((cb_) & 1) * 10 + ((cb_) >> 1); \
-      osm::floatx4_t xa_, ya_, xb_, yb_;                                                   \
-      if (W8_ABL & 8) { xa_ = ya_ = xb_ = yb_ = osm::floatx4_t{(float)oa_, sg, (float)ob_, 1.f}; } \
-      else { xa_ = t_x[oa_]; ya_ = t_y[oa_]; xb_ = t_x[ob_]; yb_ = t_y[ob_]; }            \
-      float4 v_;                                                                           \
-      v_.x = fmaf(sg, ya_[0], xa_[0]) + (sb_) * fmaf(sg, yb_[0], xb_[0]);                  \
-      v_.y = fmaf(sg, ya_[1], xa_[1]) + (sb_) * fmaf(sg, yb_[1], xb_[1]);                  \
-      v_.z = fmaf(sg, ya_[2], xa_[2]) + (sb_) * fmaf(sg, yb_[2], xb_[2]);                  \
-      v_.w = fmaf(sg, ya_[3], xa_[3]) + (sb_) * fmaf(sg, yb_[3], xb_[3]);                  \
+      float4 ta_, tb2_;                                                                    \
+      if (W8_ABL & 8) { ta_ = tb2_ = make_float4((float)oa_, sg, (float)ob_, 1.f); }       \
+      else {                                                                               \
+        if ((use_) == 2) ta_ = ts[tb_][hq];                                                \
+        else {                                                                             \
+          const osm::floatx4_t xa_ = t_x[oa_], ya_ = t_y[oa_];                             \
+          ta_ = make_float4(fmaf(sg, ya_[0], xa_[0]), fmaf(sg, ya_[1], xa_[1]), fmaf(sg, ya_[2], xa_[2]), fmaf(sg, ya_[3], xa_[3])); \
+        }                                                                                  \
+        if ((use_) == 1) tb2_ = ts[tb_][hq];                                               \
+        else {                                                                             \
+          const osm::floatx4_t xb_ = t_x[ob_], yb_ = t_y[ob_];                             \
+          tb2_ = make_float4(fmaf(sg, yb_[0], xb_[0]), fmaf(sg, yb_[1], xb_[1]), fmaf(sg, yb_[2], xb_[2]), fmaf(sg, yb_[3], xb_[3])); \
+        }                                                                                  \
+        if (keep_) ts[tb_][hq] = tb2_;                                                     \
+      }                                                                                    \
+      const float4 v_ = make_float4(ta_.x + (sb_) * tb2_.x, ta_.y + (sb_) * tb2_.y, ta_.z + (sb_) * tb2_.z, ta_.w + (sb_) * tb2_.w); \
       if (W8_ABL & 16) { _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                  \
           vh_[hq][q2] = make_uint2(__float_as_uint(v_.x) + q2, __float_as_uint(v_.y) ^ __float_as_uint(v_.z) ^ __float_as_uint(v_.w)); } \
       else if constexpr (HP) split_f16x2(v_, vh_[hq]);                                     \
@@ -226,6 +247,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     constexpr int CA0 = H ? 2 : 0, CB0 = H ? 1 : 2;
     constexpr int CA1 = 1, CB1 = H ? 3 : 2;
     constexpr float SB1 = H ? -1.f : 1.f;
+    // the shared t column (CB0) is operand b of the second xi for h = 0 (t1 + t2) and operand a for h = 1 (t1 - t3)
+    constexpr int USE1 = W8_TSHARE ? (H ? 2 : 1) : 0;
+    static_assert(CB0 == (H ? CA1 : CB1), "the shared column");
     const int k1 = min(kc0 + 1, kc1 - 1);
     OSM_W8_LOAD_RAW(kc0, 0) OSM_W8_LOAD_RAW(kc0, 1) OSM_W8_LOAD_RAW(kc0, 2)
     OSM_W8_LOAD_TAB(kc0)
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     OSM_W8_LOAD_RAW(k1, 0) OSM_W8_LOAD_RAW(k1, 1) OSM_W8_LOAD_RAW(k1, 2)
     OSM_W8_LOAD_TAB(k1)
     __syncthreads();
-    OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, (kc0 & 1) * (4 * WN_QP))
+    OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, (kc0 & 1) * (4 * WN_QP), W8_TSHARE, 0)
     OSM_W8_FENCE()
     for (int c = kc0; c < kc1; ++c) {
       const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
 #endif
-      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo)
+      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo, W8_TSHARE, 0)
       OSM_W8_MMA(0, 0, 0)
 #if W8_LATE
       __builtin_amdgcn_sched_barrier(0);
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
 #endif
-      OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo)
+      OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo, 0, USE1)
       OSM_W8_MMA(1, 0, 1)
 #if W8_LATE
       __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
 #endif
-      OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo)
+      OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo, 0, USE1)
       OSM_W8_MMA(0, 1, 0)
 #if W8_LATE
       __builtin_amdgcn_sched_barrier(0);
@@ -276,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       OSM_W8_FENCE()
       __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
       // unit 3 = (xi 1, block 1) | builds (xi 0, block 0) of slab c + 1
-      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn)
+      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, W8_TSHARE, 0)
       OSM_W8_MMA(1, 1, 1)
       OSM_W8_FENCE()
     }

@@ -10,10 +10,12 @@ own GRBM, hence the / 8), SQ_WAVE_CYCLES, SQ_BUSY_CU_CYCLES.  Derived per dispat
     gui_cycles      = GRBM_GUI_ACTIVE / 8
     mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x gui_cycles)
     clock_ghz       = gui_cycles / dispatch duration               (what the power manager grants under this load)
-    expected_mfma   = algorithmic flops x 6 / (2 x 32 x 32 x 16)   (bf16x6: six MFMAs per fp32 product group;
+    expected_mfma   = algorithmic flops x N / (2 x 32 x 32 x 16)   (N MFMAs per fp32 product group: 6 for bf16x6, 3 for f16x3;
                       x 16/36 for the Winograd F(2x2,3x3) kernel, which multiplies 16 instead of 36 times per tile)
     mfma_count_seen = SQ_VALU_MFMA_BUSY_CYCLES / 32                (sanity check against expected_mfma)
-Each shape is measured twice: the direct halo-tile kernel and (--winograd) the Winograd kernel the engine now uses.
+Each conv shape is measured three times: the direct halo-tile kernel (bf16x6), the Winograd kernel in bf16x6 and in f16x3 (the
+arithmetic the engine uses by default); then the three kernels of the flash-attention family at the three block shapes of the
+UNet (tools/attn_probe.py).
 """
 import csv
 import glob
@@ -25,45 +27,70 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = ["1,256,256,256,256,3", "1,128,128,512,512,3", "1,64,64,512,512,3"]
+ATTN = ["1,1024,8", "1,256,16", "1,64,16"]
 COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES"]
+# (label, conv_probe arguments, kernel-name substring, MFMAs per fp32 product, executed fraction of the algorithmic products)
+CONV_VARIANTS = [
+    ("conv3_halo_bf16s_kernel<3,*> (direct, bf16x6)", ["--mode", "bf16x6"], "conv3_halo", 6, 1.0),
+    ("conv3_wino8_kernel<3,*,false> (Winograd F(2x2,3x3), bf16x6)", ["--mode", "bf16x6", "--winograd"], "conv3_wino8", 6, 16.0 / 36.0),
+    ("conv3_wino8_kernel<2,*,true> (Winograd F(2x2,3x3), f16x3: the default)", ["--mode", "f16x3"], "conv3_wino8", 3, 16.0 / 36.0),
+]
+
+
+def collect(cmd_tail, substrs):
+    """One rocprofv3 --pmc run (counters only); per kernel-name substring: counter -> [sum, dispatches, total us]."""
+    d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc", *COUNTERS, "--output-format", "csv", "-d", d, "--", sys.executable] + cmd_tail
+    subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   timeout=400)
+    accs = {k: {} for k in substrs}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k in substrs:
+                if k in r["Kernel_Name"]:
+                    a = accs[k].setdefault(r["Counter_Name"], [0.0, 0, 0.0])
+                    a[0] += float(r["Counter_Value"])
+                    a[1] += 1
+                    a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    return accs
+
+
+def row(label, acc, flops, nmfma, exec_frac, extra):
+    if "GRBM_GUI_ACTIVE" not in acc:
+        return dict(extra, kernel=label, error="no counters collected")
+    avg = {k: v[0] / v[1] for k, v in acc.items()}
+    us = acc["GRBM_GUI_ACTIVE"][2] / acc["GRBM_GUI_ACTIVE"][1]
+    gui = avg["GRBM_GUI_ACTIVE"] / 8.0
+    out = dict(extra, kernel=label, dispatches=acc["GRBM_GUI_ACTIVE"][1], avg_us_under_pmc=round(us, 2),
+               counters_avg_per_dispatch={k: round(v, 1) for k, v in avg.items()},
+               mfma_busy_frac=round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui), 4), clock_ghz=round(gui / (us * 1e3), 3),
+               mfma_instructions_seen=round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 32))
+    if flops is not None:
+        out.update(expected_mfma_instructions=round(flops * exec_frac * nmfma / (2 * 32 * 32 * 16)),
+                   algorithmic_tflops_under_pmc=round(flops / us / 1e6, 1),
+                   roof_at_that_clock_tflops=round(2500.0 / nmfma * (gui / (us * 1e3)) / 2.4, 1))
+    return out
 
 
 def main():
     out_json = sys.argv[1]
     rows = []
-    for shape, wino in [(s, w) for s in SHAPES for w in (False, True)]:
-        d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp")
-        cmd = ["rocprofv3", "--pmc", *COUNTERS, "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(REPO, "tools", "conv_probe.py"), "--shape", shape, "--iters", "10"] + (["--winograd"] if wino else [])
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400)
-        acc = {}
-        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-            for r in csv.DictReader(open(f)):
-                if ("conv3_wino" if wino else "conv3_halo") not in r["Kernel_Name"]:
-                    continue
-                a = acc.setdefault(r["Counter_Name"], [0.0, 0, 0.0])
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
-                a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
-        if "GRBM_GUI_ACTIVE" not in acc:
-            rows.append({"shape": shape, "error": "no counters collected"})
-            continue
-        avg = {k: v[0] / v[1] for k, v in acc.items()}
-        us = acc["GRBM_GUI_ACTIVE"][2] / acc["GRBM_GUI_ACTIVE"][1]
+    probe = os.path.join(REPO, "tools", "conv_probe.py")
+    for shape in SHAPES:
         B, H, W, Cin, Cout, k = (int(v) for v in shape.split(","))
         flops = 2.0 * B * H * W * Cin * Cout * k * k
-        exec_frac = 16.0 / 36.0 if wino else 1.0
-        rows.append({
-            "shape_B,H,W,Cin,Cout,k": shape,
-            "kernel": "conv3_wino_kernel<3,*> (bf16x6, Winograd F(2x2,3x3))" if wino else "conv3_halo_bf16s_kernel<3,*> (bf16x6)", "dispatches": acc["GRBM_GUI_ACTIVE"][1],
-            "avg_us_under_pmc": round(us, 2), "counters_avg_per_dispatch": {k: round(v, 1) for k, v in avg.items()},
-            "mfma_busy_frac": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0), 4),
-            "clock_ghz": round(avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3), 3),
-            "bf16x6_roof_at_that_clock_tflops": round(2500.0 / 6.0 * (avg["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)) / 2.4, 1),
-            "expected_mfma_instructions": round(flops * exec_frac * 6 / (2 * 32 * 32 * 16)),
-            "mfma_instructions_seen": round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 32),
-            "algorithmic_tflops_under_pmc": round(flops / us / 1e6, 1)})
+        for label, args, sub, nmfma, ef in CONV_VARIANTS:
+            acc = collect([probe, "--shape", shape, "--iters", "10"] + args, [sub])[sub]
+            rows.append(row(label, acc, flops, nmfma, ef, {"shape_B,H,W,Cin,Cout,k": shape}))
+    # attention cores (VERDICT r02 item 8: a counter behind bench.py's attention_mfma_util): per kernel of the flash family
+    for shape in ATTN:
+        B, T, heads = (int(v) for v in shape.split(","))
+        subs = ["flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_kernel"]
+        accs = collect([os.path.join(REPO, "tools", "attn_probe.py"), "--shape", shape, "--iters", "10"], subs)
+        per = 2.0 * B * heads * T * T * 64
+        for sub, ngemm in (("flash_fwd_kernel", 2), ("flash_bwd_q_kernel", 3), ("flash_bwd_kv_kernel", 4)):
+            # forward: S, PV; bwd_q: S, dP, dq; bwd_kv: S, dP, dv, dk (S and dP are recomputed by both backward kernels)
+            rows.append(row(sub + " (bf16x6)", accs[sub], per * ngemm, 6, 1.0, {"shape_B,T,heads": shape, "gemms_executed": ngemm}))
     json.dump({"note": __doc__.split("Counters:")[1].strip(), "rows": rows}, open(out_json, "w"), indent=1)
     print(json.dumps(rows, indent=1))
 
