@@ -26,9 +26,6 @@
 #ifndef W8_TSHARE
 #define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
 #endif
-#ifndef W8_LATE
-#define W8_LATE 0
-#endif
 constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
 
 // HP ("f16x3", NP = 2): the two planes of V and of U are IEEE halfs of the operands scaled into the fp16 range -- V by
@@ -141,7 +138,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   float4 gm, gs, gb;        // fused GroupNorm: mean | rstd * gamma | beta of this thread's channel quad
   gm = gs = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
-  uint4 uq[2][2][NP];       // [local xi][column tile][plane]
+  // the shared t column costs 16 registers: the 3-plane arithmetic has none to spare (it would spill 16)
+  constexpr int TSH = (W8_TSHARE && (HP || NP < 3)) ? 1 : 0;
+  uint4 uq[2][2][NP];       // [local xi][column tile][plane]: loaded two units ahead into the registers the previous slab's
+                            // same xi released (a second slab-deep set was measured: +8..12 % time, it spills)
   uint4 va[2][NP];          // A fragments, [unit parity][plane]
   float4 ts[2][2];          // the t column both xi of this wave use, [tile block][channel quad] (W8_TSHARE)
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     constexpr int CA1 = 1, CB1 = H ? 3 : 2;
     constexpr float SB1 = H ? -1.f : 1.f;
     // the shared t column (CB0) is operand b of the second xi for h = 0 (t1 + t2) and operand a for h = 1 (t1 - t3)
-    constexpr int USE1 = W8_TSHARE ? (H ? 2 : 1) : 0;
+    constexpr int USE1 = TSH ? (H ? 2 : 1) : 0;
     static_assert(CB0 == (H ? CA1 : CB1), "the shared column");
     const int k1 = min(kc0 + 1, kc1 - 1);
     OSM_W8_LOAD_RAW(kc0, 0) OSM_W8_LOAD_RAW(kc0, 1) OSM_W8_LOAD_RAW(kc0, 2)
@@ -258,49 +258,31 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     OSM_W8_LOAD_RAW(k1, 0) OSM_W8_LOAD_RAW(k1, 1) OSM_W8_LOAD_RAW(k1, 2)
     OSM_W8_LOAD_TAB(k1)
     __syncthreads();
-    OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, (kc0 & 1) * (4 * WN_QP), W8_TSHARE, 0)
+    OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, (kc0 & 1) * (4 * WN_QP), TSH, 0)
     OSM_W8_FENCE()
     for (int c = kc0; c < kc1; ++c) {
       const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
       const int bo = (c & 1) * (4 * WN_QP), bn = ((c + 1) & 1) * (4 * WN_QP);
       // unit 0 = (xi 0, block 0) | builds (xi 0, block 1); U of xi 1 for this slab
       OSM_W8_LOAD_U(c, 1)
-#if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
-#endif
-      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo, W8_TSHARE, 0)
+      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo, TSH, 0)
       OSM_W8_MMA(0, 0, 0)
-#if W8_LATE
-      __builtin_amdgcn_sched_barrier(0);
-      OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
-#endif
       OSM_W8_FENCE()
       // unit 1 = (xi 0, block 1) | builds (xi 1, block 0)
-#if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
-#endif
       OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo, 0, USE1)
       OSM_W8_MMA(1, 0, 1)
-#if W8_LATE
-      __builtin_amdgcn_sched_barrier(0);
-      OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
-#endif
       OSM_W8_FENCE()
       // unit 2 = (xi 1, block 0) | builds (xi 1, block 1); U of xi 0 for the next slab
       OSM_W8_LOAD_U(c1, 0)
-#if !W8_LATE
       OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
-#endif
       OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo, 0, USE1)
       OSM_W8_MMA(0, 1, 0)
-#if W8_LATE
-      __builtin_amdgcn_sched_barrier(0);
-      OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
-#endif
       OSM_W8_FENCE()
       __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
       // unit 3 = (xi 1, block 1) | builds (xi 0, block 0) of slab c + 1
-      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, W8_TSHARE, 0)
+      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, TSH, 0)
       OSM_W8_MMA(1, 1, 1)
       OSM_W8_FENCE()
     }
