@@ -57,7 +57,7 @@ typedef struct osm_conv_desc {
                           (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16);
                           1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file;
                           4 | OSM_WFMT_WINOGRAD = "f16x3": two IEEE-half planes per operand, both operands scaled into the
-                          fp16 range by powers of two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs */
+                          fp16 range by powers of two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs, refuses gn_table */
   const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from

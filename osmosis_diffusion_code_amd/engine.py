@@ -366,7 +366,9 @@ class UNetEngine:
         H, W = hw
         if not (self.fuse_gn and cv.wfmt != 0 and cv.k == 3 and W >= 16 and H >= 8 and H * W > 256):
             return False
-        return self.fuse_gn_wino or not self._is_wino(cv, hw)
+        if not self._is_wino(cv, hw):
+            return True
+        return self.fuse_gn_wino and cv.wwfmt != 4      # f16x3 needs the range of the tensor it multiplies: never fused
 
     def _gn_stats_from_conv(self, cv: _Conv, hw) -> bool:
         """May the convolution that produces a tensor also emit the column sums for the GroupNorm `cv` reads it through?"""

@@ -176,6 +176,10 @@ def test_f16x3_refusals(ops):
         ops.conv2d(ops.Mat.of(x), wf, None, ops.Mat.of(y), 1, 16, 16, 3, wfmt=4 | ops.WINOGRAD)
     with pytest.raises(OsmosisHipError):        # wfmt 4 exists as a Winograd image only
         ops.conv2d(ops.Mat.of(x), wf, None, ops.Mat.of(y), 1, 16, 16, 3, wfmt=4)
+    parts = torch.zeros(ops.MAXABS_PARTS, device=DEV)
+    with pytest.raises(OsmosisHipError, match="fused GroupNorm"):      # the range handed over is x's, not GN(x)'s
+        ops.conv2d(ops.Mat.of(x), wf, None, ops.Mat.of(y), 1, 16, 16, 3, wfmt=4 | ops.WINOGRAD, x_maxabs=parts,
+                   gn_table=torch.zeros(4 * 64, device=DEV))
 
 
 def test_winograd_matches_direct_kernel_and_accumulates(ops):
