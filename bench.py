@@ -475,7 +475,12 @@ def main():
         "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
                                "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime (t <= 0.3T)",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
-                   "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode, "parallelism": f"images[rank::{world}] (no collective on the path)",
+                   "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode,
+                   "conv_arithmetic_note": ("f16x3: Winograd 3x3 layers multiply ~22-bit operands (two IEEE-half terms per fp32 value after "
+                                            "a power-of-two scaling) with three fp16 MFMAs per product and fp32 accumulation; every other "
+                                            "contraction is bf16x6 (exact three-term bf16 split, six MFMAs).  Tests hold both to the same "
+                                            "4e-6 against fp64; `same_workload_bf16x6` is this run in bf16x6 everywhere")
+                   if args.conv_mode == "f16x3" else None, "parallelism": f"images[rank::{world}] (no collective on the path)",
                    "finite_outputs": finite},
         "images_per_sec_at_1000_steps": round(units / dt / 1000.0, 6),
     }
@@ -494,6 +499,19 @@ def main():
             del model
             model = None
             torch.cuda.empty_cache()
+            if args.conv_mode == "f16x3":
+                # the same workload in round 2's arithmetic (every fp32 operand split EXACTLY into three bf16 terms, six
+                # MFMAs per product), measured in the same run: what the headline would be without the f16x3 Winograd images
+                try:
+                    m2, s2, c2 = build_case(args, dev, args.batch, conv_mode="bf16x6")
+                    dt2, fin2 = timed_steps(args, dev, m2, s2, c2, args.batch, 0, args.steps, args.warmup)
+                    line["same_workload_bf16x6"] = {"conv_arithmetic": "bf16x6", "value": round(args.batch * args.steps / dt2, 4),
+                                                    "ms_per_step": round(1e3 * dt2 / args.steps, 3), "steps": args.steps,
+                                                    "warmup": args.warmup, "finite_outputs": fin2}
+                    del m2, s2, c2
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    line["same_workload_bf16x6"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             line["secondary"] = run_secondary(args, dev)
         if world == 1 and args.cpu_steps > 0:
             del model

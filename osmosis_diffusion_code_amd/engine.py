@@ -238,6 +238,7 @@ class UNetEngine:
             raise ValueError(f"H, W must be divisible by {1 << (nlev - 1)}")
         self.ticket = 0
         self._saved: Dict[int, dict] = {}       # per-block activations kept for the data-gradient pass
+        self._xmax_reg: Dict[Tuple, torch.Tensor] = {}
         self.params_version = None
         self._scratch: Dict[str, torch.Tensor] = {}
         self._fwd_plan: Optional[Recorder] = None
@@ -472,8 +473,11 @@ class UNetEngine:
         # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
         # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
         # holds dy in registers and reads x once); what remains is a tiny finalize and the apply pass.
+        # max |dy| for an f16x3 data-gradient: left behind by the GroupNorm pass that wrote dy (the previous ResBlock's last
+        # launch; a bound over the wider concat-gradient buffer serves its column slice), else a pass of its own
         cs = self._conv(dy, blk.c2, dh2, (ho, wo), dgrad=True,
-                        stat=("bwd", s["h1"], s["tab2"]) if s["tab2"] is not None else None)
+                        stat=("bwd", s["h1"], s["tab2"]) if s["tab2"] is not None else None,
+                        xmax=self._xmax_reg.get((dy.p, dy.rows, dy.ld)))
         dh1 = self._scr("b", Mo, blk.cout)
         gst = self._small(B * G * 2)
         xmh = self._xmax_from_gn(blk.c1, (ho, wo), (ho, wo), "gnb", dgrad=True)
@@ -513,13 +517,19 @@ class UNetEngine:
             add = dy
             add2 = dx_dst if accumulate else None
         gst1 = self._small(B * G * 2)
+        # this pass is the LAST writer of dx_dst (every level's first layer is a ResBlock): it leaves max |dx_dst| behind for the
+        # f16x3 data-gradient convolution of whichever ResBlock reads the buffer as its dy
+        xmo = None
+        if self.conv_mode == "f16x3" and ops.gn_nchunk(H * W) <= ops.MAXABS_PARTS:
+            xmo = self._small(B * ops.MAXABS_PARTS)
+            self._xmax_reg[(dx_dst.p, dx_dst.rows, dx_dst.ld)] = xmo
         if cs1 is not None:
             ops.gn_finalize_cols(cs1[0], cs1[1], B, H * W, blk.cin, G, gst1, mode=1)
             ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add,
-                             addend2=add2)
+                             addend2=add2, maxabs=xmo)
         else:
             ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
-                       silu=True, addend=add, addend2=add2)
+                       silu=True, addend=add, addend2=add2, maxabs=xmo)
 
     # ------------------------------------------------------------------ Attention
     def _gemm(self, *a, **kw):
@@ -759,6 +769,7 @@ class UNetEngine:
     def _backward_impl(self):
         B, H, W = self.B, self.H, self.W
         n_in = len(self.inp)
+        self._xmax_reg = {}         # (pointer, rows, ld) of a gradient buffer -> max |.| slot its last writer filled
         do = self._buf(B * H * W, self.cout)
         ops.nchw_to_nhwc(self.d_out, do, B, self.cout, H * W)
         da = self._scr("a", B * H * W, self.h_last.cols)
