@@ -21,7 +21,7 @@
 #ifndef W8_ABL
 #define W8_ABL 0        // measurement builds (tools/wino8_ablate.sh; results are then wrong): 1 no activation loads, 2 no U loads,
                         // 4 no epilogue, 8 no LDS reads in the V build, 16 no split, 32 MFMAs replaced by one VALU op each,
-                        // 64 activation loads re-read slab 0 (cache hits), 128 U loads re-read one 6 KB piece (cache hits)
+                        // 64 activation loads re-read slab 0 (cache hits), 128 U loads re-read one 6 KB piece (cache hits), 1024 no barrier in the slab loop
 #endif
 #ifndef W8_TSHARE
 #define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
@@ -93,15 +93,25 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(Uglob)), 0, 0x7fffffff, 0x00020000);
 
-  f32x16 acc[2][2][2];      // [local xi jj][tile block][column tile]
+  // accumulators [local xi jj][tile block][column tile], cleared by eight MFMAs on zero operands with the literal 0 as C
+  // (one matrix instruction writes the 16 registers 16 v_mov would: 128 VALU issues less per wave)
+  f32x16 acc[2][2][2];
+  {
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    f32x16 z16;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int e = 0; e < 16; ++e) z16[e] = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][a][b][e] = 0.f;
+        for (int b = 0; b < 2; ++b) {
+          uint4 z = z4;
+          asm("" : "+v"(z.x));       // opaque to the optimiser: eight separate instructions, not one result copied 7 x 16 times
+          acc[j][a][b] = mma16h(z, z4, z16);
+        }
+  }
 
   // ---- this wave's row of B^T d:  t = x + sg y  with (x, y) = input rows (0, 2) | (1, 2) | (2, 1) | (1, 3) of the 4 x 4
   // tile and sg = -1 | +1 | -1 | -1.  Lane = tile (lr >> 3, lr & 7) of a 32-tile block, channel half lk.
@@ -236,9 +246,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
         else if constexpr (HP) acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]); \
         else acc[jj_][tb_][b] = mma16<NP>(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);
 // nothing crosses a unit boundary (keeps the prefetch distance of the loads and the live ranges of va / uq as written)
+#ifndef W8_FENCE_MODE
+#define W8_FENCE_MODE 0
+#endif
 #define OSM_W8_FENCE()                                                                     \
-  asm volatile("" ::: "memory");                                                           \
-  __builtin_amdgcn_sched_barrier(0);
+  if (W8_FENCE_MODE != 2) asm volatile("" ::: "memory");                                   \
+  if (W8_FENCE_MODE == 0) __builtin_amdgcn_sched_barrier(0);
 
   // one K loop per column pair: the (column, sign) constants of V differ, everything else is shared
   auto slab_loop = [&](auto hc) __attribute__((always_inline)) {
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo, 0, USE1)
       OSM_W8_MMA(0, 1, 0)
       OSM_W8_FENCE()
-      __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
+      if (!(W8_ABL & 1024)) __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
       // unit 3 = (xi 1, block 1) | builds (xi 0, block 0) of slab c + 1
       OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, TSH, 0)
       OSM_W8_MMA(1, 1, 1)
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 
   if ((W8_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
   // ---- Y = A^T M A.  xi columns: s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 -> this wave's partials p0 | p1:
-  //   h = 0 (M0, M1): (M0 + M1, M1);   h = 1 (M2, M3): (M2, -(M2 + M3)).
+  //   h = 0 (M0, M1): (M0 + M1, M1);   h = 1 (M2, M3): (M2, M2 + M3), the latter subtracted.
   // xi rows: Y[0][.] = s(0) + s(1) + s(2), Y[1][.] = s(1) - s(2) - s(3).  One tile block per round.
   // red: [wave = 4 h + r][ox][column tile][e][lane = 32 lk + column]; finishing wave f = (oy, ox, column tile b).
   const int oy = wave >> 2, ox = (wave >> 1) & 1, fb = wave & 1;
@@ -338,11 +351,20 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
+        // h = 0: (M0 + M1, M1);  h = 1: (M2, M2 + M3) -- the second is SUBTRACTED by the finishing waves.  A real (scalar)
+        // branch per wave: as selects this was 128 v_cndmask per wave
         const float m0 = acc[0][a][b][e], m1 = acc[1][a][b][e];
-        float p0, p1;
-        if (wh == 0) { p0 = m0 + m1; p1 = m1; } else { p0 = m0; p1 = -(m0 + m1); }      // wave-uniform
-        red[(((wave * 2 + 0) * 2 + b) * 16 + e) * 64 + lane] = p0;
-        red[(((wave * 2 + 1) * 2 + b) * 16 + e) * 64 + lane] = p1;
+        float* r0_ = red + (((wave * 2 + 0) * 2 + b) * 16 + e) * 64 + lane;
+        float* r1_ = red + (((wave * 2 + 1) * 2 + b) * 16 + e) * 64 + lane;
+        if (wh == 0) {
+          asm volatile("" ::: "memory");
+          *r0_ = m0 + m1;
+          *r1_ = m1;
+        } else {
+          *r0_ = m0;
+          *r1_ = m0 + m1;
+          asm volatile("" ::: "memory");
+        }
       }
     __syncthreads();
 #pragma unroll
@@ -353,7 +375,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const float4 s = *reinterpret_cast<const float4*>(red_rd + (((h2 * 4 + oy + k) * 4) * 16 + 4 * i) * 64);
-          if (oy == 0 || k == 0) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+          // xi rows: + + + (oy = 0) | + - - (oy = 1); the second column partial of the h = 1 waves enters negated
+          if ((oy == 0 || k == 0) != (h2 == 1 && ox == 1)) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
           else { v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w; }
         }
       if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--winograd", action="store_true", help="Winograd F(2x2,3x3) image where the layer allows it")
     ap.add_argument("--dgrad", action="store_true", help="run the data-gradient image (Cout -> Cin)")
+    ap.add_argument("--zero-x", action="store_true", help="all-zero activations (same instruction stream, minimal data toggling: "
+                    "if the kernel gets faster it is power / clock limited, not issue limited)")
     ap.add_argument("--gn", action="store_true", help="fused GroupNorm + SiLU of the input while staging (synthetic table)")
     a = ap.parse_args()
     shapes = a.shape or ["1,256,256,256,256,3", "1,128,128,512,512,3", "1,128,128,256,256,3", "1,64,64,512,512,3",
@@ -34,6 +36,9 @@ def main():
         g = torch.Generator(device=dev).manual_seed(0)
         adt = torch.float16 if a.mode == "f16" else torch.float32
         x = torch.randn(M, Cin, device=dev, generator=g).to(adt)
+        if a.zero_x:
+            x.zero_()
+            x[0, 0] = 1.0       # a non-zero maximum keeps the f16x3 scale finite
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, device=dev, generator=g)
         y = torch.empty(M, Cout, device=dev, dtype=adt)
