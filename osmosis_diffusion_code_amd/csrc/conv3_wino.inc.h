@@ -63,7 +63,7 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, unsigned sh
   if (np == 4) {
     const float mx = __uint_as_float(*reinterpret_cast<const unsigned*>(out + 2 * per_plane + 2));   // copy made below
     int e = 0;
-    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 14 - e; }
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = min(14 - e, 100); }
     wsc = ldexpf(1.f, e);
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_plane;
@@ -102,7 +102,7 @@ __global__ void wino_scale_word_kernel(unsigned* __restrict__ word, int stage) {
   if (stage == 0) { word[1] = word[0]; return; }
   const float mx = __uint_as_float(word[1]);
   int e = 0;
-  if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 14 - e; }
+  if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = min(14 - e, 100); }
   word[0] = __float_as_uint(ldexpf(1.f, e));
 }
 

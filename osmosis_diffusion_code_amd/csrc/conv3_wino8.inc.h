@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     __syncthreads();              // the staging stores that follow reuse smem
     const float mx = __uint_as_float(mb);
     int ex = 0;
-    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 12 - ex; }
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(12 - ex, 100); }   // (denormal maxima: 2^ex stays finite)
     xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
     oscale = ldexpf(1.f, -ex) / p.wscale[0];
   }

@@ -104,7 +104,7 @@ def test_f16x3_fwd_and_dgrad(ops, B, Cin, Cout, H, W, splitk):
     assert e < tol, ("dgrad", e)
 
 
-@pytest.mark.parametrize("xs,wsc", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 2e3), (1e-20, 1e-12), (1e12, 1e9)])
+@pytest.mark.parametrize("xs,wsc", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 2e3), (1e-20, 1e-12), (1e12, 1e9), (1e-30, 1e3)])
 def test_f16x3_is_scale_invariant(ops, xs, wsc):
     """fp16 has 5 exponent bits; the kernel's power-of-two scaling of both operands must make the result independent of
     their magnitudes (activations of 1e-6 as in late-chain gradients, weights of 1e-5 ... 1e3): same relative error."""
@@ -150,6 +150,22 @@ def test_f16x3_per_image_scale_outliers_zero_and_nan(ops):
     _f16x3_conv(ops, ops.Mat.of(to_nhwc(xn)), wf, bias.to(DEV), ops.Mat.of(y), B, H, W)
     o2 = from_nhwc(y, B, H, W)
     assert torch.isnan(o2[0]).all() and torch.isfinite(o2[1]).all() and torch.isfinite(o2[2]).all()
+
+
+def test_f16x3_denormal_inputs_stay_finite(ops):
+    """An image whose every activation is an fp32 denormal (max |x| = 1e-40): the power-of-two scale is clamped, the
+    output is finite and what an fp32 convolution gives to its own resolution (~0 next to the bias)."""
+    B, Cin, Cout, H, W = 1, 64, 64, 16, 16
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(B, Cin, H, W, generator=g) * 1e-40
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    wf, _ = ops.pack_conv_weight_winograd(w.to(DEV), wfmt=4)
+    y = torch.full((B * H * W, Cout), float("nan"), device=DEV)
+    _f16x3_conv(ops, ops.Mat.of(to_nhwc(x)), wf, bias.to(DEV), ops.Mat.of(y), B, H, W)
+    out = from_nhwc(y, B, H, W)
+    assert torch.isfinite(out).all()
+    assert float((out - bias[None, :, None, None]).abs().max()) < 1e-30
 
 
 def test_maxabs_partials(ops):
