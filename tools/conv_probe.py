@@ -22,7 +22,6 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--winograd", action="store_true", help="Winograd F(2x2,3x3) image where the layer allows it")
     ap.add_argument("--dgrad", action="store_true", help="run the data-gradient image (Cout -> Cin)")
-    ap.add_argument("--direct", action="store_true", help="mode f16x3: the direct halo-tile kernel's image even where Winograd applies")
     ap.add_argument("--zero-x", action="store_true", help="all-zero activations (same instruction stream, minimal data toggling: "
                     "if the kernel gets faster it is power / clock limited, not issue limited)")
     ap.add_argument("--gn", action="store_true", help="fused GroupNorm + SiLU of the input while staging (synthetic table)")
@@ -43,7 +42,7 @@ def main():
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, device=dev, generator=g)
         y = torch.empty(M, Cout, device=dev, dtype=adt)
-        wino = (a.winograd or (a.mode == "f16x3" and not a.direct)) and ops.conv_winograd_ok(H, W, Cin, Cout, k, ops.WFMT[a.mode])
+        wino = (a.winograd or a.mode == "f16x3") and ops.conv_winograd_ok(H, W, Cin, Cout, k, ops.WFMT[a.mode])
         wfmt = ops.WFMT[a.mode] | (ops.WINOGRAD if wino else 0)
         wf, _ = (ops.pack_conv_weight_winograd(w, wfmt=wfmt & 7) if wino else ops.pack_conv_weight(w, wfmt=wfmt))
         xm = None
