@@ -23,6 +23,9 @@
                         // 4 no epilogue, 8 no LDS reads in the V build, 16 no split, 32 MFMAs replaced by one VALU op each,
                         // 64 activation loads re-read slab 0 (cache hits), 128 U loads re-read one 6 KB piece (cache hits), 1024 no barrier in the slab loop
 #endif
+#ifndef W8_DBL
+#define W8_DBL 0        // measurement builds: 1 the build's LDS reads issued twice, 2 the split done twice, 4 every MFMA issued twice
+#endif
 #ifndef W8_TSHARE
 #define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
 #endif
@@ -218,12 +221,20 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       else {                                                                               \
         if ((use_) == 2) ta_ = ts[tb_][hq];                                                \
         else {                                                                             \
-          const osm::floatx4_t xa_ = t_x[oa_], ya_ = t_y[oa_];                             \
+          osm::floatx4_t xa_ = t_x[oa_], ya_ = t_y[oa_];                                   \
+          if (W8_DBL & 1) {   /* measurement: every LDS read of the build issued twice */ \
+            asm volatile("" :: "v"(xa_), "v"(ya_));                                        \
+            xa_ = *(volatile const osm::floatx4_t*)(t_x + oa_); ya_ = *(volatile const osm::floatx4_t*)(t_y + oa_); \
+          }                                                                                \
           ta_ = make_float4(fmaf(sg, ya_[0], xa_[0]), fmaf(sg, ya_[1], xa_[1]), fmaf(sg, ya_[2], xa_[2]), fmaf(sg, ya_[3], xa_[3])); \
         }                                                                                  \
         if ((use_) == 1) tb2_ = ts[tb_][hq];                                               \
         else {                                                                             \
-          const osm::floatx4_t xb_ = t_x[ob_], yb_ = t_y[ob_];                             \
+          osm::floatx4_t xb_ = t_x[ob_], yb_ = t_y[ob_];                                   \
+          if (W8_DBL & 1) {                                                                \
+            asm volatile("" :: "v"(xb_), "v"(yb_));                                        \
+            xb_ = *(volatile const osm::floatx4_t*)(t_x + ob_); yb_ = *(volatile const osm::floatx4_t*)(t_y + ob_); \
+          }                                                                                \
           tb2_ = make_float4(fmaf(sg, yb_[0], xb_[0]), fmaf(sg, yb_[1], xb_[1]), fmaf(sg, yb_[2], xb_[2]), fmaf(sg, yb_[3], xb_[3])); \
         }                                                                                  \
         if (keep_) ts[tb_][hq] = tb2_;                                                     \
@@ -231,7 +242,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       const float4 v_ = make_float4(ta_.x + (sb_) * tb2_.x, ta_.y + (sb_) * tb2_.y, ta_.z + (sb_) * tb2_.z, ta_.w + (sb_) * tb2_.w); \
       if (W8_ABL & 16) { _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                  \
           vh_[hq][q2] = make_uint2(__float_as_uint(v_.x) + q2, __float_as_uint(v_.y) ^ __float_as_uint(v_.z) ^ __float_as_uint(v_.w)); } \
-      else if constexpr (HP) split_f16x2(v_, vh_[hq]);                                     \
+      else if constexpr (HP) {                                                             \
+        split_f16x2(v_, vh_[hq]);                                                          \
+        if (W8_DBL & 2) {   /* measurement: the split done twice */                        \
+          asm volatile("" :: "v"(vh_[hq][0].x), "v"(vh_[hq][0].y), "v"(vh_[hq][1].x), "v"(vh_[hq][1].y)); \
+          float4 v2_ = v_; asm volatile("" : "+v"(v2_.x), "+v"(v2_.y), "+v"(v2_.z), "+v"(v2_.w)); \
+          split_f16x2(v2_, vh_[hq]);                                                       \
+        }                                                                                  \
+      }                                                                                    \
       else split_planes<NP>(v_, vh_[hq]);                                                  \
     }                                                                                      \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
@@ -243,7 +261,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
         if (W8_ABL & 32) acc[jj_][tb_][b][(pa * 3 + pb) & 15] += __uint_as_float((va[par_][pa].x ^ uq[jj_][b][pb].y) + (va[par_][pa].z ^ uq[jj_][b][pb].w)); \
-        else if constexpr (HP) acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]); \
+        else if constexpr (HP) {                                                           \
+          acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);       \
+          if (W8_DBL & 4) acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]); \
+        }                                                                                  \
         else acc[jj_][tb_][b] = mma16<NP>(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);
 // nothing crosses a unit boundary (keeps the prefetch distance of the loads and the live ranges of va / uq as written)
 #ifndef W8_FENCE_MODE
