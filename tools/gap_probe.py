@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Kernel-busy time vs wall time over the timed steps of a bench.py run, from a rocprofv3 --kernel-trace CSV.
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- \
+        python bench.py --steps 20 --warmup 3 --cpu-steps 0 --secondary-steps 0
+    tools/gap_probe.py $OUT/**/*kernel_trace.csv
+The window is the span between the first and the last `phys_finalize_kernel` (only the sampler's steps launch it); prints
+wall, busy (union of kernel intervals), the gap histogram and the kernels that follow the longest gaps.
+"""
+import csv
+import glob
+import sys
+from collections import Counter
+
+
+def main():
+    files = [f for a in sys.argv[1:] for f in glob.glob(a, recursive=True)]
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    idx = [i for i, r in enumerate(rows) if "phys_finalize_kernel" in r[2]]
+    if not idx:
+        raise SystemExit("no phys_finalize_kernel in the trace")
+    # steps are separated by > 1 UNet's worth of kernels between finalize launches; skip the first quarter (warm-up)
+    lo, hi = idx[len(idx) // 4], idx[-1]
+    win = rows[lo:hi + 1]
+    wall = win[-1][1] - win[0][0]
+    busy, end = 0, win[0][0]
+    gaps = []
+    for k, (s, e, n) in enumerate(win):
+        if s > end:
+            gaps.append((s - end, n, win[k - 1][2] if k else ""))
+            busy += e - s
+        elif e > end:
+            busy += e - end
+        end = max(end, e)
+    nfin = sum(1 for r in win if "phys_finalize_kernel" in r[2])
+    print(f"window: {len(win)} kernels, {nfin} phys_finalize launches, wall {wall / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms "
+          f"({busy / wall:.1%}), idle {(wall - busy) / 1e6:.2f} ms in {len(gaps)} gaps")
+    h = Counter()
+    for g, _, _ in gaps:
+        h[min(int(g / 1000), 20)] += g
+    print("idle time by gap length (us: total ms):", {k: round(v / 1e6, 2) for k, v in sorted(h.items())})
+    after = Counter()
+    for g, n, p in gaps:
+        after[(p[:50], n[:50])] += g
+    for (p, n), v in after.most_common(15):
+        print(f"  {v / 1e6:7.2f} ms idle between  {p}  ->  {n}")
+
+
+if __name__ == "__main__":
+    main()
