@@ -121,7 +121,9 @@ class UNetWeights:
         self.mid = seq(model.middle_block)
         self.outb = [seq(s) for s in model.output_blocks]
         self.out_norm = _Norm(model.out.at(0), dev)
-        self.out_conv = _Conv(model.out.at(2), dev, wfmt)
+        # the reference's convert_to_fp16 leaves self.out in fp32 and casts h back before it (unet.py:697-703, 743-744):
+        # in the f16 arithmetic the head's weights are bf16x6 images (fp32-class) and the head runs in the fp32 family
+        self.out_conv = _Conv(model.out.at(2), dev, 3 if wfmt == 1 else wfmt)
 
         # every ResBlock's FiLM projection Linear(SiLU(emb)) depends on emb only: one stacked weight, ONE launch
         res_blocks = [m for seqs in (self.inp, [self.mid], self.outb) for sq in seqs for m in sq if isinstance(m, _Res)]
@@ -398,7 +400,7 @@ class UNetEngine:
             else:
                 ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
             return self._conv(x, cv, y, hw, res=res, gn_table=table, gn_silu=True, stat=stat)
-        a = self._scr("a", B * H * W, x.cols)
+        a = self._scr("a", B * H * W, x.cols, dtype=x.t.dtype)
         xm = self._xmax_from_gn(cv, hw, hw, "gn")
         if cs is not None:      # statistics from the producer's column sums, then the apply pass alone
             ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
@@ -758,10 +760,15 @@ class UNetEngine:
                 dst = self._buf(B * H * W, c_h)
             h, hw = self._run_layers_fwd(layers, self.cat[i], hw, dst)
         assert hw == (H, W)
-        # ---- head: GN, SiLU, conv3x3 -> NCHW
+        # ---- head: GN, SiLU, conv3x3 -> NCHW.  Always in fp32 (use_fp16: `h = h.type(x.dtype)` before the fp32 self.out,
+        # unet.py:743-744): half storage is converted once, eps / the variance logits are not rounded to half
+        if self.adt != torch.float32:
+            h32 = self._buf(B * H * W, h.cols, dtype=torch.float32)
+            ops.convert(h, h32)
+            h = h32
         self.h_last = h
         self.st_out = self._small(B * G * 2)
-        o = self._buf(B * H * W, self.cout)
+        o = self._buf(B * H * W, self.cout, dtype=torch.float32)
         self._gn_conv(h, self.out_norm, self.st_out, self.out_conv, o, (H, W))
         ops.nhwc_to_nchw(o, self.out, B, self.cout, H * W)
         self.x_nhwc = x_nhwc
@@ -770,14 +777,19 @@ class UNetEngine:
         B, H, W = self.B, self.H, self.W
         n_in = len(self.inp)
         self._xmax_reg = {}         # (pointer, rows, ld) of a gradient buffer -> max |.| slot its last writer filled
-        do = self._buf(B * H * W, self.cout)
+        f32 = torch.float32         # the head's gradient runs in the fp32 family in every arithmetic (see _forward_impl)
+        do = self._buf(B * H * W, self.cout, dtype=f32)
         ops.nchw_to_nhwc(self.d_out, do, B, self.cout, H * W)
-        da = self._scr("a", B * H * W, self.h_last.cols)
+        da = self._scr("a", B * H * W, self.h_last.cols, dtype=f32)
         self._conv(do, self.out_conv, da, (H, W), dgrad=True)
-        dy = self._buf(B * H * W, self.h_last.cols)
+        dy = self._buf(B * H * W, self.h_last.cols, dtype=f32)
         gst = self._small(B * G * 2)
         ops.gn_bwd(self.h_last, da, dy, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, self.gn_part,
                    gst, silu=True)
+        if self.adt != f32:
+            dy_h = self._buf(B * H * W, self.h_last.cols)
+            ops.convert(dy, dy_h)
+            dy = dy_h
         # ---- output blocks in reverse; dcat[i] receives d/d(cat_i) at full width
         dcat: List[Optional[Mat]] = [None] * len(self.outb)
         for i in range(len(self.outb) - 1, -1, -1):

@@ -101,6 +101,8 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         self.gradient_clip = utilso.str2bool(clip[0])
         self.gradient_clip_value = float(clip[1].strip()) if self.gradient_clip else None
         self._state = None
+        self._states = {}       # per (chunk size, HW, device): a batch walked in chunks of two sizes keeps both
+        self._opt = None        # optimizer state of the operator's WHOLE phi block (chunks take their rows)
 
     # ---------------------------------------------------------------- device state
     @property
@@ -118,8 +120,9 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         return s.to(device).contiguous()
 
     def _prepare(self, B, HW, device):
-        st = self._state
-        if st is not None and st["key"] == (B, HW, str(device)):
+        st = self._states.get((B, HW, str(device)))
+        if st is not None:
+            self._state = st
             return st
         op = self.operator
         if not hasattr(op, "fill_desc"):
@@ -144,14 +147,17 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         d.B, d.HW = B, HW
         d.optimizer = 1 if getattr(op, "optimizer", "") == "adam" else 0
         nblk = ops.phys_nblk(HW)
+        if d.optimizer == 1 and (self._opt is None or self._opt.shape[0] != op.phi.shape[0] or self._opt.device != op.phi.device):
+            # Adam moments + step of the operator's phi (torch.optim state lives with the optimizer = with the operator,
+            # which the driver rebuilds per image: osmosis_sampling.py:142-155)
+            self._opt = torch.zeros(op.phi.shape[0], 20, device=device, dtype=torch.float32)
         st = {"key": (B, HW, str(device)), "desc": d,
               "part": torch.empty(B * nblk * 16, device=device, dtype=torch.float32),
               "red": torch.zeros(B * 16, device=device, dtype=torch.float32),
               "loss": torch.zeros(B, device=device, dtype=torch.float32),
-              # Adam moments + step of the operator's phi (torch.optim state lives with the optimizer = with the operator,
-              # which the driver rebuilds per image: osmosis_sampling.py:142-155)
-              "opt": torch.zeros(op.phi.shape[0], 20, device=device, dtype=torch.float32) if d.optimizer == 1 else None,
+              "opt": self._opt if d.optimizer == 1 else None,
               "g": torch.empty(B, 4, HW, device=device, dtype=torch.float32)}
+        self._states[st["key"]] = st
         self._state = st
         return st
 

@@ -202,6 +202,22 @@ class GaussianDiffusion:
             tab[i, 7] = self._model_timesteps(i)
         return tab
 
+    @staticmethod
+    def chunk_sizes(B: int, cap: int):
+        """How a batch of B independent images is walked when at most `cap` fit the device at once: the fewest chunks n such
+        that either all are equal (B % n == 0, ONE engine of B / n images) or the two sizes ceil(B / n) and floor(B / n)
+        together stay within the cap (an engine owns its activation buffers, and a ragged walk keeps two engines).
+        B = 37, cap = 32 -> [13, 12, 12] (rounds 1-2 fell back to 37 chunks of one image)."""
+        cap = max(1, int(cap))
+        n = -(-B // cap)
+        while True:
+            hi, lo = -(-B // n), B // n
+            if B % n == 0:
+                return [hi] * n
+            if hi + lo <= cap:
+                return [hi] * (B % n) + [lo] * (n - B % n)
+            n += 1
+
     def _guidance_flag(self, sample_pattern, idx):
         if sample_pattern is None or sample_pattern["pattern"] == "original" or sample_pattern["pattern"] is None:
             return True
@@ -218,12 +234,17 @@ class GaussianDiffusion:
         if not (0 <= last <= first <= T - 1):
             raise ValueError(f"index_range must satisfy 0 <= last <= first <= {T - 1}, got ({first}, {last})")
         # Images are independent chains: a batch whose kept activations would not fit the device
-        # (~8 GB per 256 x 256 image in fp32) is walked in equal chunks per step, through ONE engine of the chunk
-        # size; per-image state (x_t, phi, losses) stays in [B]-sized tensors, the chunks are contiguous row blocks.
-        cap = model.images_in_flight(B, H, W)
-        Bc = max(d for d in range(1, min(B, cap) + 1) if B % d == 0)
-        chunks = [(c0, c0 + Bc) for c0 in range(0, B, Bc)]
-        eng = model.engine(Bc, H, W)
+        # (~8 GB per 256 x 256 image in fp32) is walked in chunks per step; per-image state (x_t, phi, losses) stays in
+        # [B]-sized tensors, the chunks are contiguous row blocks.
+        sizes = self.chunk_sizes(B, model.images_in_flight(B, H, W))
+        chunks, c0 = [], 0
+        for sz in sizes:
+            chunks.append((c0, c0 + sz))
+            c0 += sz
+        engs = {}
+        for sz in sorted(set(sizes), reverse=True):       # at most two sizes; the second call keeps the first engine alive
+            engs[sz] = model.engine(sz, H, W, keep=tuple(engs.values()))
+        eng = engs[sizes[0]]
         f32 = dict(device=dev, dtype=torch.float32)
         table = torch.from_numpy(self.coef_table()).to(dev)
         step = torch.tensor([first], device=dev, dtype=torch.int32)
@@ -257,11 +278,15 @@ class GaussianDiffusion:
                 noise.copy_(noise1.expand_as(noise))
             else:
                 noise.normal_()
-            ops.fetch_coefs(table, step, -1, coef, eng.t_dev, Bc)
+            for e2 in engs.values():        # every engine's timestep vector; the step counter moves once
+                if e2 is not eng:
+                    ops.fetch_coefs(table, step, 0, coef, e2.t_dev, e2.B)
+            ops.fetch_coefs(table, step, -1, coef, eng.t_dev, eng.B)
             if trace is not None:
                 rec = {"x_in": x_state.clone()}
                 grad_all = torch.empty_like(g) if guided else None
             for c0, c1 in chunks:
+                eng, Bc = engs[c1 - c0], c1 - c0
                 if not single:
                     eng.x_in.copy_(x_state[c0:c1])
                 eng.run_forward()

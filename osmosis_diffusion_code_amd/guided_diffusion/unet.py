@@ -211,15 +211,19 @@ class UNetModel(nn.Module):
             hit = self._weights[key]
         return hit[1]
 
-    def engine(self, B: int, H: int, W: int) -> UNetEngine:
+    def engine(self, B: int, H: int, W: int, keep=()) -> UNetEngine:
+        """The engine (activation buffers + launch plans) of one (B, H, W).  One live engine by default: activations are
+        large (~8 GB per 256 x 256 fp32 image).  keep: engines that must stay alive next to the requested one (a batch walked
+        in chunks of two sizes, GaussianDiffusion.chunk_sizes, needs both)."""
         w = self.packed_weights()
         key = (B, H, W, str(w.dev), self.conv_mode)
         eng = self._engines.get(key)
         if eng is None or eng.weights is not w:
-            self._engines = {}              # one live engine: activations are large (~8 GB per 256 x 256 image)
+            kept = {k: e for k, e in self._engines.items() if any(e is q for q in keep) and e.weights is w}
+            self._engines = kept
             eng = UNetEngine(w, B, H, W)
             eng.params_version = self._params_version()
-            self._engines = {key: eng}
+            self._engines = {**kept, key: eng}
         return eng
 
     def images_in_flight(self, B: int, H: int, W: int) -> int:

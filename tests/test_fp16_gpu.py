@@ -204,6 +204,9 @@ def test_tiny_unet_fp16_vs_fp32_oracle():
     assert ey < 1e-2 and ed < 1e-2
     eng = next(iter(m16._engines.values()))
     assert eng.adt == torch.float16
+    # the head is NOT converted (unet.py:697-703: convert_to_fp16 touches input / middle / output blocks only; unet.py:743-744:
+    # h.type(x.dtype) before self.out): fp32 storage and fp32-class weights for out_norm / out_conv and their gradients
+    assert eng.h_last.t.dtype == torch.float32 and eng.out_conv.wfmt == 3 and eng.inp[0][0].wfmt == 1
     m16.convert_to_fp32()
     assert m16.conv_mode != "f16"
     y32 = m16(x.to(DEV), t.to(DEV))

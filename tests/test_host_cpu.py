@@ -318,3 +318,22 @@ def test_fused_loop_argument_checks_need_no_gpu():
     assert c0.clip_value == 0.0                           # clamp to zero, like torch.clamp(g, -0, 0)
     with pytest.raises(NotImplementedError):              # inverse() drives the HIP UNetModel only
         Prior(1000, "linear").inverse(object(), shape=(4, 8, 8), steps=5, start_t=3)
+
+
+def test_chunk_sizes_of_a_batch_that_does_not_fit():
+    """GaussianDiffusion.chunk_sizes: fewest chunks, at most two sizes (an engine per size owns its activations, so the two
+    sizes together must fit the cap); a prime batch above the cap no longer degenerates into chunks of one image."""
+    from osmosis_diffusion_code_amd.guided_diffusion.gaussian_diffusion import GaussianDiffusion as GD
+    assert GD.chunk_sizes(32, 32) == [32] and GD.chunk_sizes(32, 100) == [32]
+    assert GD.chunk_sizes(32, 16) == [16, 16]
+    assert GD.chunk_sizes(37, 32) == [13, 12, 12]
+    assert GD.chunk_sizes(33, 32) == [11, 11, 11]
+    assert GD.chunk_sizes(5, 4) == [2, 2, 1]
+    assert GD.chunk_sizes(3, 2) == [1, 1, 1] and GD.chunk_sizes(7, 1) == [1] * 7
+    for B in range(1, 80):
+        for cap in range(1, 40):
+            sz = GD.chunk_sizes(B, cap)
+            kinds = sorted(set(sz))
+            assert sum(sz) == B and max(sz) <= cap and len(kinds) <= 2
+            assert len(kinds) == 1 or sum(kinds) <= cap
+            assert sz == sorted(sz, reverse=True)

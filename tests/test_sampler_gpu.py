@@ -157,6 +157,43 @@ def test_batched_images_equal_single_image_runs(pkg):
             assert torch.allclose(both[1][n][i:i + 1], one[1][n], atol=1e-6)
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_ragged_chunks_equal_whole_batch(pkg, monkeypatch, optimizer):
+    """A batch that does not fit at once is walked in chunks of (at most) two sizes through two engines
+    (GaussianDiffusion.chunk_sizes: B = 5 with room for 4 -> [2, 2, 1]); images are independent chains, so every image
+    must come out as in the one-pass run -- including the Adam state of its phi rows, which lives with the operator and
+    not with the chunk."""
+    unet, gd, M, CM = pkg
+    opname = "underwater_physical_revised"
+    spec = OPERATORS[opname]
+    model = make_model(unet)
+    gen = torch.Generator().manual_seed(33)
+    B = 5
+    xT = 0.5 * torch.randn(B, 4, 32, 32, generator=gen)
+    y = torch.rand(B, 3, 32, 32, generator=gen) * 1.6 - 0.8
+    nz = torch.randn(10, B, 4, 32, 32, generator=gen).to(DEV)
+
+    def run():
+        operator = M.get_operator(opname, device=DEV, batch_size=B, **dict(spec["operator"], optimizer=optimizer))
+        cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN,
+                                          **spec["aux"])
+        return make_sampler(gd).p_sample_loop(
+            model=model, x_start=xT.to(DEV), measurement=y.to(DEV), measurement_cond_fn=cond.conditioning,
+            record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False, sample_pattern=PATTERN,
+            noise_fn=lambda k, shape: nz[k])
+
+    whole = run()
+    assert sorted(e.B for e in model._engines.values()) == [5]
+    monkeypatch.setenv("OSM_MAX_BATCH", "4")
+    assert gd.GaussianDiffusion.chunk_sizes(5, 4) == [2, 2, 1]
+    ragged = run()
+    assert sorted(e.B for e in model._engines.values()) == [1, 2]          # two live engines, both within the cap
+    assert float((whole[0] - ragged[0]).abs().max()) < 1e-5
+    assert np.allclose(whole[2], ragged[2], rtol=1e-5)
+    for n in whole[1]:
+        assert torch.allclose(whole[1][n], ragged[1][n], atol=1e-6), n
+
+
 @pytest.mark.parametrize("name", ["ddpm", "ddim"])
 def test_rgb_guidance_ps_chain_matches_reference(pkg, name, monkeypatch):
     """`ps` conditioning + `rgb_guidance` operator + gaussian noiser through DDPM.p_sample and
