@@ -373,6 +373,12 @@ class UNetEngine:
             return True
         return self.fuse_gn_wino and cv.wwfmt != 4      # f16x3 needs the range of the tensor it multiplies: never fused
 
+    def _bwd_stats_ok(self, cv: _Conv, hw) -> bool:
+        """OSM_FUSE_STATS=all: may the data-gradient convolution of `cv` emit the two GroupNorm-backward reductions of the
+        GroupNorm in front of `cv`?  Needs the per-channel table of that GroupNorm kept from the forward pass."""
+        H, W = hw
+        return self._gn_fusable(cv, hw) or (self._is_wino(cv, hw) and self._is_wino(cv, hw, dgrad=True) and H * W > 1024)
+
     def _gn_stats_from_conv(self, cv: _Conv, hw) -> bool:
         """May the convolution that produces a tensor also emit the column sums for the GroupNorm `cv` reads it through?"""
         H, W = hw
@@ -403,7 +409,14 @@ class UNetEngine:
         a = self._scr("a", B * H * W, x.cols, dtype=x.t.dtype)
         xm = self._xmax_from_gn(cv, hw, hw, "gn")
         if cs is not None:      # statistics from the producer's column sums, then the apply pass alone
-            ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
+            if table is not None:
+                ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0, gamma=norm.g, beta=norm.b, film=film,
+                                     table=table)
+            else:
+                ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
+            ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
+        elif table is not None:     # the table is kept for the backward (OSM_FUSE_STATS=all)
+            ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
             ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
         else:
             ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
@@ -447,7 +460,7 @@ class UNetEngine:
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
             # the per-channel GroupNorm tables are kept: the data-gradient convolutions fold the GroupNorm-backward
             # reductions into their epilogues with them (see _res_bwd)
-            tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._gn_fusable(blk.c1, hw)) else None
+            tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._bwd_stats_ok(blk.c1, hw)) else None
             if blk.skip is not None:
                 self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
@@ -458,7 +471,7 @@ class UNetEngine:
             res = dst
         else:
             res = xs
-        tab2 = self._small(B * 4 * blk.cout) if (self.fuse_stats_bwd and fuse2) else None
+        tab2 = self._small(B * 4 * blk.cout) if (self.fuse_stats_bwd and self._bwd_stats_ok(blk.c2, (ho, wo))) else None
         self._gn_conv(h1, blk.n2, st2, blk.c2, dst, (ho, wo), film=film, res=res, cs=cs1, table=tab2)
         self._saved[id(blk)] = dict(x=x, st1=st1, h1=h1, st2=st2, film=film, hw=hw, hwo=(ho, wo), tab1=tab1, tab2=tab2)
         return (ho, wo)
