@@ -56,8 +56,10 @@ typedef struct osm_conv_desc {
                           3 / 2 = split-bf16 planes from osm_pack_conv_weight_bf16s
                           (3 planes = "bf16x6", fp32-class accuracy; 2 planes = "bf16x3", ~2^-16);
                           1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file;
-                          4 | OSM_WFMT_WINOGRAD = "f16x3": two IEEE-half planes per operand, both operands scaled into the
-                          fp16 range by powers of two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs, refuses gn_table */
+                          4 = "f16x3": two IEEE-half planes per operand, both operands scaled into the fp16 range by powers of
+                          two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs, refuses gn_table.  3x3 layers:
+                          4 | OSM_WFMT_WINOGRAD (osm_pack_conv_weight_winograd); 1x1 layers: plain 4 (osm_pack_conv_weight_bf16s),
+                          H * W a multiple of 128 */
   const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from
@@ -74,7 +76,7 @@ typedef struct osm_conv_desc {
   const float* stat_x;
   long long ld_sx;
   const float* stat_table;
-  const float* x_maxabs; /* wfmt 4 only ("f16x3" Winograd image): [B][OSM_MAXABS_PARTS] partial max |x| of the input from osm_maxabs --
+  const float* x_maxabs; /* wfmt 4 only ("f16x3" images): [B][OSM_MAXABS_PARTS] partial max |x| of the input from osm_maxabs --
                           the kernel scales x into the fp16 range by a power of two and undoes it in its epilogue */
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);
@@ -103,7 +105,9 @@ typedef struct osm_gemm_desc {
 /* Split-bf16 (wfmt 2, 3) / fp16 (wfmt 1: ONE plane of IEEE half, round-to-nearest-even) weight images: `wfmt` planes in MFMA-fragment order
  * [plane][tap][k16-step s][n/32 j][lane l][8]: n = 32j + (l&31), k = 16s + 8(l>>5) + e, zero padded, an even
  * number of k16 steps; forward n=Cout,k=Cin; data-gradient n=Cin,k=Cout (taps flipped).  Sizes in uint16
- * elements from osm_packed_weight_elems (wfmt 0 -> float elements of osm_pack_conv_weight). */
+ * elements from osm_packed_weight_elems (wfmt 0 -> float elements of osm_pack_conv_weight).
+ * wfmt 4 ("f16x3", ksize 1 only): two planes of IEEE halves of w * 2^ew (2^ew brings max |w| to [2^13, 2^14)), followed by
+ * 16 bytes whose first float is 2^ew. */
 long long osm_packed_weight_elems(int Cout, int Cin, int ksize, int wfmt, int dgrad);
 int osm_pack_conv_weight_bf16s(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize,
                                int wfmt, void* stream);
@@ -183,10 +187,12 @@ int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, 
 /* maxabs_out (here and in osm_gn_fwd / osm_gn_bwd / osm_gn_bwd_apply; NULL = off): the pass that writes the output also
  * leaves its per-image partial max |out| in the osm_maxabs format [B][OSM_MAXABS_PARTS] -- the f16x3 convolution that reads
  * the tensor next then needs no osm_maxabs pass.  Requires osm_gn_nchunk(HW) <= OSM_MAXABS_PARTS. */
-/* stats + apply in one call (one launch for HW <= 256); `stats` is written (kept for the backward). */
+/* stats + apply in one call (one launch for HW <= 256); `stats` is written (kept for the backward).
+ * maxabs_in (NULL = off; fp32 family, HW > 256): the statistics pass also leaves the partial max |x| of the INPUT in the osm_maxabs
+ * format -- for an f16x3 1x1 convolution that reads x itself (the skip connection of a ResBlock, unet.py:274-283). */
 int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
                float* part, float* stats, const float* gamma, const float* beta, const float* film,
-               long long ldfilm, int silu, float* maxabs_out, void* stream);
+               long long ldfilm, int silu, float* maxabs_out, float* maxabs_in, void* stream);
 /* Statistics only + the per-channel table a convolution applies itself (osm_conv_desc.gn_table):
  * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
@@ -343,7 +349,7 @@ int osm_gn_apply_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long 
                    long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
 int osm_gn_fwd_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G, float eps,
                  float* part, float* stats, const float* gamma, const float* beta, const float* film,
-                 long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
+                 long long ldfilm, int silu, float* maxabs_out /* must be NULL */, float* maxabs_in /* must be NULL */, void* stream);
 int osm_gn_prep_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
                   const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
                   void* stream);

@@ -576,7 +576,14 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     else
       hipLaunchKernelGGL((igemm_bf16s_kernel<1, 1>), g2, dim3(256), 0, st, p.A, Bp, p);
 #else
-    if (wfmt == 3 && taps == 9)
+    if (wfmt == 4) {     // f16x3 image of a 1x1 layer: two half planes behind a scale word, the input's range from the caller
+      if (taps != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 image (wfmt 4 without OSM_WFMT_WINOGRAD) is for 1x1 layers");
+      if (!p.xmax) return osm::fail(OSM_ERR_INVALID, "the f16x3 image (wfmt 4) needs x_maxabs (osm_maxabs of the input)");
+      if ((p.H * p.W) % BM != 0)
+        return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 kernel needs H * W to be a multiple of %d (one image per tile)", BM);
+      p.wscale = reinterpret_cast<const float*>(Bp + 2LL * p.ksteps * p.nt32 * 512);
+      hipLaunchKernelGGL((igemm_bf16s_kernel<1, 2, true>), g2, dim3(256), 0, st, p.A, Bp, p);
+    } else if (wfmt == 3 && taps == 9)
       hipLaunchKernelGGL((igemm_bf16s_kernel<9, 3>), g2, dim3(256), 0, st, p.A, Bp, p);
     else if (wfmt == 3)
       hipLaunchKernelGGL((igemm_bf16s_kernel<1, 3>), g2, dim3(256), 0, st, p.A, Bp, p);
@@ -773,8 +780,8 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
               "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 1 / 2 / 3 / 4");
   p.xmax = d->x_maxabs;
   if (wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
-    OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && wino),
-                "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3), 3 (bf16x6), or 4 (f16x3, Winograd image only)");
+    OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && (wino || d->ksize == 1)),
+                "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3), 3 (bf16x6), or 4 (f16x3: Winograd images and 1x1 layers)");
     p.nt32 = (d->Cout + 31) / 32;
     p.ksteps = 2 * ((d->Cin + 31) / 32);
   }
@@ -815,24 +822,37 @@ extern "C" int osm_pack_conv_weight(const float* w, float* wf, float* wd, int Co
 
 extern "C" long long osm_packed_weight_elems(int Cout, int Cin, int k, int wfmt, int dgrad) {
   if (wfmt == 0) return (long long)k * k * Cout * Cin;                         // floats
-  // wfmt 1 (one fp16 plane), 2, 3 (bf16 planes): 16-bit elements
+  // wfmt 1 (one fp16 plane), 2, 3 (bf16 planes): 16-bit elements; 4 (f16x3): two half planes + 16 bytes for the scale word
   const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-  return (long long)wfmt * k * k * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;   // bf16 (uint16) elements
+  const long long per_plane = (long long)k * k * (2 * ((K + 31) / 32)) * ((N + 31) / 32) * 512;
+  if (wfmt == 4) return 2 * per_plane + 8;
+  return wfmt * per_plane;   // bf16 (uint16) elements
 }
 
 extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int k,
                                           int wfmt, void* stream) {
   OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_bf16s: null pointer");
   OSM_REQUIRE(k == 1 || k == 3, "osm_pack_conv_weight_bf16s: ksize must be 1 or 3");
-  OSM_REQUIRE(wfmt >= 1 && wfmt <= 3, "osm_pack_conv_weight_bf16s: wfmt must be 1 (fp16), 2 or 3 (bf16 planes)");
+  OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && k == 1),
+              "osm_pack_conv_weight_bf16s: wfmt must be 1 (fp16), 2 or 3 (bf16 planes), or 4 (f16x3: 1x1 layers only)");
   for (int dg = 0; dg < 2; ++dg) {
     unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
     if (!out) continue;
-    const long long per_plane = osm_packed_weight_elems(Cout, Cin, k, wfmt, dg) / wfmt;
+    const long long per_plane = (osm_packed_weight_elems(Cout, Cin, k, wfmt, dg) - (wfmt == 4 ? 8 : 0)) / (wfmt == 4 ? 2 : wfmt);
     int blocks = (int)((per_plane + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    if (wfmt == 4) {     // pass 1: max |w| (as uint bits) into the scale word behind the planes; the pack pass scales by it
+      unsigned* sw = reinterpret_cast<unsigned*>(out + 2 * per_plane);
+      hipError_t e = hipMemsetAsync(sw, 0, 16, (hipStream_t)stream);
+      if (e != hipSuccess) return osm::fail(OSM_ERR_LAUNCH, "osm_pack_conv_weight_bf16s: memset failed");
+      hipLaunchKernelGGL(wmax_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, sw, (long long)Cout * Cin * k * k);
+      hipLaunchKernelGGL(wino_scale_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sw, 0);
+    }
     hipLaunchKernelGGL(pack_weight_bf16s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
                        k, wfmt, dg);
+    if (wfmt == 4)
+      hipLaunchKernelGGL(wino_scale_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                         reinterpret_cast<unsigned*>(out + 2 * per_plane), 1);
     int rc = osm::check_launch("pack_weight_bf16s_kernel");
     if (rc) return rc;
   }

@@ -35,7 +35,10 @@ constexpr int S_PLANE = 128 * S_ROWB;   // bytes per 128-row plane
 // 32 B of zeros every masked staging load is redirected to (halo / ragged edge / channel tail).
 __device__ uint4 g_zero_page[2];   // zero-initialised device global (never written)
 
-template <int TAPS, int NP>
+// HP ("f16x3", NP = 2, 1x1 layers): the two planes are IEEE halves of x * 2^ex (2^ex from the per-image max |x| the caller
+// supplies, IGemmParams::xmax, brings it to [2^13, 2^14)); the weight image holds halves of w * 2^ew behind a scale word; three
+// fp16 MFMAs per product, the exact power-of-two rescale in the epilogue.  A tile must not straddle two images.
+template <int TAPS, int NP, bool HP = false>
 __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Bglob,
                                                               IGemmParams p) {
@@ -59,6 +62,26 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
   const int per = (p.nchunks + p.splitk - 1) / p.splitk;
   const int kc0 = ks * per;
   const int kc1 = min(p.nchunks, kc0 + per);
+
+  float xscale = 1.f, oscale = 1.f;
+  if (HP) {
+    static_assert(!HP || NP == 2, "f16x3: two half planes");
+    static_assert(OSM_MAXABS_PARTS == 1024, "four partial maxima per thread");
+    const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)(m0 / (p.H * p.W)) * OSM_MAXABS_PARTS;
+    unsigned mb = max(max(xm[tid], xm[tid + 256]), max(xm[tid + 512], xm[tid + 768]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+    mb = max(max(red_u[0], red_u[1]), max(red_u[2], red_u[3]));
+    __syncthreads();              // the staging stores that follow reuse smem
+    const float mx = __uint_as_float(mb);
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(14 - ex, 100); }   // (denormal maxima: 2^ex stays finite)
+    xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
+    oscale = ldexpf(1.f, -ex) / p.wscale[0];
+  }
 
   // ---- A staging coordinates: float4 column group cg of rows r0 + 32 i.
   // Addressing is "uniform 64-bit base (SGPR) + per-lane 32-bit byte offset": the base points (W+1) pixels
@@ -159,15 +182,24 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
     bf[2] = (st_) ? b_##12 : b_##02;                                                                 \
     _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                           \
       _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb) {                                  \
-        acc[2 * (half_)] = mma16<NP>(f_[0][pa], bf[pb], acc[2 * (half_)]);                           \
-        acc[2 * (half_) + 1] = mma16<NP>(f_[1][pa], bf[pb], acc[2 * (half_) + 1]);                   \
+        acc[2 * (half_)] = HP ? mma16h(f_[0][pa], bf[pb], acc[2 * (half_)])                          \
+                              : mma16<NP>(f_[0][pa], bf[pb], acc[2 * (half_)]);                      \
+        acc[2 * (half_) + 1] = HP ? mma16h(f_[1][pa], bf[pb], acc[2 * (half_) + 1])                  \
+                                  : mma16<NP>(f_[1][pa], bf[pb], acc[2 * (half_) + 1]);              \
       }                                                                                              \
   }
 // split one staged float4 (rows r0 + 32 i) into NP planes of A stage `buf_`
 #define OSM_S_SPLIT(ra_, ok_, i_, buf_)                                                              \
   {                                                                                                  \
     uint2 pl[NP];                                                                                    \
-    split_planes<NP>(sel4(((ok_) >> (i_)) & 1u, ra_[i_]), pl);                                                                   \
+    if constexpr (HP) {                                                                              \
+      const float4 v_ = sel4(((ok_) >> (i_)) & 1u, ra_[i_]);                                         \
+      uint2 ph_[2];                                                                                  \
+      split_f16x2(make_float4(v_.x * xscale, v_.y * xscale, v_.z * xscale, v_.w * xscale), ph_);     \
+      pl[0] = ph_[0]; pl[NP - 1] = ph_[1];                                                           \
+    } else {                                                                                         \
+      split_planes<NP>(sel4(((ok_) >> (i_)) & 1u, ra_[i_]), pl);                                     \
+    }                                                                                                \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                                \
       *reinterpret_cast<uint2*>(As + (buf_) * (NP * S_PLANE) + q2 * S_PLANE + (r0 + 32 * (i_)) * S_ROWB + \
                                 8 * cg) = pl[q2];                                                    \
@@ -262,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
       for (int it = 0; it < RP / 8; ++it) {
         const int row = 8 * it + rr;
         float4 v = *reinterpret_cast<const float4*>(tb + row * 32 + c4);
+        if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
         const int m = m0 + pass * RP + row;
         if (m >= p.M || !nok) continue;
         if (partial) {
@@ -293,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
       const int m = m0 + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * lk;
       if (m >= p.M) continue;
       float v = acc[tm][e];
+      if (HP) v *= oscale;
       if (partial) {
         Wb[(long long)m * p.N + n] = v;
       } else {
@@ -310,6 +344,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __rest
 // forward: n = Cout, k = Cin ; data-gradient: n = Cin, k = Cout, taps flipped.  Out-of-range (n, k) are zero;
 // the step count is even (2 per 32-wide chunk) so a chunk never reads past the image.
 #ifndef OSM_ACT_F16
+// f16x3 image, pass 1: max |w| as the bit pattern of a non-negative float (atomicMax on uint; pack time only)
+__global__ void wmax_kernel(const float* __restrict__ w, unsigned* __restrict__ wmax, long long total) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = osm::wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(wmax, __float_as_uint(m));
+}
 __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout,
                                          int Cin, int k, int np, int dgrad) {
   const int N = dgrad ? Cin : Cout;
@@ -317,6 +359,15 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned s
   const int nt32 = (N + 31) / 32;
   const int ksteps = 2 * ((K + 31) / 32);
   const long long per_plane = (long long)k * k * ksteps * nt32 * 512;
+  // np = 4 (f16x3): 2^ew = the power of two that brings max |w| (left behind the planes by wmax_kernel, copied to word [1] by
+  // wino_scale_word_kernel stage 0) to [2^13, 2^14); stage 1 of that kernel rewrites word [0] as the scale
+  float wsc = 1.f;
+  if (np == 4) {
+    const float mx = __uint_as_float(*reinterpret_cast<const unsigned*>(out + 2 * per_plane + 2));
+    int e2 = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e2); e2 = min(14 - e2, 100); }
+    wsc = ldexpf(1.f, e2);
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_plane;
        i += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
@@ -342,6 +393,13 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, unsigned s
     }
     if (np == 1) {      // wfmt 1: ONE plane of IEEE half (RNE) for the fp16-arithmetic family
       out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+      continue;
+    }
+    if (np == 4) {      // wfmt 4 (f16x3): two IEEE-half planes of w * 2^ew
+      const float rs = v * wsc;
+      const _Float16 h0 = (_Float16)rs;
+      out[i] = __builtin_bit_cast(unsigned short, h0);
+      out[per_plane + i] = __builtin_bit_cast(unsigned short, (_Float16)(rs - (float)h0));
       continue;
     }
     float rr = v;

@@ -42,6 +42,7 @@ struct GNArgs {
   float* fin;           // finalized statistics written by the one-launch kernel / the fused apply prologue
   unsigned* maxabs;     // optional [B][OSM_MAXABS_PARTS] partial max |out| (bit patterns), the contract of osm_maxabs: the
                         // f16x3 convolution that reads `out` next needs its range and this pass holds every value
+  unsigned* maxabs_in;  // the same for the INPUT x, from the forward statistics pass (a 1x1 f16x3 convolution reads x itself)
   double n;             // elements per group
   int fuse;             // apply kernels: combine the chunk partials in the prologue (no finalize launch)
   long long ldx, lddy, ldo, ldadd, ldadd2, ldf;
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
   float s1[NJMAX], s2[NJMAX];
 #pragma unroll
   for (int j = 0; j < NJMAX; ++j) s1[j] = s2[j] = 0.f;
+  float imax = 0.f;
+  unsigned inan = 0u;
 
   if (tr < rowT) {
 #pragma unroll
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
           if (MODE == 0) {
             s1[j] += xv[e];
             s2[j] += xv[e] * xv[e];
+            const float fx = (float)xv[e];
+            imax = fmaxf(imax, fabsf(fx));
+            if (fx != fx) inan = 0x7fc00000u;
           } else {
             float xh, z;
             gn_fwd_elem(xv[e], mean, rstd, ga[e], be[e], a.film != nullptr, sc[e], sh[e], xh, z);
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a) {
     o[0] = t1;
     o[1] = t2;
   }
+  if (MODE == 0 && a.maxabs_in) gn_publish_max(a.maxabs_in, b, chunk, gridDim.x, imax, inan);
 }
 
 // one wave per (b, g): lanes stride over the chunk partials, fp64 combine, shuffle reduce.
@@ -660,6 +667,14 @@ extern "C" int osm_gn_nchunk(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW)
 #endif
 static int gn_nchunk_of(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
 // maxabs_out of the apply entry points: [B][OSM_MAXABS_PARTS] partial max |out| (fp32 family; the grid must fit the slots)
+static int set_maxabs_in(GNArgs& a, float* maxabs_in, const char* who) {
+  if (!maxabs_in) return OSM_OK;
+  OSM_REQUIRE(!OSM_ACT_IS_F16, "%s: maxabs_in belongs to the fp32 family", who);
+  OSM_REQUIRE(gn_nchunk_of(a.HW) <= OSM_MAXABS_PARTS && a.HW > GN_SMALL_HW,
+              "%s: maxabs_in needs the chunked statistics pass (HW > %d) and osm_gn_nchunk(HW) <= OSM_MAXABS_PARTS", who, GN_SMALL_HW);
+  a.maxabs_in = reinterpret_cast<unsigned*>(maxabs_in);
+  return OSM_OK;
+}
 static int set_maxabs(GNArgs& a, float* maxabs_out, const char* who) {
   if (!maxabs_out) return OSM_OK;
   OSM_REQUIRE(!OSM_ACT_IS_F16, "%s: maxabs_out belongs to the fp32 family", who);
@@ -776,7 +791,7 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
 
 extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C, int G,
                           float eps, float* part, float* stats, const float* gamma, const float* beta,
-                          const float* film, long long ldfilm, int silu, float* maxabs_out, void* stream) {
+                          const float* film, long long ldfilm, int silu, float* maxabs_out, float* maxabs_in, void* stream) {
   OSM_REQUIRE(x && y && part && stats && gamma && beta, "osm_gn_fwd: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_fwd: ldfilm smaller than 2*C");
   GNArgs a{};
@@ -785,6 +800,7 @@ extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* 
   int rc = check_common(a, "osm_gn_fwd");
   if (rc) return rc;
   if ((rc = set_maxabs(a, maxabs_out, "osm_gn_fwd"))) return rc;
+  if ((rc = set_maxabs_in(a, maxabs_in, "osm_gn_fwd"))) return rc;
   if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = stats;

@@ -57,6 +57,11 @@ class _Conv:
                 and _winograd_on() and ops.conv_winograd_ok(16, 16, self.cin, self.cout, 3, wfmt) \
                 and ops.conv_winograd_ok(16, 16, self.cout, self.cin, 3, wfmt):
             self.wwf, self.wwd = ops.pack_conv_weight_winograd(w, wfmt=self.wwfmt)
+        # 1x1 layers of an f16x3 model: a two-half-plane image next to the bf16x6 one (used at H W >= 4096, where the kernel is
+        # bound by its matrix work and the range of the input comes for free from the pass that wrote or normalised it)
+        self.wf16 = self.wd16 = None
+        if self.k == 1 and self.wwfmt == 4 and os.environ.get("OSM_F16X3_1X1", "1") != "0":
+            self.wf16, self.wd16 = ops.pack_conv_weight(w, wfmt=4)
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
 
 
@@ -324,6 +329,8 @@ class UNetEngine:
                 if xm is None:
                     xm = self._xmax_slot(ws_slot)
                     ops.maxabs(x, self.B, xm)
+        elif cv.wf16 is not None and xmax is not None and H * W >= 4096 and (H * W) % 128 == 0:
+            wfmt, wimg, xm = 4, (cv.wd16 if dgrad else cv.wf16), xmax     # 1x1 f16x3: only where the range is already known
         sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, wfmt, gn_table is not None)
         ws = None
         if sk > 1:
@@ -388,7 +395,7 @@ class UNetEngine:
         return self._gn_fusable(cv, hw) or H * W > 1024
 
     def _gn_conv(self, x: Mat, norm: _Norm, st, cv: _Conv, y: Mat, hw, film=None, res: Optional[Mat] = None,
-                 cs=None, table=None, stat=None):
+                 cs=None, table=None, stat=None, xin_max=None):
         """y = conv3x3(SiLU(GN(+FiLM)(x))) (+res).  Where the halo-tile kernel runs (split-bf16 weights, W >= 16,
         H >= 8) the normalised tensor is never materialised: statistics -> per-channel table -> applied by the
         convolution while it stages its input; otherwise GN writes a scratch tensor first.
@@ -419,7 +426,10 @@ class UNetEngine:
             ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
             ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
         else:
-            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
+            # xin_max: the caller asked for max |x| of the INPUT as well (it has checked that this branch is the one taken)
+            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True, maxabs=xm, maxabs_in=xin_max)
+            xin_max = None
+        assert xin_max is None, "max |x| of the input was requested on a path that has no statistics pass over x"
         return self._conv(a, cv, y, hw, res=res, stat=stat, xmax=xm)
 
     # ------------------------------------------------------------------ ResBlock
@@ -461,10 +471,16 @@ class UNetEngine:
             # the per-channel GroupNorm tables are kept: the data-gradient convolutions fold the GroupNorm-backward
             # reductions into their epilogues with them (see _res_bwd)
             tab1 = self._small(B * 4 * blk.cin) if (self.fuse_stats_bwd and self._bwd_stats_ok(blk.c1, hw)) else None
-            if blk.skip is not None:
-                self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2")
+            # the skip connection's 1x1 convolution reads x itself: where it has an f16x3 image, the statistics pass of the first
+            # GroupNorm (which reads every element of x anyway) leaves max |x| behind for it -- so it runs AFTER that pass
+            xin = None
+            if blk.skip is not None and blk.skip.wf16 is not None and HW >= 4096 and HW % 128 == 0 and tab1 is None and \
+                    not self._gn_fusable(blk.c1, hw) and ops.gn_nchunk(HW) <= ops.MAXABS_PARTS:
+                xin = self._xmax_slot("skip")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
-                                stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None)
+                                stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None, xin_max=xin)
+            if blk.skip is not None:
+                self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2", xmax=xin)
         film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
         st2 = self._small(B * G * 2)
         if blk.skip is not None:
@@ -482,8 +498,9 @@ class UNetEngine:
         H, W = s["hw"]
         ho, wo = s["hwo"]
         M, Mo = B * H * W, B * ho * wo
-        if blk.skip is not None:      # skip-path gradient
-            self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2")
+        if blk.skip is not None:      # skip-path gradient (f16x3 where max |dy| was left behind by the pass that wrote dy)
+            self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2",
+                       xmax=self._xmax_reg.get((dy.p, dy.rows, dy.ld)))
         dh2 = self._scr("a", Mo, blk.cout)
         # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
         # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
@@ -797,8 +814,12 @@ class UNetEngine:
         self._conv(do, self.out_conv, da, (H, W), dgrad=True)
         dy = self._buf(B * H * W, self.h_last.cols, dtype=f32)
         gst = self._small(B * G * 2)
+        xmo = None          # max |dy| for the f16x3 data-gradient convolutions of the last ResBlock (3x3 and skip)
+        if self.conv_mode == "f16x3" and ops.gn_nchunk(H * W) <= ops.MAXABS_PARTS:
+            xmo = self._small(B * ops.MAXABS_PARTS)
+            self._xmax_reg[(dy.p, dy.rows, dy.ld)] = xmo
         ops.gn_bwd(self.h_last, da, dy, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, self.gn_part,
-                   gst, silu=True)
+                   gst, silu=True, maxabs=xmo)
         if self.adt != f32:
             dy_h = self._buf(B * H * W, self.h_last.cols)
             ops.convert(dy, dy_h)

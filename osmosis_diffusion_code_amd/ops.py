@@ -97,7 +97,7 @@ def maxabs(x: Mat, B: int, out: torch.Tensor):
 
 # conv arithmetic modes: weight-image format code of the C ABI
 # "f16": activations AND weights in IEEE half, fp32 accumulation (the reference's use_fp16): fp16-storage family
-WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}   # 4: Winograd images only
+WFMT = {"f32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}   # 4: Winograd images and 1x1 layers
 WINOGRAD = 0x10   # OSM_WFMT_WINOGRAD: the weight image is in the Winograd F(2x2, 3x3) domain (pack_conv_weight_winograd)
 
 
@@ -261,11 +261,12 @@ def gn_apply(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, film=N
 
 
 def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, film=None, silu=True, eps: float = 1e-5,
-           maxabs=None):
-    """statistics (written to `stats`) + normalise/FiLM/SiLU; a single launch for HW <= 1024."""
+           maxabs=None, maxabs_in=None):
+    """statistics (written to `stats`) + normalise/FiLM/SiLU; a single launch for HW <= 256.
+    maxabs_in: [B][MAXABS_PARTS], the partial max |x| of the INPUT (from the statistics pass; HW > 256 only)."""
     fp, ldf = _film(film)
     call("osm_gn_fwd" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta),
-         fp, ldf, int(silu), ptr(maxabs), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film, maxabs))
+         fp, ldf, int(silu), ptr(maxabs), ptr(maxabs_in), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film, maxabs, maxabs_in))
 
 
 def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5):
