@@ -476,8 +476,8 @@ def main():
                                "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime (t <= 0.3T)",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
                    "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode,
-                   "conv_arithmetic_note": ("f16x3: Winograd 3x3 layers multiply ~22-bit operands (two IEEE-half terms per fp32 value after "
-                                            "a power-of-two scaling) with three fp16 MFMAs per product and fp32 accumulation; every other "
+                   "conv_arithmetic_note": ("f16x3: the Winograd 3x3 layers and the 1x1 layers at >= 64x64 multiply ~22-bit operands (two IEEE-half terms per fp32 "
+                                            "value after a power-of-two scaling) with three fp16 MFMAs per product and fp32 accumulation; every other "
                                             "contraction is bf16x6 (exact three-term bf16 split, six MFMAs).  Tests hold both to the same "
                                             "4e-6 against fp64; `same_workload_bf16x6` is this run in bf16x6 everywhere")
                    if args.conv_mode == "f16x3" else None, "parallelism": f"images[rank::{world}] (no collective on the path)",
