@@ -39,13 +39,18 @@ template <int PW, int PH = 8> struct HaloGeom {
 // NARROW (8 x 16 patches only): layers with <= 32 output columns (the network's head: 256 -> 8, and the stem's data-gradient:
 // 256 -> 4).  The four waves then split the four row blocks of the patch instead of the (empty) column tiles: 108 instead of
 // 432 MFMAs per wave and slab.
-template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8, bool NARROW = false>
+// NT = 32-column tiles per wave (1, or 2 on 8 x 16 patches): with ONE MFMA per product (the fp16 family) every A fragment read from
+// LDS feeds a single MFMA per column tile -- 1 KB of LDS reads per MFMA, i.e. the CU's whole LDS bandwidth at the matrix rate.  Two
+// column tiles per wave (workgroup = 128 rows x 256 columns, 8 accumulators per wave) halve that; the weight-fragment traffic per
+// MFMA stays what it was (a fragment still feeds the 4 row blocks).
+template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8, bool NARROW = false, int NT = 1>
 __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
   constexpr int B_RING = BR, B_DIST = BR - 1;
   static_assert(PH == 8, "patches are 8 x 8 or 8 x 16 (the 16 x 16 variant of round 2 lost everywhere but one layer and was removed)");
   static_assert(!NARROW || (PW == 16 && PH == 8), "the narrow variant works on 8 x 16 patches");
+  static_assert(NT == 1 || (NT == 2 && PW == 16 && !NARROW), "two column tiles per wave: 8 x 16 patches only");
   using GEO = HaloGeom<PW, PH>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
                 RB = GEO::RB;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   const int tile_n = id % p.ntiles, tile_m = id / p.ntiles;
   const int tpx = (p.W + PW - 1) / PW, tpy = (p.H + PH - 1) / PH;
   const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
-  const int x0 = tx * PW, y0 = ty * PH, n0 = tile_n * BN;
+  const int x0 = tx * PW, y0 = ty * PH, n0 = tile_n * (BN * NT);
 
   const int ks = blockIdx.y;
   const int nslab = (p.K + BK - 1) / BK;
@@ -90,8 +95,9 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 
   // ---- B fragment addressing (image [plane][tap][k16-step][n/32][lane][8])
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int jn = (n0 >> 5) + (NARROW ? 0 : wave_u);
+  const int jn = (n0 >> 5) + (NARROW ? 0 : NT * wave_u);      // this wave's first 32-column tile
   const bool b_ok = jn < p.nt32;
+  const unsigned b_nt = (NT == 2 && jn + 1 < p.nt32) ? 1024u : 0u;   // byte offset of its second tile (or the first again)
   const unsigned b_lane = b_ok ? (unsigned)((jn * 64 + lane) * 16) : (unsigned)(lane & 1) * 16u;
   // uniform 32-bit byte offsets (the largest image, 2048 -> 1024 channels, is 113 MB)
   const unsigned b_step = b_ok ? (unsigned)p.nt32 * 1024u : 0u;
@@ -104,9 +110,9 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   const __amdgpu_buffer_rsrc_t brsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbaseB0), 0, 0x7fffffff, 0x00020000);
 
-  f32x16 acc[RB];
+  f32x16 acc[RB * NT];     // [column tile][row block]
 #pragma unroll
-  for (int i = 0; i < RB; ++i)
+  for (int i = 0; i < RB * NT; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   gm = gr = gg = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
   unsigned okm = 0;
-  uint4 bq[B_RING][NP];   // rolling weight-fragment sets: step g lives in bq[g % B_RING]
+  uint4 bq[B_RING][NT][NP];   // rolling weight-fragment sets: step g lives in bq[g % B_RING]
 
 #define OSM_H_LOAD_A(cc_)                                                                  \
   {                                                                                        \
@@ -143,9 +149,10 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 #define OSM_H_LOAD_B(slot_, cc_, s_)                                                       \
   {                                                                                        \
     const unsigned so_ = (unsigned)((s_) >> 1) * b_tap + (unsigned)(2 * (cc_) + ((s_) & 1)) * b_step; \
-    _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
-      bq[slot_][q2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(    \
-          brsrc, (int)b_lane, (int)(so_ + q2 * b_plane), 0));                              \
+    _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2)                                      \
+      _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                    \
+        bq[slot_][t2][q2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128( \
+            brsrc, (int)b_lane, (int)(so_ + q2 * b_plane + (unsigned)t2 * b_nt), 0));     \
   }
 // A fragments of half-step hs_ (step hs_/2, row blocks 2 (hs_&1) and 2 (hs_&1) + 1)
 #define OSM_H_READ(f_, hs_)                                                                \
@@ -159,10 +166,11 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   }
 #define OSM_H_MMA(f_, slot_, h_)                                                           \
   _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
-    _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb) {                          \
-      acc[2 * (h_)] = mma16<NP>(f_[0][pa], bq[slot_][pb], acc[2 * (h_)]);                  \
-      acc[2 * (h_) + 1] = mma16<NP>(f_[1][pa], bq[slot_][pb], acc[2 * (h_) + 1]);          \
-    }
+    _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
+      _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2) {                                  \
+        acc[RB * t2 + 2 * (h_)] = mma16<NP>(f_[0][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_)]);         \
+        acc[RB * t2 + 2 * (h_) + 1] = mma16<NP>(f_[1][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_) + 1]); \
+      }
 
   if (kc1 > kc0) {
     OSM_H_LOAD_A(kc0);
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
           for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
             for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)
-              acc[cnt & 1] = mma16<NP>(fx[0][pa], bq[s % B_RING][pb], acc[cnt & 1]);
+              acc[cnt & 1] = mma16<NP>(fx[0][pa], bq[s % B_RING][0][pb], acc[cnt & 1]);
         }
       } else if constexpr (PW == 16) {
         OSM_H_READ(fx, 0)
@@ -263,7 +271,9 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
       static_assert(LDSB >= 4 * RP * 128 && (RB * 32) % RP == 0, "transpose slices must fit the staging LDS");
       float* tb = reinterpret_cast<float*>(As) + wave * (RP * 32);
       const int c4 = 4 * (lane & 7), rr = lane >> 3;
-      const int nb = n0 + 32 * wave + c4;
+#pragma unroll
+      for (int t2 = 0; t2 < NT; ++t2) {
+      const int nb = n0 + 32 * (NT * wave + t2) + c4;
       const bool nok = nb < p.N;
       float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!partial_ && p.bias && nok) bv4 = *reinterpret_cast<const float4*>(p.bias + nb);
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
           for (int e = 0; e < 16; ++e) {
             const int R0 = 32 * tm + 8 * (e >> 2);                       // first row of this element's 8-row group
             if (R0 / RP != pass) continue;                               // compile-time
-            tb[(R0 % RP + (e & 3) + 4 * lk) * 32 + lr] = acc[tm][e];
+            tb[(R0 % RP + (e & 3) + 4 * lk) * 32 + lr] = acc[RB * t2 + tm][e];
           }
 #pragma unroll
         for (int it = 0; it < RP / 8; ++it) {
@@ -336,8 +346,13 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
           *reinterpret_cast<float4*>(o + p.N) = make_float4(q2[0], q2[1], q2[2], q2[3]);
         }
       }
+      }   // column tile t2
       return;
     }
+  }
+  static_assert(NT == 1 || true, "");
+  if constexpr (NT == 2) {   // (two column tiles per wave are launched on aligned shapes only: launch())
+    return;
   }
   // scalar form (unaligned / odd shapes, and the narrow variant)
   const bool partial = p.splitk > 1;

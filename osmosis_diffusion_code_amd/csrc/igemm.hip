@@ -561,7 +561,27 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     else if (wide)      { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 16, 3); else OSM_HALO_LAUNCH(NP_, false, 16, 3); } \
     else                { if (p.gn_table) OSM_HALO_LAUNCH(NP_, true, 8, 3);  else OSM_HALO_LAUNCH(NP_, false, 8, 3); }
 #ifdef OSM_ACT_F16
+    // two column tiles per wave (128 rows x 256 columns per workgroup) where the layer still fills the chip with them: the
+    // one-MFMA-per-product arithmetic is bound by its LDS fragment reads (conv3_halo.inc.h, NT).  Aligned shapes only (its
+    // epilogue has the vector form only)
+    const char* nt2_env = std::getenv("OSM_HALO_NT2");      // 0: off, 1 (default): where it fills the chip, 2: wherever the shape allows (tests)
+    const int nt2_mode = nt2_env ? atoi(nt2_env) : 1;
+    const auto al = [](const void* q_, unsigned bytes) { return (reinterpret_cast<unsigned long long>(q_) & (bytes - 1)) == 0; };
+    const bool nt2 = nt2_mode > 0 && wide && !narrow && p.N % 256 == 0 &&
+                     (nt2_mode == 2 || (long long)p.mtiles * (p.N / 256) * p.splitk >= 512) &&
+                     (p.splitk > 1 ? al(p.ws, 16)
+                                   : ((p.ldc & 3) == 0 && al(p.C, 4 * ACT_B) && (!p.bias || al(p.bias, 16)) &&
+                                      (!p.res || ((p.ldr & 3) == 0 && al(p.res, 4 * ACT_B))) &&
+                                      (!p.colsum || p.stat_mode == 1 ||
+                                       ((p.ld_sx & 3) == 0 && al(p.stat_x, 4 * ACT_B) && al(p.stat_table, 16)))));
+    if (nt2) {
+      p.ntiles = p.N / 256;
+      const dim3 g3(p.mtiles * p.ntiles, p.splitk, 1);
+      if (p.gn_table) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<1, true, 16, 3, 8, false, 2>), g3, dim3(256), 0, st, p.A, Bp, p);
+      else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<1, false, 16, 3, 8, false, 2>), g3, dim3(256), 0, st, p.A, Bp, p);
+    } else {
     OSM_HALO_PICK(1)
+    }
 #else
     if (wfmt == 3) { OSM_HALO_PICK(3) } else { OSM_HALO_PICK(2) }
 #endif
