@@ -60,14 +60,14 @@ __device__ __forceinline__ void gn_fwd_elem(float x, float mean, float rstd, flo
 // workgroup `wg` of `nwg` (<= OSM_MAXABS_PARTS) publishes its partial max |out| of image b: slot wg, and zeros in the slots no
 // workgroup owns (every slot is rewritten on every call: no clearing, no atomics).  Called by ALL threads of the workgroup.
 __device__ __forceinline__ void gn_publish_max(unsigned* __restrict__ maxabs, int b, int wg, int nwg, float m, unsigned nanbits) {
-  __shared__ unsigned wmax[4];
+  __shared__ unsigned wmax[16];
   unsigned bits = __float_as_uint(m) | nanbits;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bits;
   __syncthreads();
   if (threadIdx.x == 0) {
-    bits = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) bits = max(bits, wmax[w]);
     unsigned* sl = maxabs + (long long)b * OSM_MAXABS_PARTS;
     for (int s2 = wg; s2 < OSM_MAXABS_PARTS; s2 += nwg) sl[s2] = s2 == wg ? bits : 0u;
   }
@@ -586,6 +586,167 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GNArgs a) {
   if (a.maxabs) gn_publish_max(a.maxabs, b, g, gridDim.x, omax, onan);
 }
 
+// Mid-size tensors (32 x 32 with 512 / 1024 channels, 64 x 64 with 256): three launches of the chunked path (reduce, finalize,
+// apply: 15-18 us, ~36 of them per step) are launch latency, and the two-pass one-launch kernel above walks 16 dependent sweeps.
+// Here one 512-thread workgroup per (image, group) loads its WHOLE slice -- <= 32768 elements = NV <= 16 float4 per thread, and dy
+// as well in the backward -- into REGISTERS with every load in flight at once, reduces, and applies from the registers: one
+// launch, one read of each operand.  512 % (gs / 4) == 0, so a thread's channel vector (gamma, beta, FiLM) is fixed.
+// MODE 0: stats -> a.fin, y = act(GN(x)) (+ max |x| -> a.maxabs_in).   MODE 1: (m1, m2) -> a.fin, dx = dGN(dy) (+ addends).
+template <int MODE, int NV>
+__global__ __launch_bounds__(512) void gn_reg_kernel(GNArgs a) {
+  __shared__ double red[2][8];
+  __shared__ float bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int vpg = a.gs >> 2;
+  const int tv = tid % vpg, p0 = tid / vpg, pstep = 512 / vpg;
+  const int c = g * a.gs + 4 * tv;
+  const bool film = a.film != nullptr;
+  const long long row0 = (long long)b * a.HW;
+  float4 xr[NV], dr[MODE == 1 ? NV : 1];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = p0 + k * pstep;
+    const bool live = p < a.HW;
+    const long long row = row0 + (live ? p : 0);
+    const float4 t = osm::ld4(a.x + row * a.ldx + c);
+    xr[k] = live ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 1) {
+      const float4 u = osm::ld4(a.dy + row * a.lddy + c);
+      dr[k] = live ? u : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float ga[4], be[4], sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ga[e] = a.gamma[c + e];
+    be[e] = a.beta[c + e];
+    sc[e] = film ? a.film[(long long)b * a.ldf + c + e] : 0.f;
+    sh[e] = film ? a.film[(long long)b * a.ldf + a.C + c + e] : 0.f;
+  }
+  float mean = 0.f, rstd = 0.f;
+  if (MODE == 1) {
+    mean = a.stats[(b * a.G + g) * 2];
+    rstd = a.stats[(b * a.G + g) * 2 + 1];
+  }
+  float s1 = 0.f, s2 = 0.f, imax = 0.f;
+  unsigned inan = 0u;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float xv[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1 += xv[e];
+        s2 += xv[e] * xv[e];
+        imax = fmaxf(imax, fabsf(xv[e]));
+        if (xv[e] != xv[e]) inan = 0x7fc00000u;
+      }
+    } else {
+      const float dv[4] = {dr[k].x, dr[k].y, dr[k].z, dr[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh, z;
+        gn_fwd_elem(xv[e], mean, rstd, ga[e], be[e], film, sc[e], sh[e], xh, z);
+        float dz = dv[e] * (a.silu ? osm::dsilu_f(z) : 1.0f);
+        if (film) dz *= (1.0f + sc[e]);
+        const float dxh = dz * ga[e];
+        s1 += dxh;
+        s2 += dxh * xh;
+        if (e == 0) dr[k].x = dxh; else if (e == 1) dr[k].y = dxh; else if (e == 2) dr[k].z = dxh; else dr[k].w = dxh;   // keep dxh
+      }
+    }
+  }
+  double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d1 += __shfl_xor(d1, o, 64);
+    d2 += __shfl_xor(d2, o, 64);
+  }
+  if (lane == 0) {
+    red[0][wave] = d1;
+    red[1][wave] = d2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      t1 += red[0][w];
+      t2 += red[1][w];
+    }
+    float o0, o1;
+    if (MODE == 0) {
+      const double mu = t1 / a.n;
+      double var = t2 / a.n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      o0 = (float)mu;
+      o1 = (float)(1.0 / sqrt(var + (double)a.eps));
+    } else {
+      o0 = (float)(t1 / a.n);
+      o1 = (float)(t2 / a.n);
+    }
+    a.fin[(b * a.G + g) * 2] = o0;
+    a.fin[(b * a.G + g) * 2 + 1] = o1;
+    bc[0] = o0;
+    bc[1] = o1;
+  }
+  __syncthreads();
+  const float q0 = bc[0], q1 = bc[1];
+  if (MODE == 0) {
+    mean = q0;
+    rstd = q1;
+  }
+  float omax = 0.f;
+  unsigned onan = 0u;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = p0 + k * pstep;
+    if (p >= a.HW) continue;
+    const float xv[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+    float ov[4];
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh, z;
+        gn_fwd_elem(xv[e], mean, rstd, ga[e], be[e], film, sc[e], sh[e], xh, z);
+        ov[e] = a.silu ? osm::silu_f(z) : z;
+      }
+    } else {
+      const float dxv[4] = {dr[k].x, dr[k].y, dr[k].z, dr[k].w};      // dxh of the first sweep
+      float av[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.addend) {
+        const float4 w = osm::ld4(a.addend + (row0 + p) * a.ldadd + c);
+        av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
+      }
+      if (a.addend2) {
+        const float4 w = osm::ld4(a.addend2 + (row0 + p) * a.ldadd2 + c);
+        av[0] += w.x; av[1] += w.y; av[2] += w.z; av[3] += w.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        ov[e] = rstd * (dxv[e] - q0 - xh * q1) + av[e];
+      }
+    }
+    if (a.maxabs) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = (float)(act_t)ov[e];
+        omax = fmaxf(omax, fabsf(sv));
+        if (sv != sv) onan = 0x7fc00000u;
+      }
+    }
+    osm::st4(a.out + (row0 + p) * a.ldo + c, make_float4(ov[0], ov[1], ov[2], ov[3]));
+  }
+  if (a.maxabs) gn_publish_max(a.maxabs, b, g, gridDim.x, omax, onan);
+  if (MODE == 0 && a.maxabs_in) {
+    __syncthreads();            // gn_publish_max's staging words are reused
+    gn_publish_max(a.maxabs_in, b, g, gridDim.x, imax, inan);
+  }
+}
+
+
 constexpr int GN_SMALL_HW = 256;   // measured: 32 x 32 tensors are faster on the chunked three-launch path
 
 bool use_vec4(const GNArgs& a) {
@@ -649,6 +810,30 @@ int run_apply(GNArgs& a, hipStream_t st) {
 
 bool small_path(const GNArgs& a) {
   return a.HW <= GN_SMALL_HW && use_vec4(a) && (a.C / a.G) % 4 == 0 && (a.C / a.G) <= 1024;
+}
+
+// register-resident one-launch kernel: (HW, gs) whose group slice fits 512 threads x 16 float4 and whose channel vector is fixed
+// per thread; the chunked path keeps everything else (OSM_GN_REG=0: off)
+bool reg_path(const GNArgs& a, int mode) {
+  static const bool on = [] { const char* e = std::getenv("OSM_GN_REG"); return !(e && e[0] == '0'); }();
+  const int gs = a.C / a.G;
+  if (!(on && a.out && a.HW > GN_SMALL_HW && use_vec4(a) && gs % 4 == 0)) return false;
+  const int vpg = gs / 4;
+  // (the backward holds x and dy: 16 vectors of each spill, 8 do not)
+  return 512 % vpg == 0 && (long long)a.HW * vpg <= 512LL * (mode == 1 ? 8 : 16) && a.G <= OSM_MAXABS_PARTS;
+}
+
+template <int MODE>
+int run_reg(GNArgs& a, float* finalized, hipStream_t st) {
+  a.gs = a.C / a.G;
+  a.fin = finalized;
+  a.n = (double)a.HW * a.gs;
+  const long long items = (long long)a.HW * (a.gs / 4);
+  const dim3 grid(a.G, a.B);
+  if (items <= 512 * 4) hipLaunchKernelGGL((gn_reg_kernel<MODE, 4>), grid, dim3(512), 0, st, a);
+  else if (items <= 512 * 8 || MODE == 1) hipLaunchKernelGGL((gn_reg_kernel<MODE, 8>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((gn_reg_kernel<MODE, (MODE == 1 ? 8 : 16)>), grid, dim3(512), 0, st, a);
+  return osm::check_launch("gn_reg_kernel");
 }
 
 template <int MODE>
@@ -782,6 +967,7 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
   if (rc) return rc;
   if ((rc = set_maxabs(a, maxabs_out, "osm_gn_bwd"))) return rc;
   if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
+  if (reg_path(a, 1)) return run_reg<1>(a, gstats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = gstats;
   rc = run_reduce<1>(a, gstats, (hipStream_t)stream, !a.fuse);
@@ -802,6 +988,7 @@ extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* 
   if ((rc = set_maxabs(a, maxabs_out, "osm_gn_fwd"))) return rc;
   if ((rc = set_maxabs_in(a, maxabs_in, "osm_gn_fwd"))) return rc;
   if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
+  if (reg_path(a, 0)) return run_reg<0>(a, stats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = stats;
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, !a.fuse);

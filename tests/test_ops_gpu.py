@@ -126,7 +126,10 @@ def test_gemm_asymmetric_identity(ops):
 @pytest.mark.parametrize("C,HW,film,silu", [(64, 64, True, True), (256, 256, False, True),
                                              (96, 100, True, False), (32, 64, False, False),
                                              (1536, 64, True, True), (2048, 16, False, True),
-                                             (512, 1024, True, True), (128, 4096, True, True)])
+                                             (512, 1024, True, True), (128, 4096, True, True),
+                                             # the register-resident one-launch kernel: 16 vectors per thread (forward only), a group
+                                             # width that does not divide 512 (chunked path), 64 x 64 with 256 channels
+                                             (1024, 1024, False, True), (768, 1024, True, True), (256, 4096, True, False)])
 def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
     g = torch.Generator().manual_seed(C + HW)
     B, G = 2, 32

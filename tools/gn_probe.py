@@ -21,7 +21,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--shapes", nargs="*", default=None)
-    ap.add_argument("--sync", action="store_true", help="in-kernel finalize (arrival counters)")
     a = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes] if a.shapes else SHAPES
     dev = torch.device("cuda:0")
@@ -44,12 +43,11 @@ def main():
         stats = torch.empty(B * G * 2, device=dev)
         gstats = torch.empty(B * G * 2, device=dev)
         mx = torch.empty(B * ops.MAXABS_PARTS, device=dev, dtype=torch.int32)
-        sync = torch.zeros(B, device=dev, dtype=torch.int32) if a.sync else None
         ops.gn_stats(ops.Mat.of(sets[0][0]), B, HW, G, part, stats)
 
         def fwd(s):
             x, dy, dx, y = s
-            ops.gn_fwd(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, part, stats, gamma, beta, maxabs=mx, sync=sync)
+            ops.gn_fwd(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, part, stats, gamma, beta, maxabs=mx)
 
         def apply(s):
             x, dy, dx, y = s
@@ -58,7 +56,7 @@ def main():
         def bwd(s):
             x, dy, dx, y = s
             ops.gn_bwd(ops.Mat.of(x), ops.Mat.of(dy), ops.Mat.of(dx), B, HW, G, stats, gamma, beta, part, gstats,
-                       addend=ops.Mat.of(dx), maxabs=mx, sync=sync)
+                       addend=ops.Mat.of(dx), maxabs=mx)
 
         for name, fn, nb in (("fwd", fwd, 3), ("apply", apply, 2), ("bwd", bwd, 6)):
             for s in sets[:2]:
