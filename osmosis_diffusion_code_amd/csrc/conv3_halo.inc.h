@@ -201,21 +201,32 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
       __syncthreads();
       uint4 fx[2][NP], fy[2][NP];
       if constexpr (NARROW) {
-        // one row block (= this wave's) per step, two accumulators alternate so that consecutive MFMAs are independent
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-          OSM_H_LOAD_B((s + B_DIST) % B_RING, (s + B_DIST < 18 ? c : cn), (s + B_DIST) % 18);
-          const int t_ = s >> 1, kk_ = s & 1;
-          const int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;
-#pragma unroll
-          for (int q2 = 0; q2 < NP; ++q2) fx[0][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE + off_);
-          int cnt = 0;
-#pragma unroll
-          for (int pa = NP - 1; pa >= 0; --pa)
-#pragma unroll
-            for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)
-              acc[cnt & 1] = mma16<NP>(fx[0][pa], bq[s % B_RING][0][pb], acc[cnt & 1]);
+        // one row block (= this wave's) per step, two accumulators alternate so that consecutive MFMAs are independent; the A
+        // fragments of step s + 1 are read before the MFMAs of step s (fx[0] / fx[1] by step parity): with 6 MFMAs per step the LDS
+        // latency was exposed in every step (PMC: matrix pipe 36 % busy, 65 % of the wave cycles waiting)
+#define OSM_H_NREAD(s_)                                                                    \
+        {                                                                                  \
+          constexpr int t_ = (s_) >> 1, kk_ = (s_) & 1;                                    \
+          constexpr int off_ = ((t_ / 3) * HALO_P + (t_ % 3)) * S_ROWB + 32 * kk_;         \
+          _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                \
+            fx[(s_) & 1][q2] = *reinterpret_cast<const uint4*>(a_rd + q2 * H_PLANE + off_); \
         }
+#define OSM_H_NSTEP(s_)                                                                    \
+        {                                                                                  \
+          OSM_H_LOAD_B(((s_) + B_DIST) % B_RING, ((s_) + B_DIST < 18 ? c : cn), ((s_) + B_DIST) % 18); \
+          if ((s_) + 1 < 18) OSM_H_NREAD(((s_) + 1) % 18)                                  \
+          int cnt = 0;                                                                     \
+          _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                           \
+            _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)             \
+              acc[cnt & 1] = mma16<NP>(fx[(s_) & 1][pa], bq[(s_) % B_RING][0][pb], acc[cnt & 1]); \
+          __builtin_amdgcn_sched_barrier(0);                                               \
+        }
+        OSM_H_NREAD(0)
+        OSM_H_NSTEP(0) OSM_H_NSTEP(1) OSM_H_NSTEP(2) OSM_H_NSTEP(3) OSM_H_NSTEP(4) OSM_H_NSTEP(5)
+        OSM_H_NSTEP(6) OSM_H_NSTEP(7) OSM_H_NSTEP(8) OSM_H_NSTEP(9) OSM_H_NSTEP(10) OSM_H_NSTEP(11)
+        OSM_H_NSTEP(12) OSM_H_NSTEP(13) OSM_H_NSTEP(14) OSM_H_NSTEP(15) OSM_H_NSTEP(16) OSM_H_NSTEP(17)
+#undef OSM_H_NSTEP
+#undef OSM_H_NREAD
       } else if constexpr (PW == 16) {
         OSM_H_READ(fx, 0)
 #define OSM_H_STEP(s_)                                                                     \
