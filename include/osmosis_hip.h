@@ -291,6 +291,12 @@ int osm_phys_finalize(const osm_phys_desc* d, const float* part, float* red, flo
 int osm_phys_grad(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
                   const float* red, float* g, void* stream);
 
+/* The inner phi loop of one guided step in one call (measurements.py:266-303 `optimize`, condition_methods.py:109-144):
+ * n_inner x { osm_phys_reduce; osm_phys_finalize with the phi step }, the loss (loss_out [B]) and g = dL/dx0 taken at the phi of the
+ * last iteration, which is stepped afterwards; freeze_phi != 0 (n_inner must be 1): loss and g only, phi untouched. */
+int osm_phys_optimize(const osm_phys_desc* d, const float* x0, const float* y, float* phi, float* part, float* red,
+                      float* loss_out, float* g, int n_inner, int freeze_phi, float* opt_state, void* stream);
+
 /* d_out[B,8,HW]: channels 0..3 = -c1*g, 4..7 = 0   (chain rule through x0 = c0*x - c1*eps) */
 int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream);
 /* condition_methods.py:211-224 + gaussian_diffusion.py:266-268:

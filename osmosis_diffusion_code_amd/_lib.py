@@ -108,6 +108,7 @@ _SIGS = {
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
     "osm_phys_finalize": [C.POINTER(PhysDesc), _P, _P, _P, _I, _P, _P, _P],
     "osm_phys_grad": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P, _P],
+    "osm_phys_optimize": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "osm_posterior_bwd": [_P, _P, _P, _I, _I, _P],
     "osm_guide_update": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     "osm_fetch_coefs": [_P, _I, _P, _I, _P, _P, _I, _P],

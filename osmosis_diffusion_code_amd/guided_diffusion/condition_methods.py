@@ -18,6 +18,7 @@ Two ways in:
 """
 from abc import ABC, abstractmethod
 
+import os
 import torch
 
 from .. import ops
@@ -179,11 +180,14 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         g = g_out if g_out is not None else st["g"]
         x0c, yc = x0.contiguous(), y.contiguous()
         n_inner = 1 if freeze_phi else self.n_iter
-        for it in range(n_inner):
+        # n_inner x { reduce; finalize + phi step }; loss and dL/dx0 use the phi of the LAST iteration, which is stepped afterwards:
+        # one C call enqueues the 2 n_inner + 2 launches (one Python call per launch left the GPU idle between them)
+        if os.environ.get("OSM_PHYS_PY_LOOP", "0") != "1":
+            ops.phys_optimize(d, x0c, yc, phi, part, red, loss, g, n_inner, freeze_phi, opt_state=self._opt_rows(opt, phi))
+            return g.view(x0.shape), loss
+        for it in range(n_inner):          # the same launches, one Python call each (A/B measurements, tests of the entry points)
             ops.phys_reduce(d, x0c, yc, phi, part)
-            last = it == n_inner - 1
-            if last:
-                # loss and dL/dx0 use the phi of THIS iteration; phi is stepped afterwards
+            if it == n_inner - 1:
                 ops.phys_finalize(d, part, red, phi, False, loss)
                 ops.phys_grad(d, x0c, yc, phi, red, g)
                 if not freeze_phi:

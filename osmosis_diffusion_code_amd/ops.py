@@ -364,6 +364,13 @@ def phys_grad(desc: PhysDesc, x0, y, phi, red, g):
          keep=(desc, x0, y, phi, red, g))
 
 
+def phys_optimize(desc: PhysDesc, x0, y, phi, part, red, loss_out, g, n_inner: int, freeze_phi: bool, opt_state=None):
+    """The whole inner phi loop of a guided step (n_inner reduce / finalize pairs, loss and dL/dx0 at the last phi, then its step)
+    enqueued by one call."""
+    call("osm_phys_optimize", C.byref(desc), ptr(x0), ptr(y), ptr(phi), ptr(part), ptr(red), ptr(loss_out), ptr(g), int(n_inner),
+         int(bool(freeze_phi)), ptr(opt_state), _s(), keep=(desc, x0, y, phi, part, red, loss_out, g, opt_state))
+
+
 def posterior_bwd(g, coef, d_out, B, HW):
     call("osm_posterior_bwd", ptr(g), ptr(coef), ptr(d_out), B, HW, _s(), keep=(g, coef, d_out))
 

@@ -39,6 +39,17 @@ def main():
     nfin = sum(1 for r in win if "phys_finalize_kernel" in r[2])
     print(f"window: {len(win)} kernels, {nfin} phys_finalize launches, wall {wall / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms "
           f"({busy / wall:.1%}), idle {(wall - busy) / 1e6:.2f} ms in {len(gaps)} gaps")
+    per = Counter()
+    cnt = Counter()
+    for s0, e0, n in win:
+        k = n.replace("void ", "").replace("(anonymous namespace)::", "")
+        k = k[:k.index("(")] if "(" in k else k
+        per[k] += e0 - s0
+        cnt[k] += 1
+    steps = max(1, round(nfin / 21))
+    print(f"per step (~{steps} steps in the window): kernel time by kernel")
+    for k, v in per.most_common(40):
+        print(f"  {v / 1e6 / steps:7.3f} ms  {cnt[k] / steps:7.1f} launches  {v / cnt[k] / 1e3:7.1f} us  {k}")
     h = Counter()
     for g, _, _ in gaps:
         h[min(int(g / 1000), 20)] += g
