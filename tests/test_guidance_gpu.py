@@ -132,6 +132,37 @@ def test_physics_phi_adam(mods, opname):
     assert float((oper.variables()["phi_inf"].cpu() - torch.tensor([float(u) for u in okw["phi_inf"].split(",")])[None, :, None, None]).abs().max()) > 5e-3
 
 
+@pytest.mark.parametrize("optimizer,freeze", [("sgd", False), ("adam", False), ("sgd", True)])
+def test_phys_optimize_equals_the_launch_by_launch_loop(mods, monkeypatch, optimizer, freeze):
+    """osm_phys_optimize (the inner phi loop enqueued by ONE C call) issues exactly the launches of the per-launch entry points
+    (osm_phys_reduce / finalize / grad, still reachable with OSM_PHYS_PY_LOOP=1): loss, dL/dx0, phi and the Adam state bit-identical."""
+    ops, M, CM = mods
+    opname = "underwater_physical_revised"
+    okw, ckw = OPS[opname]
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 24, 40
+    x0 = (0.6 * torch.randn(B, 4, H, W, generator=g)).to(DEV)
+    y = (torch.rand(B, 3, H, W, generator=g) * 1.6 - 0.8).to(DEV)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OSM_PHYS_PY_LOOP", mode)
+        oper = M.get_operator(opname, device=DEV, batch_size=B, **{**okw, "phi_inf_eta": 1e-3, "phi_a_eta": 1e-3, "phi_b_eta": 1e-3},
+                              optimizer=optimizer)
+        cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), loss_function="norm", loss_weight="depth",
+                                          weight_function="gamma,1.4,1.4,1", scale=ckw["scale"], gradient_x_prev=True,
+                                          gradient_clip=ckw["gradient_clip"], n_iter=20, aux_loss=ckw["aux"], pattern="pcgs")
+        out = []
+        for _ in range(2):      # two guided steps: the optimizer state carries over
+            gx0, loss = cond.loss_grad_x0(x0, y, freeze_phi=freeze)
+            out += [gx0.clone(), loss.clone(), oper.phi.clone()]
+        if cond._opt is not None:
+            out.append(cond._opt.clone())
+        res[mode] = out
+    assert len(res["0"]) == len(res["1"])
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+
+
 def test_unsupported_optimizers_are_refused(mods):
     ops, M, CM = mods
     okw, _ = OPS["haze_physical"]
