@@ -42,7 +42,7 @@ struct FlashArgs {
   float* dqkv;           // [B*T][lddqkv], same column layout as qkv
   long long lddqkv;
   int B, T, heads;
-  int nw;                // waves that split the other sequence axis: min(4, T / 32)
+  int nw;                // waves that split the other sequence axis (nw_of)
   float scale;
 };
 
@@ -81,11 +81,13 @@ __device__ __forceinline__ f32x16 zero16() {
 // ------------------------------------------------------------------------------------------------ forward
 // grid (T / 32, heads, B).  NW = min(4, T / 32) waves split the keys: wave w < NW takes keys [w T/NW, (w+1) T/NW),
 // 32 NSUB at a time (NSUB = 2 independent 32-key logit tiles where the range allows: two MFMA accumulator chains).
-template <int NSUB>
-__global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
-  __shared__ float os[4][DH][33];
-  __shared__ float ms[4][32];
-  __shared__ float ls[4][64];
+// WV = waves per workgroup (4, or 8 = two per SIMD: at B = 1 the grid is one workgroup per CU, so the second wave per SIMD is the
+// only latency hiding there is -- every fragment goes global load -> split -> MFMA with nothing prefetched).
+template <int NSUB, int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_fwd_kernel(FlashArgs a) {
+  __shared__ float os[WV][DH][33];
+  __shared__ float ms[WV][32];
+  __shared__ float ls[WV][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 32, hd = blockIdx.y;
   const long long rb = (long long)blockIdx.z * a.T;
@@ -170,12 +172,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd_kernel(FlashArgs a) {
   __syncthreads();
   const int d = tid & 63, qg = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = qg * 8 + i;
-    const float M = fmaxf(fmaxf(ms[0][q], ms[1][q]), fmaxf(ms[2][q], ms[3][q]));
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int q = qg * (32 / WV) + i;
+    float M = ms[0][q];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) M = fmaxf(M, ms[w][q]);
     float L = 0.f, o = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < WV; ++w) {
       const float sc = __expf(ms[w][q] - M);     // idle waves: exp(-inf) = 0
       L += (ls[w][q] + ls[w][q + 32]) * sc;
       o += os[w][d][q] * sc;
@@ -201,8 +205,9 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
 // dq: grid (T / 32, heads, B): workgroup = 32 queries, waves split the keys.
 //   S^T = K (scale Q)^T, P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);
 //   dq^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
-__global__ __launch_bounds__(256, 1) void flash_bwd_q_kernel(FlashArgs a) {
-  __shared__ float os[4][DH][33];
+template <int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
+  __shared__ float os[WV][DH][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 32, hd = blockIdx.y;
   const long long rb = (long long)blockIdx.z * a.T;
@@ -264,9 +269,10 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_q_kernel(FlashArgs a) {
   __syncthreads();
   const int d = tid & 63, qg = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = qg * 8 + i;
-    const float v = (os[0][d][q] + os[1][d][q]) + (os[2][d][q] + os[3][d][q]);
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int q = qg * (32 / WV) + i;
+    float v = (os[0][d][q] + os[1][d][q]) + (os[2][d][q] + os[3][d][q]);
+    if (WV == 8) v += (os[WV - 4][d][q] + os[WV - 3][d][q]) + (os[WV - 2][d][q] + os[WV - 1][d][q]);
     a.dqkv[(rb + q0 + q) * a.lddqkv + a.q_off + hd * a.hs + d] = v * a.scale;
   }
 }
@@ -274,8 +280,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_q_kernel(FlashArgs a) {
 // dk, dv: grid (T / 32, heads, B): workgroup = 32 keys, waves split the queries.
 //   S = (scale Q) K^T (queries x keys: column = this lane's key), P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q]);
 //   dv^T[d][key] = sum_q dO^T[d][q] P[q][key];   dk^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
-__global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs a) {
-  __shared__ float os[4][2 * DH][33];
+template <int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
+  __shared__ float os[WV][2 * DH][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int k0r = blockIdx.x * 32, hd = blockIdx.y;
   const long long rb = (long long)blockIdx.z * a.T;
@@ -355,17 +362,26 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs a) {
   __syncthreads();
   const int d = tid & 63, kg = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = kg * 8 + i;
-    const float dvv = (os[0][d][k] + os[1][d][k]) + (os[2][d][k] + os[3][d][k]);
-    const float dkv = (os[0][64 + d][k] + os[1][64 + d][k]) + (os[2][64 + d][k] + os[3][64 + d][k]);
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int k = kg * (32 / WV) + i;
+    float dvv = (os[0][d][k] + os[1][d][k]) + (os[2][d][k] + os[3][d][k]);
+    float dkv = (os[0][64 + d][k] + os[1][64 + d][k]) + (os[2][64 + d][k] + os[3][64 + d][k]);
+    if (WV == 8) {
+      dvv += (os[WV - 4][d][k] + os[WV - 3][d][k]) + (os[WV - 2][d][k] + os[WV - 1][d][k]);
+      dkv += (os[WV - 4][64 + d][k] + os[WV - 3][64 + d][k]) + (os[WV - 2][64 + d][k] + os[WV - 1][64 + d][k]);
+    }
     float* row = a.dqkv + (rb + k0r + k) * a.lddqkv + hd * a.hs;
     row[a.v_off + d] = dvv;
     row[a.k_off + d] = dkv * a.scale;
   }
 }
 
-int nw_of(int T) { return T >= 128 ? 4 : (T >= 64 ? 2 : 1); }
+// waves that split the other sequence axis: up to 8 (two per SIMD) from T = 256.  OSM_FLASH_WAVES=4: round 2's four
+int max_waves() {
+  static const int v = [] { const char* e = std::getenv("OSM_FLASH_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  return v;
+}
+int nw_of(int T) { return T >= 256 && T % 256 == 0 && max_waves() == 8 ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1)); }
 
 int check(const osm_attn_desc* d, const char* who) {
   OSM_REQUIRE(d && d->qkv, "%s: null pointer", who);
@@ -397,10 +413,15 @@ extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stre
   FlashArgs a = to_args(d);
   a.lse = lse;
   const dim3 g(d->T / 32, d->heads, d->B);
-  if ((d->T / a.nw) % 64 == 0)
-    hipLaunchKernelGGL(flash_fwd_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(flash_fwd_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, a);
+  const bool two = (d->T / a.nw) % 64 == 0;
+  if (a.nw == 8) {
+    if (two) hipLaunchKernelGGL((flash_fwd_kernel<2, 8>), g, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((flash_fwd_kernel<1, 8>), g, dim3(512), 0, (hipStream_t)stream, a);
+  } else if (two) {
+    hipLaunchKernelGGL((flash_fwd_kernel<2, 4>), g, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((flash_fwd_kernel<1, 4>), g, dim3(256), 0, (hipStream_t)stream, a);
+  }
   return osm::check_launch("flash_fwd_kernel");
 }
 
@@ -415,7 +436,10 @@ extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long
   const long long rows = (long long)d->B * d->T * d->heads;
   hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   const dim3 g(d->T / 32, d->heads, d->B);
-  hipLaunchKernelGGL(flash_bwd_q_kernel, g, dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(flash_bwd_kv_kernel, g, dim3(256), 0, (hipStream_t)stream, a);
+  if (a.nw == 8) hipLaunchKernelGGL(flash_bwd_q_kernel<8>, g, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(flash_bwd_q_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a);
+  // (the dk / dv kernel holds K, V fragments and four accumulators: 368 registers -- it stays at one wave per SIMD)
+  if (a.nw > 4) a.nw = 4;
+  hipLaunchKernelGGL(flash_bwd_kv_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a);
   return osm::check_launch("flash_bwd kernels");
 }
