@@ -817,7 +817,8 @@ bool small_path(const GNArgs& a) {
 bool reg_path(const GNArgs& a, int mode) {
   static const bool on = [] { const char* e = std::getenv("OSM_GN_REG"); return !(e && e[0] == '0'); }();
   const int gs = a.C / a.G;
-  if (!(on && a.out && a.HW > GN_SMALL_HW && use_vec4(a) && gs % 4 == 0)) return false;
+  static const bool small_too = [] { const char* e = std::getenv("OSM_GN_REG_SMALL"); return !(e && e[0] == '0'); }();
+  if (!(on && a.out && (small_too || a.HW > GN_SMALL_HW) && use_vec4(a) && gs % 4 == 0)) return false;
   const int vpg = gs / 4;
   // (the backward holds x and dy: 16 vectors of each spill, 8 do not)
   return 512 % vpg == 0 && (long long)a.HW * vpg <= 512LL * (mode == 1 ? 8 : 16) && a.G <= OSM_MAXABS_PARTS;
@@ -966,8 +967,8 @@ extern "C" int OSM_FN(osm_gn_bwd)(const abi_act_t* x, long long ldx, const abi_a
   int rc = check_common(a, "osm_gn_bwd");
   if (rc) return rc;
   if ((rc = set_maxabs(a, maxabs_out, "osm_gn_bwd"))) return rc;
-  if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
   if (reg_path(a, 1)) return run_reg<1>(a, gstats, (hipStream_t)stream);
+  if (small_path(a)) return run_small<1>(a, gstats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = gstats;
   rc = run_reduce<1>(a, gstats, (hipStream_t)stream, !a.fuse);
@@ -987,8 +988,8 @@ extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* 
   if (rc) return rc;
   if ((rc = set_maxabs(a, maxabs_out, "osm_gn_fwd"))) return rc;
   if ((rc = set_maxabs_in(a, maxabs_in, "osm_gn_fwd"))) return rc;
-  if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
   if (reg_path(a, 0)) return run_reg<0>(a, stats, (hipStream_t)stream);
+  if (small_path(a)) return run_small<0>(a, stats, (hipStream_t)stream);
   a.fuse = gn_nchunk_of(HW) <= GN_FUSE_CHUNKS;
   a.fin = stats;
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, !a.fuse);
