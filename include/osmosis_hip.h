@@ -223,6 +223,10 @@ int osm_pool2x2(const float* x, long long ldx, float* y, long long ldy, int B, i
                 float scale, void* stream);
 int osm_upsample2x(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
                    float scale, void* stream);
+/* two tensors of one shape through ONE launch (up != 0: osm_upsample2x, else osm_pool2x2; 4-element vectors only): an up / down
+ * ResBlock resamples both its input and its normalised input (unet.py:263-270), its backward both gradients */
+int osm_resample_pair(int up, const float* x1, long long ldx1, float* y1, long long ldy1, const float* x2, long long ldx2,
+                      float* y2, long long ldy2, int B, int H, int W, int C, float scale, void* stream);
 
 /* ------------------------------------------------------------------ attention pieces
  * unet.py:431 softmax over the last dim (rows of length T); P and optionally P^T are written.
@@ -371,6 +375,8 @@ int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long l
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                      float scale, void* stream);
+int osm_resample_pair_h(int up, const osm_half_t* x1, long long ldx1, osm_half_t* y1, long long ldy1, const osm_half_t* x2,
+                        long long ldx2, osm_half_t* y2, long long ldy2, int B, int H, int W, int C, float scale, void* stream);
 int osm_nchw_to_nhwc_h(const float* x, osm_half_t* y, long long ldy, int B, int C, int HW, void* stream);   /* fp32 NCHW -> half NHWC */
 int osm_nhwc_to_nchw_h(const osm_half_t* x, long long ldx, float* y, int B, int C, int HW, void* stream);   /* half NHWC -> fp32 NCHW */
 int osm_copy2d_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, long long M, int C,

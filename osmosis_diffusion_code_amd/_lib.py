@@ -93,6 +93,7 @@ _SIGS = {
     "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
     "osm_pool2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_upsample2x": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
+    "osm_resample_pair": [_I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_softmax_rows": [_P, _P, _P, _I, _I, _P],
     "osm_softmax_rows_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "osm_timestep_embedding": [_P, _P, _I, _I, _F, _P],
@@ -117,7 +118,7 @@ _SIGS = {
 }
 # fp16-storage family (activations as IEEE half, `_h` suffix): same argument lists
 for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_gn_bwd_apply", "osm_pool2x2",
-           "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
+           "osm_resample_pair", "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
     _SIGS[_n + "_h"] = _SIGS[_n]
 _SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]
 _SIGS["osm_f32_to_half"] = [_P, _LL, _P, _LL, _LL, _I, _P]

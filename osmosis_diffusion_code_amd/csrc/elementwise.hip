@@ -9,7 +9,9 @@ namespace {
 template <int VEC>
 __global__ __launch_bounds__(256) void pool2x2_kernel(const act_t* __restrict__ x, long long ldx,
                                                        act_t* __restrict__ y, long long ldy, int B, int H,
-                                                       int W, int C, float scale) {
+                                                       int W, int C, float scale, const act_t* __restrict__ x2 = nullptr,
+                                                       long long ldx2 = 0, act_t* __restrict__ y2 = nullptr, long long ldy2 = 0) {
+  if (blockIdx.y == 1) { x = x2; ldx = ldx2; y = y2; ldy = ldy2; }     // the second tensor of a pair (osm_*_pair)
   const int Ho = H / 2, Wo = W / 2, vpr = C / VEC;
   const long long total = (long long)B * Ho * Wo * vpr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -47,7 +49,9 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const act_t* __restrict__ 
 template <int VEC>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const act_t* __restrict__ x, long long ldx,
                                                           act_t* __restrict__ y, long long ldy, int B, int H,
-                                                          int W, int C, float scale) {
+                                                          int W, int C, float scale, const act_t* __restrict__ x2 = nullptr,
+                                                          long long ldx2 = 0, act_t* __restrict__ y2 = nullptr, long long ldy2 = 0) {
+  if (blockIdx.y == 1) { x = x2; ldx = ldx2; y = y2; ldy = ldy2; }     // the second tensor of a pair (osm_*_pair)
   const int Ho = 2 * H, Wo = 2 * W, vpr = C / VEC;
   const long long total = (long long)B * Ho * Wo * vpr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -345,6 +349,30 @@ extern "C" int OSM_FN(osm_upsample2x)(const abi_act_t* x_, long long ldx, abi_ac
   else
     hipLaunchKernelGGL((upsample2x_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
   return osm::check_launch("upsample2x_kernel");
+}
+
+// Two tensors of the same shape resampled by ONE launch (an up / down ResBlock resamples its input and its normalised input,
+// and in the backward its two gradients: unet.py:263-270): saves a dependent launch (~4.5 us) per pair.  4-element vectors only.
+extern "C" int OSM_FN(osm_resample_pair)(int up, const abi_act_t* x1_, long long ldx1, abi_act_t* y1_, long long ldy1,
+                                         const abi_act_t* x2_, long long ldx2, abi_act_t* y2_, long long ldy2, int B, int H,
+                                         int W, int C, float scale, void* stream) {
+  const act_t *x1 = OSM_CACT(x1_), *x2 = OSM_CACT(x2_);
+  act_t *y1 = OSM_ACT(y1_), *y2 = OSM_ACT(y2_);
+  OSM_REQUIRE(x1 && y1 && x2 && y2, "osm_resample_pair: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "osm_resample_pair: bad shape");
+  OSM_REQUIRE(C % 4 == 0 && ldx1 % 4 == 0 && ldy1 % 4 == 0 && ldx2 % 4 == 0 && ldy2 % 4 == 0 && osm::aligned_act4(x1) &&
+              osm::aligned_act4(y1) && osm::aligned_act4(x2) && osm::aligned_act4(y2),
+              "osm_resample_pair: C and the row strides must be multiples of 4, pointers aligned to 4 elements");
+  OSM_REQUIRE(up || (H % 2 == 0 && W % 2 == 0), "osm_resample_pair: pooling needs even H, W");
+  const long long total = up ? (long long)B * (2 * H) * (2 * W) * (C / 4) : (long long)B * (H / 2) * (W / 2) * (C / 4);
+  const dim3 grid(grid_for(total), 2);
+  if (up)
+    hipLaunchKernelGGL((upsample2x_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, x1, ldx1, y1, ldy1, B, H, W, C, scale,
+                       x2, ldx2, y2, ldy2);
+  else
+    hipLaunchKernelGGL((pool2x2_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, x1, ldx1, y1, ldy1, B, H, W, C, scale,
+                       x2, ldx2, y2, ldy2);
+  return osm::check_launch("resample pair kernel");
 }
 
 extern "C" int OSM_FN(osm_nchw_to_nhwc)(const float* x, abi_act_t* y_, long long ldy, int B, int C, int HW,

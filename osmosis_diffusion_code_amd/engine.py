@@ -447,15 +447,13 @@ class UNetEngine:
             if blk.up:
                 ho, wo = 2 * H, 2 * W
                 a1r = self._scr("b", B * ho * wo, blk.cin)
-                ops.upsample2x(a1, a1r, B, H, W, 1.0)
                 xs = self._scr("c", B * ho * wo, blk.cin)
-                ops.upsample2x(x, xs, B, H, W, 1.0)
+                ops.resample_pair(True, a1, a1r, x, xs, B, H, W, 1.0)        # both tensors, one launch
             else:
                 ho, wo = H // 2, W // 2
                 a1r = self._scr("b", B * ho * wo, blk.cin)
-                ops.pool2x2(a1, a1r, B, H, W, 0.25)
                 xs = self._scr("c", B * ho * wo, blk.cin)
-                ops.pool2x2(x, xs, B, H, W, 0.25)
+                ops.resample_pair(False, a1, a1r, x, xs, B, H, W, 0.25)
             Mo = B * ho * wo
             h1 = self._buf(Mo, blk.cout)
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
@@ -523,24 +521,19 @@ class UNetEngine:
         da1r = self._scr("a", Mo, blk.cin)
         cs1 = self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True,
                          stat=("bwd", s["x"], s["tab1"]) if s["tab1"] is not None else None, xmax=xmh)
-        if blk.up:      # forward: nearest 2x upsample  -> backward: 2x2 sum
+        # forward: nearest 2x upsample -> backward: 2x2 sum;  forward: 2x2 average -> backward: replicate / 4.  The gradient of the
+        # resampled block input (dy -> t, below) has the same shape: both in one launch
+        if blk.up or blk.down:
+            assert blk.skip is None
             da1 = self._scr("b", M, blk.cin)
-            ops.pool2x2(da1r, da1, B, ho, wo, 1.0)
-        elif blk.down:  # forward: 2x2 average          -> backward: replicate / 4
-            da1 = self._scr("b", M, blk.cin)
-            ops.upsample2x(da1r, da1, B, ho, wo, 0.25)
+            t = self._scr("c", M, blk.cin)
+            ops.resample_pair(not blk.up, da1r, da1, dy, t, B, ho, wo, 1.0 if blk.up else 0.25)
         else:
             da1 = da1r
         # skip-path gradient + the gradient already sitting in dx_dst (concat / residual accumulation) are ADDENDS of the
         # GroupNorm-backward apply pass (up to two, one of which may be dx_dst itself): no accumulation pass of its own
         add2 = None
         if blk.up or blk.down:
-            assert blk.skip is None
-            t = self._scr("c", M, blk.cin)
-            if blk.up:
-                ops.pool2x2(dy, t, B, ho, wo, 1.0)
-            else:
-                ops.upsample2x(dy, t, B, ho, wo, 0.25)
             add = t
             add2 = dx_dst if accumulate else None
         elif blk.skip is not None:

@@ -318,6 +318,13 @@ def linear(x, W, b, y, B, K, N, silu_in=False, silu_out=False):
          keep=(x, W, b, y))
 
 
+def resample_pair(up: bool, x1: Mat, y1: Mat, x2: Mat, y2: Mat, B, H, W, scale):
+    """pool2x2 (up False) / upsample2x (up True) of two tensors of the same shape in one launch."""
+    assert x1.cols == x2.cols == y1.cols == y2.cols
+    call("osm_resample_pair" + _same_family(x1.t, y1.t, x2.t, y2.t), int(bool(up)), x1.p, x1.ld, y1.p, y1.ld, x2.p, x2.ld, y2.p, y2.ld,
+         B, H, W, x1.cols, scale, _s(), keep=(x1.t, y1.t, x2.t, y2.t))
+
+
 def nchw_to_nhwc(x, y: Mat, B, Cc, HW):
     call("osm_nchw_to_nhwc" + _fam(y.t), ptr(x), y.p, y.ld, B, Cc, HW, _s(), keep=(x, y.t))
 

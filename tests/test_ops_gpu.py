@@ -225,6 +225,24 @@ def test_group_norm_fwd_bwd(ops, C, HW, film, silu):
                        maxabs_in=torch.empty(B * P, device=DEV))
 
 
+def test_resample_pair(ops):
+    """osm_resample_pair: two tensors of one shape pooled / upsampled by one launch == the single-tensor entry points, bit for bit
+    (strided views included)."""
+    g = torch.Generator().manual_seed(6)
+    B, C, H, W = 2, 24, 8, 12
+    x1 = torch.randn(B * H * W, C + 8, generator=g).to(DEV)
+    x2 = torch.randn(B * H * W, C, generator=g).to(DEV)
+    m1, m2 = ops.Mat.of(x1).cols_slice(4, 4 + C), ops.Mat.of(x2)
+    for up, scale in ((False, 0.25), (True, 1.0), (True, 0.25), (False, 1.0)):
+        rows = B * H * W * 4 if up else B * H * W // 4
+        ya, yb, ra, rb = (torch.full((rows, C), float("nan"), device=DEV) for _ in range(4))
+        ops.resample_pair(up, m1, ops.Mat.of(ya), m2, ops.Mat.of(yb), B, H, W, scale)
+        f = ops.upsample2x if up else ops.pool2x2
+        f(m1, ops.Mat.of(ra), B, H, W, scale)
+        f(m2, ops.Mat.of(rb), B, H, W, scale)
+        assert torch.equal(ya, ra) and torch.equal(yb, rb)
+
+
 def test_pool_upsample(ops):
     g = torch.Generator().manual_seed(5)
     B, C, H, W = 2, 24, 8, 12
