@@ -190,18 +190,6 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_fwd_kernel(FlashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// delta[q] = sum_d dO[q][d] O[q][d]        one wave per (row, head): grid (B*T*heads / 4)
-__global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= (long long)a.B * a.T * a.heads) return;
-  const int hd = (int)(i % a.heads);
-  const long long row = i / a.heads;        // b * T + t
-  float v = a.dout[row * a.lddout + hd * DH + lane] * a.o[row * a.ldo + hd * DH + lane];
-  v = osm::wave_sum(v);
-  if (lane == 0) a.delta[((row / a.T) * a.heads + hd) * a.T + row % a.T] = v;
-}
-
 // dq: grid (T / 32, heads, B): workgroup = 32 queries, waves split the keys.
 //   S^T = K (scale Q)^T, P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);
 //   dq^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
@@ -217,9 +205,25 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
   const float* __restrict__ dO = a.dout + hd * DH;
   const long long ld = a.ldqkv;
   const long long stat = ((long long)blockIdx.z * a.heads + hd) * a.T + q0 + lr;
-  const float lse = a.lse[stat], dl = a.delta[stat];
+  const float lse = a.lse[stat];
 
   uint4 qf[4][NP], gf[4][NP];   // B operands (k = d, column = query): scale * Q and dO
+  // delta[q] = sum_d dO[q][d] O[q][d] of this lane's query: the lane reads 32 of its 64 dims for the dO fragments anyway (the other
+  // 32 sit in lane ^ 32), so every wave forms it for itself and wave 0 leaves it in a.delta for the dk / dv kernel that follows --
+  // a launch of its own (flash_delta_kernel, ~5 us x 16 per step) is not needed
+  float dl = 0.f;
+  {
+    const float* __restrict__ Op = a.o + (rb + q0 + lr) * a.ldo + hd * DH;
+    const float* __restrict__ Gp = dO + (rb + q0 + lr) * a.lddout;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 o0 = *reinterpret_cast<const float4*>(Op + 16 * s + 8 * h), o1 = *reinterpret_cast<const float4*>(Op + 16 * s + 8 * h + 4);
+      const float4 g0 = *reinterpret_cast<const float4*>(Gp + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(Gp + 16 * s + 8 * h + 4);
+      dl += (g0.x * o0.x + g0.y * o0.y) + (g0.z * o0.z + g0.w * o0.w) + (g1.x * o1.x + g1.y * o1.y) + (g1.z * o1.z + g1.w * o1.w);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (wave == 0 && h == 0) a.delta[stat] = dl;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     frag_row(Q, ld, rb + q0 + lr, 0, s, h, a.scale, qf[s]);
@@ -433,9 +437,8 @@ extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long
   OSM_REQUIRE(d->lddout % 4 == 0 && osm::aligned16(d->dout), "osm_attn_flash_bwd: dout must be 16-byte aligned");
   FlashArgs a = to_args(d);
   a.o = out; a.ldo = ldout; a.lse = const_cast<float*>(lse); a.delta = delta;
-  const long long rows = (long long)d->B * d->T * d->heads;
-  hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
-  const dim3 g(d->T / 32, d->heads, d->B);
+  OSM_REQUIRE(ldout % 4 == 0 && osm::aligned16(out), "osm_attn_flash_bwd: out must be 16-byte aligned");
+  const dim3 g(d->T / 32, d->heads, d->B);       // (delta is formed by the dq kernel and read by the dk / dv kernel after it)
   if (a.nw == 8) hipLaunchKernelGGL(flash_bwd_q_kernel<8>, g, dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(flash_bwd_q_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a);
   // (the dk / dv kernel holds K, V fragments and four accumulators: 368 registers -- it stays at one wave per SIMD)
