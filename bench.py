@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: without this RCCL's first exchange fails with `hipIpcGetMemHandle: invalid argument`
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -89,8 +92,10 @@ SECONDARY = [
 ]
 
 
-def build_case(args, dev, batch, unet_kw=None, diffusion_kw=None, operator=None, cond_kw=None, aux=None, conv_mode=None):
-    """(model, sampler, conditioner) of one configuration; the headline run is build_case(args, dev, args.batch)."""
+def build_case(args, dev, batch, unet_kw=None, diffusion_kw=None, operator=None, cond_kw=None, aux=None, conv_mode=None,
+               model=None):
+    """(model, sampler, conditioner) of one configuration; the headline run is build_case(args, dev, args.batch).
+    `model`: reuse this UNet (and its packed weight images) instead of building one."""
     from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
     from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
     from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
@@ -102,12 +107,13 @@ def build_case(args, dev, batch, unet_kw=None, diffusion_kw=None, operator=None,
                   num_head_channels=16)
     import contextlib
     import io
-    with contextlib.redirect_stdout(io.StringIO()):     # create_model prints its "no checkpoint" notice
-        model = unet.create_model(**kw)
-    seeded_weights(model)
-    model = model.to(dev).eval()
-    if conv_mode is not None and not kw.get("use_fp16"):
-        model.conv_mode = conv_mode
+    if model is None:
+        with contextlib.redirect_stdout(io.StringIO()):     # create_model prints its "no checkpoint" notice
+            model = unet.create_model(**kw)
+        seeded_weights(model)
+        model = model.to(dev).eval()
+        if conv_mode is not None and not kw.get("use_fp16"):
+            model.conv_mode = conv_mode
     sampler = gd.create_sampler(**dict(DIFFUSION, **(diffusion_kw or {})))
     opname, opkw = operator or ("underwater_physical_revised", OPERATOR)
     op = M.get_operator(opname, device=dev, batch_size=batch, **opkw)
@@ -116,8 +122,9 @@ def build_case(args, dev, batch, unet_kw=None, diffusion_kw=None, operator=None,
     return model, sampler, cond
 
 
-def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warmup, world=1):
-    """`warmup` untimed + `steps` timed guided steps; returns (seconds of the timed steps, outputs finite?)."""
+def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warmup, world=1, sync=None):
+    """`warmup` untimed + `steps` timed guided steps; returns (seconds of the timed steps, outputs finite?).
+    `sync` (sharding.RankSync) supplies the barrier of the N > 1 contract over whatever transport works on this node."""
     x_T, y = synthetic_inputs(image_index, batch, args.image_size)
     x_T, y = x_T.to(dev), y.to(dev)
     T = sampler.num_timesteps
@@ -137,16 +144,19 @@ def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warm
 
     if warmup > 0:
         run(warmup, first)
-    import torch.distributed as dist
+    dsync = sync.device_synchronize if sync is not None else torch.cuda.synchronize
+    dsync()                     # this rank's warm-up is done before it enters the barrier
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        sync.barrier()
+    dsync()
     t0 = time.perf_counter()
     out = run(steps, first - warmup)
-    torch.cuda.synchronize()
+    dsync()
+    t_own = time.perf_counter() - t0        # this rank alone (reported per rank; the job time is the MAX below)
     if world > 1:
-        dist.barrier()
+        sync.barrier()
     dt = time.perf_counter() - t0
+    timed_steps.last_own_s = t_own
     dump = os.environ.get("OSM_BENCH_DUMP")     # tests: per-rank checksum of the final x_t (which image, what came out)
     if dump:
         import hashlib
@@ -157,13 +167,44 @@ def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warm
     return dt, bool(torch.isfinite(out[0]).all())
 
 
-def run_gpu(args, rank, world, dev):
+def run_gpu(args, rank, world, dev, sync):
+    """The headline leg on this rank.  Returns (model, job seconds = MAX over ranks of barrier-to-barrier time, finite,
+    per-rank rows [rank, image index, own ms per step, barrier-to-barrier ms per step, setup s, finite])."""
+    t_setup = time.perf_counter()
     model, sampler, cond = build_case(args, dev, args.batch, conv_mode=args.conv_mode)
-    dt, finite = timed_steps(args, dev, model, sampler, cond, args.batch, shard(world, rank, world)[0], args.steps,
-                             args.warmup, world)
-    from osmosis_diffusion_code_amd.sharding import max_over_ranks
-    dt = max_over_ranks(dt, device=dev)
-    return model, dt, finite
+    image_index = shard(world, rank, world)[0]
+    # weight packing (device kernels, ~14 GB of images per GPU) happens at the first engine build inside the warm-up:
+    # every rank packs on ITS OWN GPU; what the ranks share is host memory bandwidth for the 2.2 GB parameter upload
+    dt, finite = timed_steps(args, dev, model, sampler, cond, args.batch, image_index, args.steps, args.warmup, world, sync)
+    setup_s = time.perf_counter() - t_setup - dt
+    rows = sync.all_gather([rank, image_index, 1e3 * timed_steps.last_own_s / args.steps, 1e3 * dt / args.steps, setup_s,
+                            1.0 if finite else 0.0])
+    dt = max(r[3] for r in rows) * args.steps / 1e3
+    return model, dt, all(r[5] == 1.0 for r in rows), rows
+
+
+def run_config4(args, dev, model, rank, world, sync):
+    """BASELINE config 4's real shape -- osmosis_sample_config.yaml on a 64-image set, 8 images per GPU carried as ONE
+    batch of 8 independent chains -- on every rank of this job (same model / weight images as the headline leg): whole-job
+    image-steps/s = world x 8 x steps / MAX over ranks of the barrier-to-barrier time."""
+    B = args.images_per_gpu
+    try:
+        _, sampler, cond = build_case(args, dev, B, model=model)
+        steps, warmup = max(1, args.secondary_steps), 1
+        dt, finite = timed_steps(args, dev, model, sampler, cond, B, 100 + rank, steps, warmup, world, sync)
+        rows = sync.all_gather([rank, 1e3 * timed_steps.last_own_s / steps, 1e3 * dt / steps, 1.0 if finite else 0.0])
+        dtm = max(r[2] for r in rows) * steps / 1e3
+        model._engines = {k: v for k, v in model._engines.items() if k[0] != B}     # give the B = 8 activations back
+        torch.cuda.empty_cache()
+        return {"workload": f"config 4: osmosis_sample_config.yaml, 64-image set sharded {B} per GPU (one batch of {B} chains per rank), "
+                            "underwater_physical_revised, 1000-step DDPM + guidance, fp32 storage",
+                "images_per_gpu": B, "n_gpus": world, "dtype": "f32", "conv_arithmetic": model.conv_mode, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(1e3 * dtm / steps, 2),
+                "image_steps_per_s": round(world * B * steps / dtm, 2), "ms_per_image_step": round(1e3 * dtm / steps / B, 3),
+                "finite_outputs": all(r[3] == 1.0 for r in rows),
+                "per_rank_ms": [round(r[1], 3) for r in sorted(rows)], "ranks_seen": len(rows)}
+    except Exception as e:      # a secondary line must never cost the headline number
+        return {"workload": "config 4", "error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def run_secondary(args, dev):
@@ -432,6 +473,8 @@ def main():
                          "exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
+    ap.add_argument("--images-per-gpu", type=int, default=8,
+                    help="batch of the config-4 secondary leg (BASELINE config 4: 64 images sharded 8 per GPU); runs at every N")
     ap.add_argument("--secondary-steps", type=int, default=3,
                     help="timed steps of each secondary configuration (BASELINE configs 3 and 5; N = 1 only; 0 = skip)")
     args = ap.parse_args()
@@ -450,30 +493,32 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    # OSM_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a single-GPU box (ranks share device 0); the
-    # driver's multi-GPU runs use the default: one rank per GPU over RCCL.
+    # One rank per GPU.  OSM_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a single-GPU box (ranks share device 0
+    # and RCCL is not tried); the driver's multi-GPU runs use the default: RCCL first, and if it fails to initialise, to
+    # all-reduce or to answer in time on ANY rank, every rank falls back to gloo, then to per-rank files (sharding.RankSync).
     backend = os.environ.get("OSM_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend != "nccl" or local >= ndev:
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    from osmosis_diffusion_code_amd.sharding import RankSync
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sync = RankSync(rank, world, device=dev, probe_timeout_s=float(os.environ.get("OSM_SYNC_TIMEOUT_S", "120")),
+                    force_fail=() if backend == "nccl" else ("rccl",))
 
-    model, dt, finite = run_gpu(args, rank, world, dev)
+    model, dt, finite, rank_rows = run_gpu(args, rank, world, dev, sync)
     units = world * args.batch * args.steps
     line = {
         "metric": "denoise-steps/sec (256x256 RGBD, 1000-step DDPM+guidance)",
         "value": round(units / dt, 4), "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.conv_mode == "f16" else "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16" if args.conv_mode == "f16" else ("f32" if args.conv_mode == "f32" else f"f32 ({args.conv_mode} conv)"),
+        "data": "synthetic",
         "config": {"workload": "osmosis_sample_config.yaml: 1 underwater 256x256 image per GPU, 1000-step DDPM "
-                               "+ osmosis guidance (n_iter=20), steps timed in the phi-update regime (t <= 0.3T)",
+                               "+ osmosis guidance (n_iter=20); the timed window starts at t = 0.3 T, inside the phi-update regime "
+                               "(t <= 0.7 T: 20 phi iterations per step, the expensive 70 % of the chain)",
                    "images_per_gpu": args.batch, "image_size": args.image_size, "unet_params": 552821000,
                    "weights": "seeded synthetic", "conv_arithmetic": args.conv_mode,
                    "conv_arithmetic_note": ("f16x3: the Winograd 3x3 layers and the 1x1 layers at >= 64x64 multiply ~22-bit operands (two IEEE-half terms per fp32 "
@@ -483,7 +528,15 @@ def main():
                    if args.conv_mode == "f16x3" else None, "parallelism": f"images[rank::{world}] (no collective on the path)",
                    "finite_outputs": finite},
         "images_per_sec_at_1000_steps": round(units / dt / 1000.0, 6),
+        # how the ranks met (barrier, gather of per-rank times): "rccl" | "gloo" | "files" ("none" at N = 1); the data path has
+        # no collective.  per_rank_ms: each rank's own synchronize-to-synchronize time per step; the job time is the MAX over
+        # ranks of the barrier-to-barrier time
+        "collective": sync.transport, "collective_failures": sync.failures or None,
+        "ranks_seen": len(rank_rows), "per_rank_ms": [round(r[2], 3) for r in sorted(rank_rows)],
+        "per_rank_image": [int(r[1]) for r in sorted(rank_rows)],
+        "per_rank_setup_s": [round(r[4], 1) for r in sorted(rank_rows)],
     }
+    cfg4 = run_config4(args, dev, model, rank, world, sync) if (args.secondary_steps > 0 and not args.tiny) else None
     if rank == 0:
         rl, breakdown = roofline(model, args)
         line["roofline"] = rl
@@ -513,15 +566,18 @@ def main():
                 except Exception as e:
                     line["same_workload_bf16x6"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             line["secondary"] = run_secondary(args, dev)
+        if cfg4 is not None:
+            line.setdefault("secondary", []).insert(0, cfg4)
         if world == 1 and args.cpu_steps > 0:
             del model
             line["cpu_baseline"] = cpu_baseline(args)
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        sync.barrier()
+    sync.close()
+    if not sync.device_sync_safe:
+        os._exit(0)             # an abandoned (hung) RCCL probe thread must not keep the process alive
 
 
 if __name__ == "__main__":

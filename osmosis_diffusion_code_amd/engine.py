@@ -245,7 +245,7 @@ class UNetEngine:
             raise ValueError(f"H, W must be divisible by {1 << (nlev - 1)}")
         self.ticket = 0
         self._saved: Dict[int, dict] = {}       # per-block activations kept for the data-gradient pass
-        self._xmax_reg: Dict[Tuple, torch.Tensor] = {}
+        self._xmax_reg: Dict[Tuple, Tuple] = {}      # (ptr, rows, ld) -> (slot, byte range): see _xmax_register
         self.params_version = None
         self._scratch: Dict[str, torch.Tensor] = {}
         self._fwd_plan: Optional[Recorder] = None
@@ -267,6 +267,7 @@ class UNetEngine:
         self.fuse_gn_wino = os.environ.get("OSM_FUSE_GN_WINO", "0") == "1"
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs == "all"
+        self._check_xmax = os.environ.get("OSM_CHECK_XMAX", "0") == "1"
 
         w = weights
         self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
@@ -331,6 +332,9 @@ class UNetEngine:
                     ops.maxabs(x, self.B, xm)
         elif cv.wf16 is not None and xmax is not None and H * W >= 4096 and (H * W) % 128 == 0:
             wfmt, wimg, xm = 4, (cv.wd16 if dgrad else cv.wf16), xmax     # 1x1 f16x3: only where the range is already known
+        if xm is not None and xmax is not None and self._check_xmax:
+            self._xmax_debug_check(x, xm, f"conv {cin}->{cout} k{cv.k} at {H}x{W}{' dgrad' if dgrad else ''}")
+        self._xmax_invalidate(y)            # a convolution leaves no max |y| behind
         sk = ops.conv_splitk(self.B, H, W, cin, cout, cv.k, wfmt, gn_table is not None)
         ws = None
         if sk > 1:
@@ -353,6 +357,39 @@ class UNetEngine:
         cin, cout = (cv.cout, cv.cin) if dgrad else (cv.cin, cv.cout)
         return cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
             bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
+
+    # ---- registry of "max |.| of this gradient buffer was left behind by its last writer" (f16x3 range hand-over)
+    @staticmethod
+    def _span(m: Mat):
+        """Byte range [lo, hi) a matrix view may touch (its rows at its row stride: a column slice covers its own columns only
+        per row, the interval is conservative)."""
+        lo = m.t.data_ptr()
+        return lo, lo + ((m.rows - 1) * m.ld + m.cols) * m.t.element_size()
+
+    def _xmax_register(self, m: Mat, slot: torch.Tensor):
+        self._xmax_invalidate(m)
+        self._xmax_reg[(m.t.data_ptr(), m.rows, m.ld)] = (slot, *self._span(m))
+
+    def _xmax_lookup(self, m: Mat):
+        e = self._xmax_reg.get((m.t.data_ptr(), m.rows, m.ld))
+        return e[0] if e is not None else None
+
+    def _xmax_invalidate(self, m: Mat):
+        """A pass that does NOT leave max |out| behind is about to write `m`: forget every bound registered for memory it
+        overlaps (a stale, too-small bound would scale an f16x3 operand out of the fp16 range silently)."""
+        if not self._xmax_reg:
+            return
+        lo, hi = self._span(m)
+        for k in [k for k, e in self._xmax_reg.items() if e[1] < hi and lo < e[2]]:
+            del self._xmax_reg[k]
+
+    def _xmax_debug_check(self, x: Mat, xm: torch.Tensor, what: str):
+        """OSM_CHECK_XMAX=1 (recording pass only: kernels execute there): the bound handed over must cover max |x|."""
+        bound = xm.view(self.B, -1).view(torch.int32).max(dim=1).values.view(torch.float32)
+        actual = x.t.reshape(self.B, -1, x.cols).abs().amax(dim=(1, 2))
+        ok = bool(((actual <= bound) | torch.isnan(bound)).all())
+        if not ok:
+            raise OsmosisHipError(f"f16x3 range hand-over broken at {what}: max |x| {actual.tolist()} > bound {bound.tolist()}")
 
     def _xmax_slot(self, key: str) -> torch.Tensor:
         """[B][MAXABS_PARTS] partial max |x| of an f16x3 convolution's input (every entry is rewritten by its producer)."""
@@ -498,7 +535,7 @@ class UNetEngine:
         M, Mo = B * H * W, B * ho * wo
         if blk.skip is not None:      # skip-path gradient (f16x3 where max |dy| was left behind by the pass that wrote dy)
             self._conv(dy, blk.skip, dx_dst, (H, W), dgrad=True, accumulate=accumulate, ws_slot="splitk2",
-                       xmax=self._xmax_reg.get((dy.p, dy.rows, dy.ld)))
+                       xmax=self._xmax_lookup(dy))
         dh2 = self._scr("a", Mo, blk.cout)
         # GroupNorm backward = two reductions over (x, dy) + an apply pass.  Where the forward kept the per-channel
         # table, the reductions are folded into the epilogue of the data-gradient convolution that PRODUCES dy (it
@@ -507,7 +544,7 @@ class UNetEngine:
         # launch; a bound over the wider concat-gradient buffer serves its column slice), else a pass of its own
         cs = self._conv(dy, blk.c2, dh2, (ho, wo), dgrad=True,
                         stat=("bwd", s["h1"], s["tab2"]) if s["tab2"] is not None else None,
-                        xmax=self._xmax_reg.get((dy.p, dy.rows, dy.ld)))
+                        xmax=self._xmax_lookup(dy))
         dh1 = self._scr("b", Mo, blk.cout)
         gst = self._small(B * G * 2)
         xmh = self._xmax_from_gn(blk.c1, (ho, wo), (ho, wo), "gnb", dgrad=True)
@@ -542,12 +579,14 @@ class UNetEngine:
             add = dy
             add2 = dx_dst if accumulate else None
         gst1 = self._small(B * G * 2)
-        # this pass is the LAST writer of dx_dst (every level's first layer is a ResBlock): it leaves max |dx_dst| behind for the
-        # f16x3 data-gradient convolution of whichever ResBlock reads the buffer as its dy
+        # this pass writes dx_dst and leaves max |dx_dst| behind for the f16x3 data-gradient convolution of whichever ResBlock
+        # reads the buffer as its dy; any OTHER later writer of that memory (attention backward, a convolution) drops the entry
         xmo = None
         if self.conv_mode == "f16x3" and ops.gn_nchunk(H * W) <= ops.MAXABS_PARTS:
             xmo = self._small(B * ops.MAXABS_PARTS)
-            self._xmax_reg[(dx_dst.p, dx_dst.rows, dx_dst.ld)] = xmo
+            self._xmax_register(dx_dst, xmo)
+        else:
+            self._xmax_invalidate(dx_dst)
         if cs1 is not None:
             ops.gn_finalize_cols(cs1[0], cs1[1], B, H * W, blk.cin, G, gst1, mode=1)
             ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add,
@@ -680,6 +719,7 @@ class UNetEngine:
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
         gst = self._small(B * G * 2)
+        self._xmax_invalidate(dx_dst)       # this pass leaves no max |dx_dst| behind
         ops.gn_bwd(s["x"], dxn, dx_dst, B, T, G, s["st"], blk.norm.g, blk.norm.b, self.gn_part, gst,
                    silu=False, addend=dy, addend2=dx_dst if accumulate else None)
 
@@ -810,7 +850,7 @@ class UNetEngine:
         xmo = None          # max |dy| for the f16x3 data-gradient convolutions of the last ResBlock (3x3 and skip)
         if self.conv_mode == "f16x3" and ops.gn_nchunk(H * W) <= ops.MAXABS_PARTS:
             xmo = self._small(B * ops.MAXABS_PARTS)
-            self._xmax_reg[(dy.p, dy.rows, dy.ld)] = xmo
+            self._xmax_register(dy, xmo)
         ops.gn_bwd(self.h_last, da, dy, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, self.gn_part,
                    gst, silu=True, maxabs=xmo)
         if self.adt != f32:

@@ -156,8 +156,9 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
               "part": torch.empty(B * nblk * 16, device=device, dtype=torch.float32),
               "red": torch.zeros(B * 16, device=device, dtype=torch.float32),
               "loss": torch.zeros(B, device=device, dtype=torch.float32),
-              "opt": self._opt if d.optimizer == 1 else None,
               "g": torch.empty(B, 4, HW, device=device, dtype=torch.float32)}
+        while len(self._states) >= 4:          # a walk uses at most two chunk sizes; older shapes give their buffers back
+            self._states.pop(next(iter(self._states)))
         self._states[st["key"]] = st
         self._state = st
         return st
@@ -171,7 +172,8 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         if y.shape[0] != B or y.shape[1] != 3 or x0.shape[1] != 4:
             raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
         st = self._prepare(B, HW, x0.device)
-        d, part, red, loss, opt = st["desc"], st["part"], st["red"], st["loss"], st["opt"]
+        d, part, red, loss = st["desc"], st["part"], st["red"], st["loss"]
+        opt = self._opt if d.optimizer == 1 else None       # read at call time: _prepare may have re-allocated it
         if loss_out is not None:
             loss = loss_out
         phi = self.operator.phi if phi is None else phi
@@ -203,7 +205,13 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         full = self.operator.phi
         if phi.data_ptr() == full.data_ptr() and phi.shape[0] == full.shape[0]:
             return opt
-        r0 = (phi.data_ptr() - full.data_ptr()) // (9 * 4)
+        off = phi.data_ptr() - full.data_ptr()
+        r0, rem = divmod(off, 9 * 4)
+        if rem != 0 or r0 < 0 or r0 + phi.shape[0] > full.shape[0]:
+            # the kernel writes opt_state + b * 20 for every phi row it is handed: rows of anything but the operator's own
+            # [B][9] block would be an out-of-bounds device write
+            raise ValueError("optimizer: adam needs `phi` to be a row block of the operator's own phi tensor "
+                             f"(byte offset {off}, {phi.shape[0]} rows of {full.shape[0]})")
         return opt[r0:r0 + phi.shape[0]]
 
     def aux_values(self):

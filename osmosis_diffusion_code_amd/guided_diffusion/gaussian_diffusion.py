@@ -278,33 +278,38 @@ class GaussianDiffusion:
                 noise.copy_(noise1.expand_as(noise))
             else:
                 noise.normal_()
-            for e2 in engs.values():        # every engine's timestep vector; the step counter moves once
+            # every engine's timestep vector is filled from the SAME step counter; the counter moves once, in the last fetch,
+            # which always goes through the first engine (stream order: the delta-0 fetches read it before it moves)
+            for e2 in engs.values():
                 if e2 is not eng:
                     ops.fetch_coefs(table, step, 0, coef, e2.t_dev, e2.B)
             ops.fetch_coefs(table, step, -1, coef, eng.t_dev, eng.B)
             if trace is not None:
                 rec = {"x_in": x_state.clone()}
                 grad_all = torch.empty_like(g) if guided else None
+                model_out = torch.empty(B, eng.out.shape[1], H, W, **f32)
             for c0, c1 in chunks:
-                eng, Bc = engs[c1 - c0], c1 - c0
+                ce, Bc = engs[c1 - c0], c1 - c0            # this chunk's engine (`eng` stays the first one)
                 if not single:
-                    eng.x_in.copy_(x_state[c0:c1])
-                eng.run_forward()
-                ops.posterior(eng.out, eng.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW)
+                    ce.x_in.copy_(x_state[c0:c1])
+                ce.run_forward()
+                ops.posterior(ce.out, ce.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW)
+                if trace is not None:
+                    model_out[c0:c1].copy_(ce.out)
                 if guided:
                     cond.loss_grad_x0(x0[c0:c1], y[c0:c1], freeze_phi=freeze, g_out=g[c0:c1], phi=phi[c0:c1],
                                       loss_out=loss_all[c0:c1])
                     have_loss = True
-                    ops.posterior_bwd(g[c0:c1], coef, eng.d_out, Bc, HW)
-                    eng.run_backward()
+                    ops.posterior_bwd(g[c0:c1], coef, ce.d_out, Bc, HW)
+                    ce.run_backward()
                     grad_out = grad_all[c0:c1] if trace is not None else None
-                    ops.guide_update(mean[c0:c1], logvar[c0:c1], g[c0:c1], eng.dx, noise[c0:c1], coef, scale4,
+                    ops.guide_update(mean[c0:c1], logvar[c0:c1], g[c0:c1], ce.dx, noise[c0:c1], coef, scale4,
                                      cond.clip_value, x_state[c0:c1], grad_out, Bc, HW)
                 else:
                     ops.guide_update(mean[c0:c1], logvar[c0:c1], None, None, noise[c0:c1], coef, None, -1.0,
                                      x_state[c0:c1], None, Bc, HW)
             if trace is not None:
-                rec.update(x0=x0.clone(), mean=mean.clone(), x_out=x_state.clone(),
+                rec.update(x0=x0.clone(), mean=mean.clone(), x_out=x_state.clone(), model_out=model_out,
                            loss=loss_all.clone() if have_loss else None, phi=phi.clone())
                 if guided:
                     rec["grad"] = grad_all

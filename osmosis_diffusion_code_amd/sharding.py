@@ -43,3 +43,190 @@ def gather_per_image(values: Sequence[float], n_items: int, device=None) -> List
         for k, idx in enumerate(shard_indices(n_items, r, world)):
             out[idx] = float(allv[r][k])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rank bookkeeping that cannot lose a run.  The data path needs no collective (images are independent chains), so a
+# broken collective library must never cost the measurement: `RankSync` offers barrier / all-gather-of-floats over the
+# first transport that WORKS ON EVERY RANK, tried in this order:
+#   "rccl"  -- torch.distributed backend "nccl" (= RCCL on ROCm), device tensors, one rank per GPU over xGMI;
+#   "gloo"  -- torch.distributed backend "gloo", host tensors over TCP on 127.0.0.1;
+#   "files" -- one small JSON file per rank and round in a node-local directory (the contract is ONE node), polled.
+# Agreement on the transport itself goes through that directory, so every rank takes the same branch even when the failure
+# is one-sided.  A transport whose probe raises OR does not finish in `probe_timeout_s` (a hang) counts as failed; a
+# hung RCCL probe thread is abandoned (daemon) and `device_sync_safe` turns False: callers then synchronise their own
+# stream instead of the whole device (a wedged RCCL kernel would block `torch.cuda.synchronize()`).
+class RankSync:
+    ORDER = ("rccl", "gloo", "files")
+
+    def __init__(self, rank: int, world: int, device=None, sync_dir: str = None, probe_timeout_s: float = 120.0,
+                 force_fail: Sequence[str] = ()):
+        import os
+        self.rank, self.world, self.device = int(rank), int(world), device
+        self.transport, self.failures = "none", {}
+        self.device_sync_safe = True
+        self._round = 0
+        self._group = None
+        self._dist_up = False
+        if self.world == 1:
+            return
+        if sync_dir is None:
+            sync_dir = os.environ.get("OSM_SYNC_DIR") or os.path.join(
+                "/tmp", "osm_sync_%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                                os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        os.makedirs(sync_dir, exist_ok=True)
+        self.dir = sync_dir
+        self._timeout = float(probe_timeout_s)
+        force_fail = set(force_fail) | set(filter(None, os.environ.get("OSM_SYNC_FORCE_FAIL", "").split(",")))
+        for name in self.ORDER:
+            if name == "files":
+                self.transport = "files"
+                break
+            ok, why = (False, "forced failure (test)") if name in force_fail else self._probe(name)
+            votes = self._file_gather("vote_" + name, [1.0 if ok else 0.0])
+            if not ok:
+                self.failures[name] = why
+            if all(v[0] == 1.0 for v in votes):
+                self.transport = name
+                break
+            if ok:
+                self.failures[name] = "failed on rank(s) %s" % [r for r, v in enumerate(votes) if v[0] != 1.0]
+
+    # -- probes -------------------------------------------------------------------------------------------------------
+    def _run_with_timeout(self, fn):
+        import threading
+        box = {}
+
+        def body():
+            try:
+                fn()
+                box["ok"] = True
+            except BaseException as e:     # noqa: BLE001 -- any failure of a probe means "do not use this transport"
+                box["err"] = "%s: %s" % (type(e).__name__, str(e).replace("\n", " ")[:300])
+
+        th = threading.Thread(target=body, daemon=True)
+        th.start()
+        th.join(self._timeout)
+        if th.is_alive():
+            return False, "no answer within %.0f s (hang)" % self._timeout, True
+        return ("ok" in box), box.get("err", ""), False
+
+    def _probe(self, name):
+        import datetime
+        import os
+
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=max(30.0, self._timeout))
+
+        def ensure_default_group():
+            # gloo is the default group: it only needs TCP on 127.0.0.1; RCCL rides on it as a sub-group, so a failed /
+            # hung RCCL leaves a working process group behind
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=tmo)
+            self._dist_up = True
+
+        if name == "gloo":
+            def fn():
+                ensure_default_group()
+                t = torch.tensor([float(self.rank)], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                assert float(t) == self.world * (self.world - 1) / 2.0, "gloo all_reduce returned a wrong sum"
+            ok, why, _hung = self._run_with_timeout(fn)
+            return ok, why
+
+        def fn():
+            assert self.device is not None and torch.device(self.device).type == "cuda", "rccl needs a HIP device"
+            # a failed / timed-out RCCL collective must raise here, not let torch's NCCL watchdog tear the process down
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            ensure_default_group()
+            g = dist.new_group(backend="nccl", timeout=tmo)
+            t = torch.tensor([float(self.rank)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g)
+            torch.cuda.current_stream(self.device).synchronize()
+            assert float(t.item()) == self.world * (self.world - 1) / 2.0, "rccl all_reduce returned a wrong sum"
+            dist.barrier(group=g)
+            self._group = g
+        ok, why, hung = self._run_with_timeout(fn)
+        if hung:
+            self.device_sync_safe = False
+        if not ok:
+            self._group = None
+        return ok, why
+
+    # -- file transport (also the agreement channel) ---------------------------------------------------------------------
+    def _file_gather(self, tag: str, values, timeout_s: float = None):
+        import json
+        import os
+        import time
+        path = os.path.join(self.dir, "%s_r%d.json" % (tag, self.rank))
+        with open(path + ".tmp", "w") as f:
+            json.dump([float(v) for v in values], f)
+        os.replace(path + ".tmp", path)            # atomic: a reader sees the whole file or none
+        out, t0 = [None] * self.world, time.monotonic()
+        limit = timeout_s if timeout_s is not None else max(600.0, 4 * self._timeout)
+        while True:
+            for r in range(self.world):
+                if out[r] is None:
+                    try:
+                        with open(os.path.join(self.dir, "%s_r%d.json" % (tag, r))) as f:
+                            out[r] = json.load(f)
+                    except (FileNotFoundError, ValueError):
+                        pass
+            if all(o is not None for o in out):
+                return out
+            if time.monotonic() - t0 > limit:
+                missing = [r for r in range(self.world) if out[r] is None]
+                raise RuntimeError("RankSync(files): ranks %s never wrote %r in %s" % (missing, tag, self.dir))
+            time.sleep(0.0002)
+
+    # -- the two primitives -----------------------------------------------------------------------------------------------
+    def all_gather(self, values: Sequence[float]) -> List[List[float]]:
+        """Every rank passes the same number of floats; returns the per-rank lists in rank order."""
+        vals = [float(v) for v in values]
+        if self.world == 1:
+            return [vals]
+        self._round += 1
+        if self.transport == "files":
+            return self._file_gather("g%d" % self._round, vals)
+        import torch.distributed as dist
+        dev = self.device if self.transport == "rccl" else None
+        mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+        allv = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine, group=self._group if self.transport == "rccl" else None)
+        return [[float(x) for x in t.cpu()] for t in allv]
+
+    def barrier(self) -> None:
+        if self.world == 1:
+            return
+        if self.transport == "files":
+            self._round += 1
+            self._file_gather("b%d" % self._round, [0.0])
+            return
+        import torch.distributed as dist
+        if self.transport == "rccl":
+            dist.barrier(group=self._group)
+            torch.cuda.current_stream(self.device).synchronize()   # an RCCL barrier is a kernel: the host must see it done
+        else:
+            dist.barrier()
+
+    def max(self, value: float) -> float:
+        return max(v[0] for v in self.all_gather([value]))
+
+    def device_synchronize(self) -> None:
+        if self.device is None or torch.device(self.device).type != "cuda":
+            return
+        if self.device_sync_safe:
+            torch.cuda.synchronize(self.device)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def close(self) -> None:
+        if self.world == 1 or not self._dist_up:
+            return
+        import torch.distributed as dist
+        try:
+            if self.device_sync_safe and dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:      # noqa: BLE001 -- teardown must not turn a finished measurement into a failure
+            pass

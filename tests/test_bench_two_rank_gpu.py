@@ -62,3 +62,46 @@ def test_bench_eight_ranks_full_size_dry_run(tmp_path):
     assert one.returncode == 0, one.stderr[-3000:]
     single = json.load(open(tmp_path / "rank0_of_1.json"))
     assert single["image_index"] == 0 and single["sha1"] == ranks[0]["sha1"]
+
+
+def _bench_two(tmp, env_extra, tag):
+    d = tmp / tag
+    d.mkdir()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OSM_BENCH_DUMP=str(d), OSM_SYNC_TIMEOUT_S="45",
+               OSM_SYNC_DIR=str(d / "sync"), **env_extra)
+    if "OSM_BENCH_BACKEND" not in env_extra:
+        env.pop("OSM_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--tiny", "--image-size", "32", "--cpu-steps", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    ranks = [json.load(open(d / f"rank{r}_of_2.json")) for r in range(2)]
+    return json.loads(lines[0]), ranks
+
+
+def test_bench_survives_rccl_failure(tmp_path):
+    """the first real multi-GPU run must be un-losable.  Two ranks on the ONE GPU of the test box with the
+    DEFAULT backend: RCCL is really tried and really fails (two ranks on one device) -- the failure branch the driver's 8-GPU
+    box would take on an RCCL problem.  Every rank must fall back to gloo and still produce ONE JSON line whose per-rank
+    results are those of the gloo run; with gloo failing too (forced), the per-rank-files transport carries the run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if torch.cuda.device_count() > 1:
+        pytest.skip("RCCL would work here: the natural failure needs a single-GPU box")
+    ref, ref_ranks = _bench_two(tmp_path, {"OSM_BENCH_BACKEND": "gloo"}, "gloo")
+    assert ref["collective"] == "gloo" and ref["ranks_seen"] == 2 and len(ref["per_rank_ms"]) == 2
+    got, got_ranks = _bench_two(tmp_path, {}, "default")
+    assert got["collective"] == "gloo" and "rccl" in got["collective_failures"], got.get("collective_failures")
+    files, files_ranks = _bench_two(tmp_path, {"OSM_SYNC_FORCE_FAIL": "rccl,gloo"}, "files")
+    assert files["collective"] == "files" and set(files["collective_failures"]) == {"rccl", "gloo"}
+    for d, ranks in ((got, got_ranks), (files, files_ranks)):
+        assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["per_rank_image"] == [0, 1] and d["scaling"] == "weak"
+        assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+        assert max(d["per_rank_ms"]) <= d["ms_per_step"] * 1.001
+        assert [r["sha1"] for r in ranks] == [r["sha1"] for r in ref_ranks]        # same images, same bits, whatever the transport

@@ -59,3 +59,37 @@ def test_single_process_identities():
     assert gather_per_image([1.0, 2.0], 2) == [1.0, 2.0]
     with pytest.raises(ValueError):
         shard_indices(4, 2, 2)
+
+
+def _sync_worker(rank, world, port, sync_dir, force_fail, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from osmosis_diffusion_code_amd.sharding import RankSync
+    s = RankSync(rank, world, device=None, sync_dir=sync_dir, probe_timeout_s=60, force_fail=force_fail)
+    s.barrier()
+    rows = s.all_gather([rank, 10.0 + rank])
+    t = s.max(1.0 + rank)
+    s.barrier()
+    q.put((rank, s.transport, sorted(s.failures), rows, t))
+    s.close()
+
+
+@pytest.mark.parametrize("force_fail,expect", [((), "gloo"), (("gloo",), "files"), (("rccl", "gloo"), "files")])
+def test_rank_sync_falls_back_and_agrees(tmp_path, force_fail, expect):
+    """No GPU here, so the RCCL probe fails on its own ("rccl needs a HIP device") -- the branch the driver's 8-GPU box would
+    take on an RCCL failure: every rank lands on the same next transport and barrier / gather / max still work."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, str(tmp_path), force_fail, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, transport, failures, rows, t in res:
+        assert transport == expect
+        assert "rccl" in failures and (expect != "files" or "gloo" in failures)
+        assert rows == [[0.0, 10.0], [1.0, 11.0]] and t == 2.0

@@ -474,3 +474,37 @@ def test_full_size_unet_winograd_vs_direct_kernel(monkeypatch):
         ed = relerr(outs[key][1], direct[1])
         print("Winograd", key[0], "vs direct bf16x6, full size: y", ey, "dx", ed)
         assert ey < 2e-5 and ed < 2e-5, key
+
+
+def test_f16x3_range_handover_is_checked_launch_by_launch(monkeypatch):
+    """OSM_CHECK_XMAX=1: while the plans are recorded (kernels execute), every f16x3 convolution that takes the per-image max |x|
+    from the pass that produced x compares that bound with max |x| of the tensor it really reads (engine._xmax_debug_check).
+    A model with attention blocks between ResBlocks (a second kind of writer of the gradient buffers), skip 1x1 convolutions
+    at >= 64 x 64 and up / down blocks; forward + input gradient must pass the check and equal the unchecked run."""
+    from oracle import unet_ref as U
+    from osmosis_diffusion_code_amd.guided_diffusion.unet import create_model
+    kw = dict(image_size=256, num_channels=64, num_res_blocks=2, channel_mult="1,2,2", learn_sigma=True,
+              attention_resolutions="128,64", num_heads=4, num_head_channels=64, use_scale_shift_norm=True,
+              resblock_updown=True, pretrain_model="osmosis")
+    cfg = U.UNetConfig.from_create_model_kwargs(**kw)
+    sd = U.seeded_state_dict(cfg, 77)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 128, 128, generator=g)
+    x[1] *= 30.0                                         # per-image ranges differ
+    t = torch.tensor([11.0, 640.0])
+    w = torch.randn(2, 8, 128, 128, generator=g)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OSM_CHECK_XMAX", flag)
+        m = create_model(**kw)
+        m.load_state_dict(sd, strict=True)
+        m.conv_mode = "f16x3"
+        m = m.to(DEV).eval()
+        xd = x.to(DEV).requires_grad_(True)
+        yd = m(xd, t.to(DEV))
+        (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+        eng = next(iter(m._engines.values()))
+        assert eng._check_xmax == (flag == "1")
+        outs.append((yd.detach().cpu(), dxd.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
