@@ -374,6 +374,15 @@ def roofline(model, args, reps=3):
                 traffic_src = os.path.relpath(path, ROOT)
         except Exception:
             pass
+    traffic_how = None if traffic is None else "builder profile (committed PMC summary), relayed -- not observed by this run"
+    traffic_detail = None
+    if getattr(args, "pmc", "off") == "auto" and reps > 1:          # the headline leg only (secondary legs pass reps=1)
+        live, detail = live_traffic(args, kname)
+        if live is not None:
+            traffic, traffic_src, traffic_detail = live, "this run", detail
+            traffic_how = "measured in this run (child processes of bench.py under rocprofv3 --pmc)"
+        else:
+            traffic_detail = {"live_measurement_failed": detail}
     dshapes = {k: v for k, v in per_shape.items() if shape_tag.get(k) == dom}
     esz = 2.0 if args.conv_mode == "f16" else 4.0
     alg_bytes = sum(esz * (k[0] * k[1] * k[2] * (k[3] + k[4]) + 9 * k[3] * k[4]) * v[1]
@@ -396,7 +405,7 @@ def roofline(model, args, reps=3):
             "frac": round(achieved / peak, 4), **extra,
             "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # 157.3 TF: the exact-fp32 MFMA / vector peak
             "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_measured_in": None if traffic is None else "builder profile (committed PMC summary), relayed -- not observed by this run",
+            "traffic_measured_in": traffic_how, "traffic_detail": traffic_detail,
             # achieved HBM GB/s of the conv kernel (north_star asks for it; the kernel is MFMA / power bound, not HBM-bound):
             # relayed PMC bytes and algorithmic bytes, each / the live HIP-event launch time
             "hbm_gbps": None if traffic is None else round(traffic / lt / 1e6, 1),
@@ -405,6 +414,58 @@ def roofline(model, args, reps=3):
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
             "avg_launch_ms": lt, "avg_launch_ms_is": "HIP events around one osm_conv2d_nhwc call (kernel + split-K combine where there is one)",
             "launches_per_step": c["launches_per_step"]}, out
+
+
+def live_traffic(args, kname):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two child runs of this script (one guided step
+    each) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no trace domains, as
+    MI355X_MICROARCH.md prescribes -- summarised like tools/pmc_summary.py (read side x 2: the gfx950 half-count of 16 B/lane
+    streaming reads).  Returns (bytes per launch, detail dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    pref = kname.split("<")[0]
+    targs = kname.split("<")[1].rstrip(">").split(",") if "<" in kname else []
+
+    def match(name):
+        kn = name.replace(" ", "")
+        i = kn.find(pref + "<")
+        if i < 0:
+            return False
+        ka = kn[i + len(pref) + 1:].split(">")[0].split(",")
+        return all(t == "*" or (j < len(ka) and ka[j] == t) for j, t in enumerate(targs))
+
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="osm_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "1", "--cpu-steps", "0", "--secondary-steps", "0", "--pmc", "off",
+               "--conv-mode", args.conv_mode, "--batch", str(args.batch), "--image-size", str(args.image_size)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=args.pmc_timeout)
+            tot, n = 0.0, 0
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and match(r["Kernel_Name"]):
+                        tot += float(r["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None, f"no {counter} rows for {kname}"
+            got[counter] = (tot * 1024.0 / n, n)
+        except Exception as e:          # a profiler problem must never cost the bench line
+            return None, f"{counter} pass failed: {type(e).__name__}: {e}"[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return round(rd + wr), {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                            "launches_counted": got["FETCH_SIZE"][1],
+                            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate child runs of this script (1 warm-up + 1 "
+                                   "guided step each), read side x 2 (gfx950 half-count of 16 B/lane reads), KiB -> bytes"}
 
 
 def cpu_baseline(args):
@@ -473,6 +534,13 @@ def main():
                          "exact-fp32 MFMA, or fp32 split into 3 / 2 bf16 terms (6 / 3 bf16 MFMAs)")
     ap.add_argument("--dump-layers", default="", help="write per-conv-shape timings (JSON) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (plumbing check only; NOT a valid bench)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto: roofline.traffic is measured in this run (two short child runs under rocprofv3 --pmc, rank 0, N = 1); "
+                         "off: relayed from the committed profile")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0, help="seconds allowed per rocprofv3 child run")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="2: the headline workload (default).  3 / 5: time ONLY that BASELINE configuration (profiling target) and "
+                         "print its compact line")
     ap.add_argument("--images-per-gpu", type=int, default=8,
                     help="batch of the config-4 secondary leg (BASELINE config 4: 64 images sharded 8 per GPU); runs at every N")
     ap.add_argument("--secondary-steps", type=int, default=3,
@@ -507,6 +575,17 @@ def main():
     sync = RankSync(rank, world, device=dev, probe_timeout_s=float(os.environ.get("OSM_SYNC_TIMEOUT_S", "120")),
                     force_fail=() if backend == "nccl" else ("rccl",))
 
+    if world > 1 or args.tiny:
+        args.pmc = "off"
+    if args.config != 2:        # profiling target: one secondary configuration alone
+        c = SECONDARY[0 if args.config == 3 else 1]
+        model, sampler, cond = build_case(args, dev, c["batch"], c["unet"], c["diffusion"], c["operator"], c["cond"], c["aux"],
+                                          conv_mode=args.conv_mode)
+        dt, finite = timed_steps(args, dev, model, sampler, cond, c["batch"], 7, args.steps, args.warmup)
+        print(json.dumps({"workload": c["workload"], "images_per_gpu": c["batch"], "conv_arithmetic": model.conv_mode,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "image_steps_per_s": round(c["batch"] * args.steps / dt, 2), "finite_outputs": finite}), flush=True)
+        return
     model, dt, finite, rank_rows = run_gpu(args, rank, world, dev, sync)
     units = world * args.batch * args.steps
     line = {

@@ -193,6 +193,23 @@ int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, 
 int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
                float* part, float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, float* maxabs_out, float* maxabs_in, void* stream);
+/* Cooperative single-read GroupNorm (round 4): ONE launch that reads x (and dy) ONCE -- the tensor's row chunks stay in the
+ * registers of osm_gn_coop_plan(...) workgroups per image while the 32 per-group partial sums travel through `ws`.
+ * Same results contract as osm_gn_fwd / osm_gn_bwd (nn.py:17-19,93-100; unet.py:263,287,327-331).
+ *   osm_gn_coop_plan     workgroups per image for this shape (mode 0 = forward, 1 = backward), or 0: not applicable (the grid
+ *                        would not be resident at once, C not a multiple of 128 or > 2048, G != 32, image < 512 KB) -- use
+ *                        osm_gn_fwd / osm_gn_bwd then.
+ *   osm_gn_coop_ws_bytes size of `ws`.  ws must be zero-initialised ONCE and then always be used with the SAME
+ *                        (B, HW, C, G, mode): one workspace per call site (its slots carry a launch counter).
+ * A workgroup that waits longer than OSM_GN_COOP_TIMEOUT_US (2000) for the others recomputes what is missing itself: the call
+ * cannot hang when the device is shared, and its results do not depend on which path a workgroup took. */
+int osm_gn_coop_plan(int B, int HW, int C, int G, int mode);
+long long osm_gn_coop_ws_bytes(int B, int HW, int C, int G, int mode);
+/* run-time knobs (defaults from the environment, OSM_GN_COOP*): "on", "kb", "min_kb", "force", "timeout_us" */
+int osm_gn_coop_set(const char* key, long long value);
+int osm_gn_fwd_coop(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
+                    float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
+                    float* maxabs_out, float* maxabs_in, void* ws, void* stream);
 /* Statistics only + the per-channel table a convolution applies itself (osm_conv_desc.gn_table):
  * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
@@ -215,6 +232,11 @@ int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, f
                const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                const float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, float* part, float* gstats, float* maxabs_out, void* stream);
+/* osm_gn_bwd as ONE cooperative launch (see osm_gn_fwd_coop; plan / workspace with mode 1).  dx must not alias x or dy. */
+int osm_gn_bwd_coop(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
+                    const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
+                    const float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
+                    float* gstats, float* maxabs_out, void* ws, void* stream);
 
 /* ------------------------------------------------------------------ resampling (unet.py:186, 215)
  * y[B][H/2][W/2][C] = scale * sum_{2x2} x   (avg-pool: scale=0.25; upsample-backward: scale=1)
@@ -371,6 +393,16 @@ int osm_gn_bwd_apply_h(const osm_half_t* x, long long ldx, const osm_half_t* dy,
                        const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                        const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
                        long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
+int osm_gn_coop_plan_h(int B, int HW, int C, int G, int mode);
+int osm_gn_coop_set_h(const char* key, long long value);
+long long osm_gn_coop_ws_bytes_h(int B, int HW, int C, int G, int mode);
+int osm_gn_fwd_coop_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G, float eps,
+                      float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
+                      float* maxabs_out, float* maxabs_in, void* ws, void* stream);
+int osm_gn_bwd_coop_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
+                      const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C,
+                      int G, const float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm,
+                      int silu, float* gstats, float* maxabs_out, void* ws, void* stream);
 int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,

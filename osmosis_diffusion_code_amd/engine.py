@@ -464,10 +464,36 @@ class UNetEngine:
             ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
         else:
             # xin_max: the caller asked for max |x| of the INPUT as well (it has checked that this branch is the one taken)
-            ops.gn_fwd(x, a, B, H * W, G, self.gn_part, st, norm.g, norm.b, film=film, silu=True, maxabs=xm, maxabs_in=xin_max)
+            self._gn_fwd(x, a, H * W, st, norm, film=film, silu=True, maxabs=xm, maxabs_in=xin_max)
             xin_max = None
         assert xin_max is None, "max |x| of the input was requested on a path that has no statistics pass over x"
         return self._conv(a, cv, y, hw, res=res, stat=stat, xmax=xm)
+
+    # ------------------------------------------------------------------ GroupNorm dispatch
+    def _gn_fwd(self, x: Mat, y: Mat, HW: int, st, norm: _Norm, film=None, silu=True, maxabs=None, maxabs_in=None):
+        """statistics + normalise (+FiLM) (+SiLU).  Where the cooperative single-read kernel has a plan for the shape (the tensor
+        fits the register file: ONE launch, x read once) it runs, with a workspace of its own per call site; otherwise the
+        one-launch kernels (small tensors) / the chunked two-pass path."""
+        B = self.B
+        half = x.t.dtype == torch.float16
+        if ops.gn_coop_plan(B, HW, x.cols, G, 0, half=half) > 0:
+            ws = ops.gn_coop_workspace(B, HW, x.cols, G, 0, self.dev, half=half)
+            ops.gn_fwd_coop(x, y, B, HW, G, st, norm.g, norm.b, ws, film=film, silu=silu, maxabs=maxabs, maxabs_in=maxabs_in)
+        else:
+            ops.gn_fwd(x, y, B, HW, G, self.gn_part, st, norm.g, norm.b, film=film, silu=silu, maxabs=maxabs,
+                       maxabs_in=maxabs_in)
+
+    def _gn_bwd(self, x: Mat, dy: Mat, dx: Mat, HW: int, st, norm: _Norm, gst, film=None, silu=True, addend=None,
+                addend2=None, maxabs=None):
+        B = self.B
+        half = x.t.dtype == torch.float16
+        if ops.gn_coop_plan(B, HW, x.cols, G, 1, half=half) > 0:
+            ws = ops.gn_coop_workspace(B, HW, x.cols, G, 1, self.dev, half=half)
+            ops.gn_bwd_coop(x, dy, dx, B, HW, G, st, norm.g, norm.b, gst, ws, film=film, silu=silu, addend=addend,
+                            addend2=addend2, maxabs=maxabs)
+        else:
+            ops.gn_bwd(x, dy, dx, B, HW, G, st, norm.g, norm.b, self.gn_part, gst, film=film, silu=silu, addend=addend,
+                       addend2=addend2, maxabs=maxabs)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):
@@ -480,7 +506,7 @@ class UNetEngine:
             a1 = self._scr("a", M, blk.cin)
             hwo = (2 * H, 2 * W) if blk.up else (H // 2, W // 2)
             xm1 = self._xmax_from_gn(blk.c1, hwo, hw, "gn")      # max |pool(a)|, max |upsample(a)| <= max |a|
-            ops.gn_fwd(x, a1, B, HW, G, self.gn_part, st1, blk.n1.g, blk.n1.b, silu=True, maxabs=xm1)
+            self._gn_fwd(x, a1, HW, st1, blk.n1, silu=True, maxabs=xm1)
             if blk.up:
                 ho, wo = 2 * H, 2 * W
                 a1r = self._scr("b", B * ho * wo, blk.cin)
@@ -553,8 +579,7 @@ class UNetEngine:
             ops.gn_bwd_apply(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], gst, blk.n2.g, blk.n2.b, film=s["film"],
                              silu=True, maxabs=xmh)
         else:
-            ops.gn_bwd(s["h1"], dh2, dh1, B, ho * wo, G, s["st2"], blk.n2.g, blk.n2.b, self.gn_part, gst,
-                       film=s["film"], silu=True, maxabs=xmh)
+            self._gn_bwd(s["h1"], dh2, dh1, ho * wo, s["st2"], blk.n2, gst, film=s["film"], silu=True, maxabs=xmh)
         da1r = self._scr("a", Mo, blk.cin)
         cs1 = self._conv(dh1, blk.c1, da1r, (ho, wo), dgrad=True,
                          stat=("bwd", s["x"], s["tab1"]) if s["tab1"] is not None else None, xmax=xmh)
@@ -592,8 +617,7 @@ class UNetEngine:
             ops.gn_bwd_apply(s["x"], da1, dx_dst, B, H * W, G, s["st1"], gst1, blk.n1.g, blk.n1.b, silu=True, addend=add,
                              addend2=add2, maxabs=xmo)
         else:
-            ops.gn_bwd(s["x"], da1, dx_dst, B, H * W, G, s["st1"], blk.n1.g, blk.n1.b, self.gn_part, gst1,
-                       silu=True, addend=add, addend2=add2, maxabs=xmo)
+            self._gn_bwd(s["x"], da1, dx_dst, H * W, s["st1"], blk.n1, gst1, silu=True, addend=add, addend2=add2, maxabs=xmo)
 
     # ------------------------------------------------------------------ Attention
     def _gemm(self, *a, **kw):
@@ -621,7 +645,7 @@ class UNetEngine:
         ch, (qo, ko, vo), hs = self._attn_offsets(blk)
         st = self._small(B * G * 2)
         xn = self._scr("a", M, C)
-        ops.gn_fwd(x, xn, B, T, G, self.gn_part, st, blk.norm.g, blk.norm.b, silu=False)
+        self._gn_fwd(x, xn, T, st, blk.norm, silu=False)
         half = self.adt != torch.float32
         if half:     # the attention core is fp32 in both modes (the reference soft-maxes in fp32, unet.py:431)
             qkv_h = self._scr("b", M, 3 * C)
@@ -720,8 +744,8 @@ class UNetEngine:
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
         gst = self._small(B * G * 2)
         self._xmax_invalidate(dx_dst)       # this pass leaves no max |dx_dst| behind
-        ops.gn_bwd(s["x"], dxn, dx_dst, B, T, G, s["st"], blk.norm.g, blk.norm.b, self.gn_part, gst,
-                   silu=False, addend=dy, addend2=dx_dst if accumulate else None)
+        self._gn_bwd(s["x"], dxn, dx_dst, T, s["st"], blk.norm, gst, silu=False, addend=dy,
+                     addend2=dx_dst if accumulate else None)
 
     # ------------------------------------------------------------------ whole network
     @staticmethod
@@ -851,8 +875,7 @@ class UNetEngine:
         if self.conv_mode == "f16x3" and ops.gn_nchunk(H * W) <= ops.MAXABS_PARTS:
             xmo = self._small(B * ops.MAXABS_PARTS)
             self._xmax_register(dy, xmo)
-        ops.gn_bwd(self.h_last, da, dy, B, H * W, G, self.st_out, self.out_norm.g, self.out_norm.b, self.gn_part,
-                   gst, silu=True, maxabs=xmo)
+        self._gn_bwd(self.h_last, da, dy, H * W, self.st_out, self.out_norm, gst, silu=True, maxabs=xmo)
         if self.adt != f32:
             dy_h = self._buf(B * H * W, self.h_last.cols)
             ops.convert(dy, dy_h)

@@ -37,6 +37,11 @@ CONV_VARIANTS = [
 ]
 
 
+# the dominant kernel of BASELINE config 5 (B = 32, use_fp16): the direct kernel, one fp16 MFMA per product
+F16_SHAPES = ["32,256,256,256,256,3", "32,128,128,256,256,3", "32,64,64,512,512,3"]
+F16_VARIANT = ("conv3_halo_bf16s_kernel<1,*> (direct, fp16 storage: config 5)", ["--mode", "f16"], "conv3_halo", 1, 1.0)
+
+
 def collect(cmd_tail, substrs):
     """One rocprofv3 --pmc run (counters only); per kernel-name substring: counter -> [sum, dispatches, total us]."""
     d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
@@ -82,6 +87,11 @@ def main():
         for label, args, sub, nmfma, ef in CONV_VARIANTS:
             acc = collect([probe, "--shape", shape, "--iters", "10"] + args, [sub])[sub]
             rows.append(row(label, acc, flops, nmfma, ef, {"shape_B,H,W,Cin,Cout,k": shape}))
+    for shape in F16_SHAPES:
+        B, H, W, Cin, Cout, k = (int(v) for v in shape.split(","))
+        label, args, sub, nmfma, ef = F16_VARIANT
+        acc = collect([probe, "--shape", shape, "--iters", "6"] + args, [sub])[sub]
+        rows.append(row(label, acc, 2.0 * B * H * W * Cin * Cout * k * k, nmfma, ef, {"shape_B,H,W,Cin,Cout,k": shape}))
     # attention cores (a counter behind bench.py's attention_mfma_util): per kernel of the flash family
     for shape in ATTN:
         B, T, heads = (int(v) for v in shape.split(","))

@@ -3,9 +3,11 @@
 # evidence for the clock the power manager grants under the bf16x6 MFMA stream.   usage: tools/power_probe.sh <out.txt> [extra conv_probe args, e.g. --winograd]
 repo=$(cd "$(dirname "$0")/.." && pwd)
 out=$1; shift
+shape=${SHAPE:-1,256,256,256,256,3}      # SHAPE=32,256,256,256,256,3 with --mode f16: the dominant kernel of BASELINE config 5
+iters=${ITERS:-60000}
 {
   echo "== idle"; rocm-smi --showpower --showclocks --showperflevel --showmaxpower 2>&1 | grep -v "^$" | head -40
-  python "$repo/tools/conv_probe.py" --shape 1,256,256,256,256,3 --iters 60000 "$@" > /tmp/probe_busy.txt 2>&1 &
+  python "$repo/tools/conv_probe.py" --shape $shape --iters $iters "$@" > /tmp/probe_busy.txt 2>&1 &
   pid=$!
   for w in $(seq 1 170); do     # wait for the load (the first import of torch on a fresh box takes 1-2 minutes)
     pw=$(rocm-smi --showpower 2>/dev/null | grep -oE "Power \(W\): [0-9.]+" | grep -oE "[0-9.]+$" | head -1)
