@@ -52,7 +52,7 @@ class AttnDesc(C.Structure):
                 ("q_off", C.c_int), ("k_off", C.c_int), ("v_off", C.c_int), ("head_stride", C.c_int),
                 ("B", C.c_int), ("T", C.c_int), ("heads", C.c_int), ("ch", C.c_int), ("scale", C.c_float),
                 ("out", C.c_void_p), ("ldout", C.c_longlong), ("dout", C.c_void_p), ("lddout", C.c_longlong),
-                ("dqkv", C.c_void_p), ("lddqkv", C.c_longlong), ("ws", C.c_void_p)]
+                ("dqkv", C.c_void_p), ("lddqkv", C.c_longlong), ("ws", C.c_void_p), ("arith", C.c_int)]
 
 
 class PhysDesc(C.Structure):

@@ -21,10 +21,15 @@
 //     128-byte-coalesced rows.
 #include "osm_common.h"
 #include "mfma_split.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
-constexpr int NP = 3;      // bf16x6
+// NP (template parameter of everything below): 3 = bf16x6 (fp32 operands split exactly into three bf16 planes, six MFMAs per product:
+// the fp32-class arithmetic of the fp32 family);  1 = ONE IEEE-half plane, one fp16 MFMA per product with fp32 accumulation: what the
+// reference's use_fp16 attention computes (QKVAttentionLegacy on half tensors: fp16 einsum, softmax in fp32, unet.py:426-433) --
+// osm_attn_desc.arith = 1, the fp16-storage family (round 4: the core was bf16x6 there too, 6x the matrix work the reference asks for).
 constexpr int DH = 64;     // head width
 
 struct FlashArgs {
@@ -47,6 +52,7 @@ struct FlashArgs {
 };
 
 // X[row][col + 16 s + 8 h + e], e = 0..7  ->  NP fragments (A operand: rows x k; or B operand: k x columns)
+template <int NP>
 __device__ __forceinline__ void frag_row(const float* __restrict__ X, long long ld, long long row, int col, int s, int h,
                                          float scale, uint4 (&f)[NP]) {
   const float* p = X + row * ld + col + 16 * s + 8 * h;
@@ -57,6 +63,7 @@ __device__ __forceinline__ void frag_row(const float* __restrict__ X, long long 
 }
 // X[row0 + 16 s + (e & 3) + 8 (e >> 2) + 4 h][col], e = 0..7: the operand contracted over its row index, in the
 // slot order in which a C-layout accumulator hands over the other operand
+template <int NP>
 __device__ __forceinline__ void frag_gather(const float* __restrict__ X, long long ld, long long row0, int col, int s,
                                             int h, uint4 (&f)[NP]) {
   const float* p = X + (row0 + 16 * s + 4 * h) * ld + col;
@@ -65,6 +72,7 @@ __device__ __forceinline__ void frag_gather(const float* __restrict__ X, long lo
   split_frag8<NP>(a, b, f);
 }
 // accumulator registers [8 s .. 8 s + 7] -> fragment of step s
+template <int NP>
 __device__ __forceinline__ void frag_acc(const f32x16& c, int s, uint4 (&f)[NP]) {
   if (s == 0)
     split_frag8<NP>(make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7]), f);
@@ -83,7 +91,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // 32 NSUB at a time (NSUB = 2 independent 32-key logit tiles where the range allows: two MFMA accumulator chains).
 // WV = waves per workgroup (4, or 8 = two per SIMD: at B = 1 the grid is one workgroup per CU, so the second wave per SIMD is the
 // only latency hiding there is -- every fragment goes global load -> split -> MFMA with nothing prefetched).
-template <int NSUB, int WV>
+template <int NP, int NSUB, int WV>
 __global__ __launch_bounds__(64 * WV, 1) void flash_fwd_kernel(FlashArgs a) {
   __shared__ float os[WV][DH][33];
   __shared__ float ms[WV][32];
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_fwd_kernel(FlashArgs a) {
 // dq: grid (T / 32, heads, B): workgroup = 32 queries, waves split the keys.
 //   S^T = K (scale Q)^T, P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);
 //   dq^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
-template <int WV>
+template <int NP, int WV>
 __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
   __shared__ float os[WV][DH][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
 // dk, dv: grid (T / 32, heads, B): workgroup = 32 keys, waves split the queries.
 //   S = (scale Q) K^T (queries x keys: column = this lane's key), P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q]);
 //   dv^T[d][key] = sum_q dO^T[d][q] P[q][key];   dk^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
-template <int WV>
+template <int NP, int WV>
 __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
   __shared__ float os[WV][2 * DH][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
@@ -392,6 +400,7 @@ int check(const osm_attn_desc* d, const char* who) {
   OSM_REQUIRE(d->ch == DH && d->T >= 64 && d->T % (32 * nw_of(d->T)) == 0,
               "%s: needs 64-wide heads and T a multiple of 64 (of 128 from T = 128) (got ch %d, T %d)", who, d->ch, d->T);
   OSM_REQUIRE(d->B > 0 && d->heads > 0, "%s: bad shape", who);
+  OSM_REQUIRE(d->arith == 0 || d->arith == 1, "%s: arith must be 0 (bf16x6) or 1 (fp16)", who);
   OSM_REQUIRE(d->ldqkv % 4 == 0 && d->q_off % 4 == 0 && d->k_off % 4 == 0 && d->v_off % 4 == 0 && d->head_stride % 4 == 0 &&
               osm::aligned16(d->qkv), "%s: qkv columns must be 16-byte aligned", who);
   return OSM_OK;
@@ -418,14 +427,21 @@ extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stre
   a.lse = lse;
   const dim3 g(d->T / 32, d->heads, d->B);
   const bool two = (d->T / a.nw) % 64 == 0;
-  if (a.nw == 8) {
-    if (two) hipLaunchKernelGGL((flash_fwd_kernel<2, 8>), g, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((flash_fwd_kernel<1, 8>), g, dim3(512), 0, (hipStream_t)stream, a);
-  } else if (two) {
-    hipLaunchKernelGGL((flash_fwd_kernel<2, 4>), g, dim3(256), 0, (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL((flash_fwd_kernel<1, 4>), g, dim3(256), 0, (hipStream_t)stream, a);
-  }
+  const hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](auto np) {
+    constexpr int P = decltype(np)::value;
+    if (a.nw == 8) {
+      // (the one-plane instance with two logit tiles in flight spills 48 registers at two waves per SIMD: one tile there)
+      if (two && P != 1) hipLaunchKernelGGL((flash_fwd_kernel<P, 2, 8>), g, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((flash_fwd_kernel<P, 1, 8>), g, dim3(512), 0, st, a);
+    } else if (two) {
+      hipLaunchKernelGGL((flash_fwd_kernel<P, 2, 4>), g, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((flash_fwd_kernel<P, 1, 4>), g, dim3(256), 0, st, a);
+    }
+  };
+  if (d->arith == 1) launch(std::integral_constant<int, 1>{});
+  else launch(std::integral_constant<int, 3>{});
   return osm::check_launch("flash_fwd_kernel");
 }
 
@@ -439,10 +455,17 @@ extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long
   a.o = out; a.ldo = ldout; a.lse = const_cast<float*>(lse); a.delta = delta;
   OSM_REQUIRE(ldout % 4 == 0 && osm::aligned16(out), "osm_attn_flash_bwd: out must be 16-byte aligned");
   const dim3 g(d->T / 32, d->heads, d->B);       // (delta is formed by the dq kernel and read by the dk / dv kernel after it)
-  if (a.nw == 8) hipLaunchKernelGGL(flash_bwd_q_kernel<8>, g, dim3(512), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(flash_bwd_q_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a);
-  // (the dk / dv kernel holds K, V fragments and four accumulators: 368 registers -- it stays at one wave per SIMD)
-  if (a.nw > 4) a.nw = 4;
-  hipLaunchKernelGGL(flash_bwd_kv_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a);
+  const hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](auto np) {
+    constexpr int P = decltype(np)::value;
+    if (a.nw == 8) hipLaunchKernelGGL((flash_bwd_q_kernel<P, 8>), g, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((flash_bwd_q_kernel<P, 4>), g, dim3(256), 0, st, a);
+    // (the bf16x6 dk / dv kernel holds K, V fragments and four accumulators: 368 registers -- it stays at one wave per SIMD)
+    FlashArgs b = a;
+    if (b.nw > 4) b.nw = 4;
+    hipLaunchKernelGGL((flash_bwd_kv_kernel<P, 4>), g, dim3(256), 0, st, b);
+  };
+  if (d->arith == 1) launch(std::integral_constant<int, 1>{});
+  else launch(std::integral_constant<int, 3>{});
   return osm::check_launch("flash_bwd kernels");
 }

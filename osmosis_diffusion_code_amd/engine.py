@@ -268,6 +268,7 @@ class UNetEngine:
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs == "all"
         self._check_xmax = os.environ.get("OSM_CHECK_XMAX", "0") == "1"
+        self._attn_half = self.adt == torch.float16 and os.environ.get("OSM_ATTN_F16", "1") != "0"
 
         w = weights
         self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
@@ -674,7 +675,9 @@ class UNetEngine:
         if flash:      # logits / probabilities stay in registers; the output and its log-sum-exp are kept for the backward
             a = self._buf(M, C, torch.float32)
             lse = self._small(nmat * T)
-            ops.attn_flash_fwd(qkv, a, lse, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+            # fp16-storage family: one fp16 MFMA per product, fp32 accumulation and softmax -- what the reference's half attention
+            # computes (unet.py:426-433); OSM_ATTN_F16=0 keeps the fp32-class bf16x6 core there too (rounds 2-3)
+            ops.attn_flash_fwd(qkv, a, lse, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half)
         elif fused:    # 8x8: logits stay on the CU, one launch, nothing kept for the backward
             ops.attn_small_fwd(qkv, a, B, T, nh, ch, (qo, ko, vo), hs, alpha)
         else:
@@ -717,7 +720,7 @@ class UNetEngine:
         dqkv = self._scr("b", M, 3 * C, torch.float32)
         if s["flash"]:
             delta = self._scr_flat("s0", nmat * T)
-            ops.attn_flash_bwd(qkv, s["a"], da, dqkv, s["lse"], delta, B, T, nh, ch, (qo, ko, vo), hs, alpha)
+            ops.attn_flash_bwd(qkv, s["a"], da, dqkv, s["lse"], delta, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half)
         elif s["fused"]:
             ws = self._scr_flat("s0", 2 * nmat * T * T)
             ops.attn_small_bwd(qkv, da, dqkv, ws, B, T, nh, ch, (qo, ko, vo), hs, alpha)

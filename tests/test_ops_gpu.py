@@ -355,6 +355,20 @@ def test_attn_flash_fwd_bwd(ops, B, T, heads, new_order):
                        delta, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch))
     e = relerr(dq.cpu().reshape(B, T, 3 * C), dref.float())
     assert e < 1e-5, e
+    # the fp16-storage family's arithmetic (round 4): ONE half plane per operand, one fp16 MFMA per product, fp32 accumulation and
+    # softmax -- the reference's use_fp16 attention (unet.py:426-433 on half tensors).  Operands and P are rounded to half (2^-11
+    # relative each); stated tolerance 2e-3 of the max-abs forward, 4e-3 for the gradients (five chained GEMMs)
+    oh = torch.full((B * T, C), float("nan"), device=DEV)
+    lh = torch.full((B * heads * T,), float("nan"), device=DEV)
+    ops.attn_flash_fwd(ops.Mat.of(qd), ops.Mat.of(oh), lh, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch), half=True)
+    eh = relerr(oh.cpu().reshape(B, T, C), ref.float())
+    assert 1e-6 < eh < 2e-3, eh               # really the half arithmetic, and within its tolerance
+    assert float((lh.cpu().reshape(B, heads, T) - lref).abs().max()) < 2e-2
+    dqh = torch.full((B * T, 3 * C), float("nan"), device=DEV)
+    ops.attn_flash_bwd(ops.Mat.of(qd), ops.Mat.of(oh), ops.Mat.of(dout.reshape(B * T, C).to(DEV)), ops.Mat.of(dqh), lh,
+                       delta, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch), half=True)
+    eh = relerr(dqh.cpu().reshape(B, T, 3 * C), dref.float())
+    assert eh < 4e-3, eh
 
 
 def test_attn_small_rejects_other_shapes(ops):
