@@ -117,7 +117,7 @@ class RankSync:
 
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tmo = datetime.timedelta(seconds=max(30.0, self._timeout))
+        tmo = datetime.timedelta(seconds=max(10.0, self._timeout))
 
         def ensure_default_group():
             # gloo is the default group: it only needs TCP on 127.0.0.1; RCCL rides on it as a sub-group, so a failed /
@@ -145,7 +145,7 @@ class RankSync:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g)
             torch.cuda.current_stream(self.device).synchronize()
             assert float(t.item()) == self.world * (self.world - 1) / 2.0, "rccl all_reduce returned a wrong sum"
-            dist.barrier(group=g)
+            dist.barrier(group=g, device_ids=[torch.device(self.device).index])
             self._group = g
         ok, why, hung = self._run_with_timeout(fn)
         if hung:
@@ -181,34 +181,61 @@ class RankSync:
             time.sleep(0.0002)
 
     # -- the two primitives -----------------------------------------------------------------------------------------------
+    # Every round ALSO leaves each rank's payload in the node-local directory before the collective is tried: a rank whose
+    # collective raises (alone or with the others) finishes the round from those files, while the ranks whose collective
+    # returned move on -- no rank can be left waiting for a fallback the others never entered.
+    def _degrade(self, why: Exception):
+        self.failures[self.transport] = "failed after selection: %s: %s" % (type(why).__name__, str(why).replace("\n", " ")[:200])
+        self.transport = "files"
+
+    def _file_post(self, tag: str, values):
+        import json
+        import os
+        path = os.path.join(self.dir, "%s_r%d.json" % (tag, self.rank))
+        with open(path + ".tmp", "w") as f:
+            json.dump([float(v) for v in values], f)
+        os.replace(path + ".tmp", path)
+
     def all_gather(self, values: Sequence[float]) -> List[List[float]]:
         """Every rank passes the same number of floats; returns the per-rank lists in rank order."""
         vals = [float(v) for v in values]
         if self.world == 1:
             return [vals]
         self._round += 1
+        tag = "g%d" % self._round
         if self.transport == "files":
-            return self._file_gather("g%d" % self._round, vals)
-        import torch.distributed as dist
-        dev = self.device if self.transport == "rccl" else None
-        mine = torch.tensor(vals, dtype=torch.float64, device=dev)
-        allv = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(allv, mine, group=self._group if self.transport == "rccl" else None)
-        return [[float(x) for x in t.cpu()] for t in allv]
+            return self._file_gather(tag, vals)
+        self._file_post(tag, vals)
+        try:
+            import torch.distributed as dist
+            dev = self.device if self.transport == "rccl" else None
+            mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+            allv = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(allv, mine, group=self._group if self.transport == "rccl" else None)
+            return [[float(x) for x in t.cpu()] for t in allv]
+        except Exception as e:      # noqa: BLE001 -- the measurement outlives the collective library
+            self._degrade(e)
+            return self._file_gather(tag, vals)
 
     def barrier(self) -> None:
         if self.world == 1:
             return
+        self._round += 1
+        tag = "b%d" % self._round
         if self.transport == "files":
-            self._round += 1
-            self._file_gather("b%d" % self._round, [0.0])
+            self._file_gather(tag, [0.0])
             return
-        import torch.distributed as dist
-        if self.transport == "rccl":
-            dist.barrier(group=self._group)
-            torch.cuda.current_stream(self.device).synchronize()   # an RCCL barrier is a kernel: the host must see it done
-        else:
-            dist.barrier()
+        self._file_post(tag, [0.0])
+        try:
+            import torch.distributed as dist
+            if self.transport == "rccl":
+                dist.barrier(group=self._group, device_ids=[torch.device(self.device).index])
+                torch.cuda.current_stream(self.device).synchronize()   # an RCCL barrier is a kernel: the host must see it done
+            else:
+                dist.barrier()
+        except Exception as e:      # noqa: BLE001
+            self._degrade(e)
+            self._file_gather(tag, [0.0])
 
     def max(self, value: float) -> float:
         return max(v[0] for v in self.all_gather([value]))
