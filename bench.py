@@ -539,7 +539,7 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: roofline.traffic is measured in this run (two short child runs under rocprofv3 --pmc, rank 0, N = 1); "
                          "off: relayed from the committed profile")
-    ap.add_argument("--pmc-timeout", type=float, default=240.0, help="seconds allowed per rocprofv3 child run")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0, help="seconds allowed per rocprofv3 child run")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="2: the headline workload (default).  3 / 5: time ONLY that BASELINE configuration (profiling target) and "
                          "print its compact line")
