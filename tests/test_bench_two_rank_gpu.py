@@ -105,3 +105,26 @@ def test_bench_survives_rccl_failure(tmp_path):
         assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
         assert max(d["per_rank_ms"]) <= d["ms_per_step"] * 1.001
         assert [r["sha1"] for r in ranks] == [r["sha1"] for r in ref_ranks]        # same images, same bits, whatever the transport
+
+
+def test_bench_two_ranks_full_size_with_the_config4_leg(tmp_path):
+    """What the driver's SCALE run executes at N > 1 with the default flags, on the one GPU of the test box (gloo, two ranks share
+    cuda:0): the headline leg, then the config-4 leg on EVERY rank (a batch of `--images-per-gpu` chains per rank through the same
+    model / weight images, barriers through RankSync), one JSON line whose first `secondary` entry is that leg."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, OSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OSM_BENCH_DUMP=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                          "--secondary-steps", "1", "--images-per-gpu", "2"], env=env, capture_output=True, text=True, timeout=1200,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective"] == "gloo" and d["ranks_seen"] == 2 and d["per_rank_image"] == [0, 1]
+    assert "cpu_baseline" not in d and len(d["secondary"]) == 1          # N > 1: only the leg every rank runs
+    c4 = d["secondary"][0]
+    assert "error" not in c4, c4
+    assert c4["workload"].startswith("config 4") and c4["images_per_gpu"] == 2 and c4["n_gpus"] == 2 and c4["ranks_seen"] == 2
+    assert c4["finite_outputs"] and abs(c4["image_steps_per_s"] - 2 * 2 * 1 / (c4["ms_per_step"] * 1e-3)) < 1e-2 * c4["image_steps_per_s"]
+    assert len({json.load(open(tmp_path / f"rank{r}_of_2.json"))["sha1"] for r in range(2)}) == 2
