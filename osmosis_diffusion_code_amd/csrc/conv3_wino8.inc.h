@@ -29,6 +29,12 @@
 #ifndef W8_TSHARE
 #define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
 #endif
+#ifndef W8_PRIO
+#define W8_PRIO 0        // measurement builds: s_setprio level around the MFMA group of a unit (0: none)
+#endif
+#ifndef W8_PRIO_BUILD
+#define W8_PRIO_BUILD 0  // measurement builds: s_setprio level around the V build of a unit (0: none)
+#endif
 constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
 
 // HP ("f16x3", NP = 2): the two planes of V and of U are IEEE halfs of the operands scaled into the fp16 range -- V by
@@ -212,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 // use_ 1: t[cb] comes from ts[tb_], 2: t[ca] comes from ts[tb_] (no LDS reads / FMAs for that column).
 #define OSM_W8_BUILD(par_, ca_, cb_, sb_, tb_, bo_, keep_, use_)                           \
   {                                                                                        \
+    if (W8_PRIO_BUILD) __builtin_amdgcn_s_setprio(W8_PRIO_BUILD);                          \
     uint2 vh_[2][NP];                                                                      \
     _Pragma("unroll") for (int hq = 0; hq < 2; ++hq) {                                     \
       const int oa_ = (bo_) + hq * WN_QP + 8 * (tb_) * WN_ROWP + ((ca_) & 1) * 10 + ((ca_) >> 1); \
@@ -254,9 +261,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     }                                                                                      \
     _Pragma("unroll") for (int q2 = 0; q2 < NP; ++q2)                                      \
       va[par_][q2] = make_uint4(vh_[0][q2].x, vh_[0][q2].y, vh_[1][q2].x, vh_[1][q2].y);   \
+    if (W8_PRIO_BUILD) __builtin_amdgcn_s_setprio(0);                                      \
   }
 // the 12 MFMAs of unit (jj_, tb_): smallest plane-pair terms first
 #define OSM_W8_MMA(par_, jj_, tb_)                                                         \
+  if (W8_PRIO) __builtin_amdgcn_s_setprio(W8_PRIO);                                        \
+  OSM_W8_MMA_BODY(par_, jj_, tb_)                                                          \
+  if (W8_PRIO) __builtin_amdgcn_s_setprio(0);
+#define OSM_W8_MMA_BODY(par_, jj_, tb_)                                                    \
   _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
     _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                        \
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #undef OSM_W8_LOAD_U
 #undef OSM_W8_BUILD
 #undef OSM_W8_MMA
+#undef OSM_W8_MMA_BODY
 #undef OSM_W8_FENCE
 
   if ((W8_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
