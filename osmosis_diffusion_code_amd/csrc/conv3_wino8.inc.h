@@ -29,6 +29,13 @@
 #ifndef W8_TSHARE
 #define W8_TSHARE 1      // 1: the t column the two xi of a wave share is formed once per slab and tile block
 #endif
+#ifndef W8_ORDER
+#define W8_ORDER 0       // measurement builds: 1 = a unit's MFMAs are written BEFORE the build of the next unit's A fragments; 2 = as 1, and the
+                         // unit is pinned to "8 LDS reads, then 6 x (1 MFMA, W8_SGB_VALU VALU)" with sched_group_barrier
+#endif
+#ifndef W8_SGB_VALU
+#define W8_SGB_VALU 8
+#endif
 #ifndef W8_PRIO
 #define W8_PRIO 0        // measurement builds: s_setprio level around the MFMA group of a unit (0: none)
 #endif
@@ -278,6 +285,20 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
           if (W8_DBL & 4) acc[jj_][tb_][b] = mma16h(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]); \
         }                                                                                  \
         else acc[jj_][tb_][b] = mma16<NP>(va[par_][pa], uq[jj_][b][pb], acc[jj_][tb_][b]);
+// one unit: the build of the NEXT unit's A fragments and the MFMAs of the current one (independent of each other)
+#if W8_ORDER == 0
+#define OSM_W8_UNIT(build_, mma_) build_ mma_
+#elif W8_ORDER == 1
+#define OSM_W8_UNIT(build_, mma_) mma_ build_
+#else
+#define OSM_W8_UNIT(build_, mma_)                                                          \
+  mma_ build_                                                                              \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   /* the build's LDS reads first */   \
+  _Pragma("unroll") for (int sg_ = 0; sg_ < 6; ++sg_) {                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          /* one MFMA */             \
+    __builtin_amdgcn_sched_group_barrier(0x002, W8_SGB_VALU, 0); /* VALU of the build */    \
+  }
+#endif
 // nothing crosses a unit boundary (keeps the prefetch distance of the loads and the live ranges of va / uq as written)
 #ifndef W8_FENCE_MODE
 #define W8_FENCE_MODE 0
@@ -312,24 +333,20 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       // unit 0 = (xi 0, block 0) | builds (xi 0, block 1); U of xi 1 for this slab
       OSM_W8_LOAD_U(c, 1)
       OSM_W8_STORE_RAW(c + 1, 0) OSM_W8_LOAD_RAW(c2, 0)
-      OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo, TSH, 0)
-      OSM_W8_MMA(0, 0, 0)
+      OSM_W8_UNIT(OSM_W8_BUILD(1, CA0, CB0, -1.f, 1, bo, TSH, 0), OSM_W8_MMA(0, 0, 0))
       OSM_W8_FENCE()
       // unit 1 = (xi 0, block 1) | builds (xi 1, block 0)
       OSM_W8_STORE_RAW(c + 1, 1) OSM_W8_LOAD_RAW(c2, 1)
-      OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo, 0, USE1)
-      OSM_W8_MMA(1, 0, 1)
+      OSM_W8_UNIT(OSM_W8_BUILD(0, CA1, CB1, SB1, 0, bo, 0, USE1), OSM_W8_MMA(1, 0, 1))
       OSM_W8_FENCE()
       // unit 2 = (xi 1, block 0) | builds (xi 1, block 1); U of xi 0 for the next slab
       OSM_W8_LOAD_U(c1, 0)
       OSM_W8_STORE_RAW(c + 1, 2) OSM_W8_LOAD_RAW(c2, 2) OSM_W8_LOAD_TAB(c2)
-      OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo, 0, USE1)
-      OSM_W8_MMA(0, 1, 0)
+      OSM_W8_UNIT(OSM_W8_BUILD(1, CA1, CB1, SB1, 1, bo, 0, USE1), OSM_W8_MMA(0, 1, 0))
       OSM_W8_FENCE()
       if (!(W8_ABL & 1024)) __syncthreads();          // raw(c + 1) is complete in its buffer; nobody reads raw(c) any more
       // unit 3 = (xi 1, block 1) | builds (xi 0, block 0) of slab c + 1
-      OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, TSH, 0)
-      OSM_W8_MMA(1, 1, 1)
+      OSM_W8_UNIT(OSM_W8_BUILD(0, CA0, CB0, -1.f, 0, bn, TSH, 0), OSM_W8_MMA(1, 1, 1))
       OSM_W8_FENCE()
     }
   };
@@ -344,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #undef OSM_W8_BUILD
 #undef OSM_W8_MMA
 #undef OSM_W8_MMA_BODY
+#undef OSM_W8_UNIT
 #undef OSM_W8_FENCE
 
   if ((W8_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
