@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--coop-kb", nargs="*", type=int, default=[32],
                     help="also time the cooperative single-read kernel with these KB-per-workgroup targets (empty: skip)")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-silu", action="store_true", help="normalise only (how much of a pass is the SiLU / dSiLU arithmetic?)")
     a = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes] if a.shapes else SHAPES
     dev = torch.device("cuda:0")
@@ -52,16 +53,16 @@ def main():
 
         def fwd(s):
             x, dy, dx, y = s
-            ops.gn_fwd(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, part, stats, gamma, beta, maxabs=mx)
+            ops.gn_fwd(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, part, stats, gamma, beta, maxabs=mx, silu=not a.no_silu)
 
         def apply(s):
             x, dy, dx, y = s
-            ops.gn_apply(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, stats, gamma, beta, maxabs=mx)
+            ops.gn_apply(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, stats, gamma, beta, maxabs=mx, silu=not a.no_silu)
 
         def bwd(s):
             x, dy, dx, y = s
             ops.gn_bwd(ops.Mat.of(x), ops.Mat.of(dy), ops.Mat.of(dx), B, HW, G, stats, gamma, beta, part, gstats,
-                       addend=ops.Mat.of(dx), maxabs=mx)
+                       addend=ops.Mat.of(dx), maxabs=mx, silu=not a.no_silu)
 
         def timed(name, fn, nb, note=""):
             for s in sets[:2]:
