@@ -139,6 +139,7 @@ class RankSync:
             assert self.device is not None and torch.device(self.device).type == "cuda", "rccl needs a HIP device"
             # a failed / timed-out RCCL collective must raise here, not let torch's NCCL watchdog tear the process down
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            torch.cuda.set_device(self.device)          # the current device is per THREAD: this probe runs in its own
             ensure_default_group()
             g = dist.new_group(backend="nccl", timeout=tmo)
             t = torch.tensor([float(self.rank)], dtype=torch.float64, device=self.device)
