@@ -19,6 +19,8 @@ Sections (SURVEY.md section 8c recipe):
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
+  fp16_reference.npz  (round 4) the reference with convert_to_fp16() applied, on CPU: tiny UNet forward / input gradient and the
+                      10-step guided loop in fp16, next to the fp32 reference on the same inputs
 """
 import os
 import sys
@@ -197,67 +199,105 @@ PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local
                n_iter=20, start_guidance=1, stop_guidance=0)
 
 
+def _loop_trace(m, spec):
+    """10-step guided p_sample_loop of the reference (model m) for one operator spec; every randn_like draw logged."""
+    operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
+    noiser = get_noise(name="clean")
+    cond = get_conditioning_method("osmosis", operator, noiser, **spec["cond"], **PATTERN, **spec["aux"])
+    sampler = R_gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10),
+                                       betas=R_gd.get_named_beta_schedule("linear", 1000),
+                                       model_mean_type="epsilon", model_var_type="learned_range",
+                                       dynamic_threshold=False, clip_denoised=False,
+                                       rescale_timesteps=False)
+    x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(0))
+    y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
+
+    trace = []
+    orig_cond = cond.conditioning
+
+    def traced(**kw):
+        rec = {"x_in": kw["x_prev"].detach().clone(), "x0": kw["x_0_hat"].detach().clone(),
+               "mean": kw["x_t"].detach().clone()}
+        ret = orig_cond(**kw)
+        rec["x_guided"] = ret[0].detach().clone()
+        rec["loss"] = np.array(ret[1], dtype=np.float32)
+        rec["phi"] = {k: v.detach().clone() for k, v in ret[2].items()}
+        rec["grad"] = ret[3].clone()
+        trace.append(rec)
+        return ret
+
+    draws = []
+    orig_randn_like = torch.randn_like
+
+    def logged_randn_like(t, **kw):
+        r = orig_randn_like(t, **kw)
+        draws.append(r.clone())
+        return r
+
+    torch.manual_seed(0)
+    torch.randn_like = logged_randn_like
+    try:
+        img, variables, loss, x0 = sampler.p_sample_loop(
+            model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced,
+            record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+            sample_pattern=PATTERN)
+    finally:
+        torch.randn_like = orig_randn_like
+    # draws alternate: randn_like(measurement) [unused], randn_like(img) [used]  (SURVEY F7)
+    assert len(draws) == 2 * len(trace)
+    used = [d for d in draws if d.shape[1] == 4]
+    out = {"x_T": npy(x_T), "y": npy(y), "final_img": npy(img), "final_x0": npy(x0),
+           "final_loss": np.array(loss, dtype=np.float32),
+           "noise": np.stack([npy(n) for n in used]),
+           "timestep_map": np.array(sampler.timestep_map, dtype=np.int64)}
+    for k, v in variables.items():
+        out[f"final.{k}"] = npy(v)
+    for key in ("x_in", "x0", "mean", "x_guided", "grad"):
+        out[f"trace.{key}"] = np.stack([npy(r[key]) for r in trace])
+    out["trace.loss"] = np.stack([r["loss"] for r in trace])
+    for k in trace[0]["phi"]:
+        out[f"trace.{k}"] = np.stack([npy(r["phi"][k]) for r in trace])
+    return out, loss, variables
+
+
 def gen_loops():
     m, cfg, sd = tiny_model()
     for opname, spec in OPERATORS.items():
-        operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
-        noiser = get_noise(name="clean")
-        cond = get_conditioning_method("osmosis", operator, noiser, **spec["cond"], **PATTERN, **spec["aux"])
-        sampler = R_gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10),
-                                           betas=R_gd.get_named_beta_schedule("linear", 1000),
-                                           model_mean_type="epsilon", model_var_type="learned_range",
-                                           dynamic_threshold=False, clip_denoised=False,
-                                           rescale_timesteps=False)
-        x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(0))
-        y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
-
-        trace = []
-        orig_cond = cond.conditioning
-
-        def traced(**kw):
-            rec = {"x_in": kw["x_prev"].detach().clone(), "x0": kw["x_0_hat"].detach().clone(),
-                   "mean": kw["x_t"].detach().clone()}
-            ret = orig_cond(**kw)
-            rec["x_guided"] = ret[0].detach().clone()
-            rec["loss"] = np.array(ret[1], dtype=np.float32)
-            rec["phi"] = {k: v.detach().clone() for k, v in ret[2].items()}
-            rec["grad"] = ret[3].clone()
-            trace.append(rec)
-            return ret
-
-        draws = []
-        orig_randn_like = torch.randn_like
-
-        def logged_randn_like(t, **kw):
-            r = orig_randn_like(t, **kw)
-            draws.append(r.clone())
-            return r
-
-        torch.manual_seed(0)
-        torch.randn_like = logged_randn_like
-        try:
-            img, variables, loss, x0 = sampler.p_sample_loop(
-                model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced,
-                record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
-                sample_pattern=PATTERN)
-        finally:
-            torch.randn_like = orig_randn_like
-        # draws alternate: randn_like(measurement) [unused], randn_like(img) [used]  
-        assert len(draws) == 2 * len(trace)
-        used = [d for d in draws if d.shape[1] == 4]
-        out = {"x_T": npy(x_T), "y": npy(y), "final_img": npy(img), "final_x0": npy(x0),
-               "final_loss": np.array(loss, dtype=np.float32),
-               "noise": np.stack([npy(n) for n in used]),
-               "timestep_map": np.array(sampler.timestep_map, dtype=np.int64)}
-        for k, v in variables.items():
-            out[f"final.{k}"] = npy(v)
-        for key in ("x_in", "x0", "mean", "x_guided", "grad"):
-            out[f"trace.{key}"] = np.stack([npy(r[key]) for r in trace])
-        out["trace.loss"] = np.stack([r["loss"] for r in trace])
-        for k in trace[0]["phi"]:
-            out[f"trace.{k}"] = np.stack([npy(r["phi"][k]) for r in trace])
+        out, loss, variables = _loop_trace(m, spec)
         np.savez_compressed(os.path.join(OUT, f"loop_{opname}.npz"), **out)
         print(opname, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+
+
+def gen_fp16():
+    """The reference in fp16 -- `create_model(use_fp16=True)` PLUS the `convert_to_fp16()` call its driver forgets (SURVEY F3;
+    unet.py:697-703: input / middle / output blocks to half, time_embed and out stay fp32; GroupNorm32 computes in fp32,
+    attention soft-maxes in fp32) -- on CPU: tiny seeded UNet forward + input gradient, and the 10-step guided loop of the
+    revised underwater operator.  Next to each: the fp32 reference on the same inputs, so that a test can say "the HIP fp16
+    family is as close to the reference's fp16 as the reference's fp16 is to its fp32"."""
+    m32, cfg, sd = tiny_model()
+    m16 = R_unet.create_model(**dict(TINY_KW, use_fp16=True))
+    m16.load_state_dict(sd, strict=True)
+    m16.eval()
+    m16.convert_to_fp16()
+    assert m16.input_blocks[0][0].weight.dtype == torch.float16 and m16.out[2].weight.dtype == torch.float32
+    g = torch.Generator().manual_seed(0)
+    x = 0.7 * torch.randn(2, 4, 32, 32, generator=g)
+    t = torch.tensor([37.0, 5.0])
+    w = torch.randn(2, 8, 32, 32, generator=g)
+    out = {"x": npy(x), "t": npy(t), "w": npy(w)}
+    for tag, m in (("16", m16), ("32", m32)):
+        xr = x.clone().requires_grad_(True)
+        y = m(xr, t)
+        assert y.dtype == torch.float32
+        (dx,) = torch.autograd.grad((y * w).sum(), xr)
+        out["y" + tag], out["dx" + tag] = npy(y), npy(dx)
+    print("tiny UNet: reference fp16 vs reference fp32: y", float(np.abs(out["y16"] - out["y32"]).max()), "of", float(np.abs(out["y32"]).max()),
+          " dx", float(np.abs(out["dx16"] - out["dx32"]).max()), "of", float(np.abs(out["dx32"]).max()))
+    tr, loss, variables = _loop_trace(m16, OPERATORS["underwater_physical_revised"])
+    for k, v in tr.items():
+        out["loop." + k] = v
+    print("fp16 loop final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+    np.savez_compressed(os.path.join(OUT, "fp16_reference.npz"), **out)
 
 
 def gen_prior():
@@ -392,5 +432,6 @@ if __name__ == "__main__":
     gen_prior()
     gen_postprocess()
     gen_ps()
+    gen_fp16()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -142,3 +142,23 @@ def test_guided_loop_10_steps(opname):
     assert torch.allclose(x0, T(g["final_x0"]), atol=5e-5)
     for n, v in variables.items():
         assert torch.allclose(v, T(g[f"final.{n}"]), atol=1e-6), n
+
+
+def test_fp16_reference_fixture_is_consistent():
+    """tests/golden/fp16_reference.npz (round 4: the real reference with convert_to_fp16() applied): its fp32 half is the same
+    network on the same inputs -- the oracle reproduces it -- and its fp16 half differs from it by the half-precision amount."""
+    from oracle import unet_ref as U
+    g = dict(np.load(os.path.join(GOLD, "fp16_reference.npz")))
+    kw = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+              num_head_channels=16, num_heads=4, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+              pretrain_model="osmosis")
+    cfg = U.UNetConfig.from_create_model_kwargs(**kw)
+    sd = U.seeded_state_dict(cfg, 1234)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = U.unet_forward(sd, cfg, x, torch.from_numpy(g["t"]))
+    (dx,) = torch.autograd.grad((y * torch.from_numpy(g["w"])).sum(), x)
+    assert float((y.detach() - torch.from_numpy(g["y32"])).abs().max()) < 2e-5
+    assert float((dx - torch.from_numpy(g["dx32"])).abs().max()) < 2e-5 * float(np.abs(g["dx32"]).max()) + 1e-6
+    gap = float(np.abs(g["y16"] - g["y32"]).max()) / float(np.abs(g["y32"]).max())
+    assert 5e-4 < gap < 1e-2            # really fp16 (not a silently un-converted model), and no worse than fp16
+    assert g["loop.trace.x0"].shape == (10, 1, 4, 32, 32) and np.isfinite(g["loop.final_img"]).all()
