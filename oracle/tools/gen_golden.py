@@ -293,6 +293,28 @@ def gen_fp16():
         out["y" + tag], out["dx" + tag] = npy(y), npy(dx)
     print("tiny UNet: reference fp16 vs reference fp32: y", float(np.abs(out["y16"] - out["y32"]).max()), "of", float(np.abs(out["y32"]).max()),
           " dx", float(np.abs(out["dx16"] - out["dx32"]).max()), "of", float(np.abs(out["dx32"]).max()))
+    # a second, wider model whose attention blocks have 64-wide heads at T = 1024 and 256 (the shapes of the 552.8 M-parameter net's
+    # attention; the tiny model's 16-wide heads take another kernel in the HIP build): 1 x 4 x 64 x 64
+    MID_KW = dict(TINY_KW, num_channels=64, num_head_channels=64)
+    cfgm = UNetConfig.from_create_model_kwargs(**MID_KW)
+    sdm = seeded_state_dict(cfgm, seed=77)
+    xm = 0.7 * torch.randn(1, 4, 64, 64, generator=g)
+    tm = torch.tensor([300.0])
+    wm = torch.randn(1, 8, 64, 64, generator=g)
+    out.update({"mid.x": npy(xm), "mid.t": npy(tm), "mid.w": npy(wm)})
+    for tag, half in (("16", True), ("32", False)):
+        mm = R_unet.create_model(**dict(MID_KW, use_fp16=half))
+        mm.load_state_dict(sdm, strict=True)
+        mm.eval()
+        if half:
+            mm.convert_to_fp16()
+        xr = xm.clone().requires_grad_(True)
+        y = mm(xr, tm)
+        (dx,) = torch.autograd.grad((y * wm).sum(), xr)
+        out["mid.y" + tag], out["mid.dx" + tag] = npy(y), npy(dx)
+    print("mid UNet (64-wide heads): reference fp16 vs fp32: y", float(np.abs(out["mid.y16"] - out["mid.y32"]).max()), "of",
+          float(np.abs(out["mid.y32"]).max()), " dx", float(np.abs(out["mid.dx16"] - out["mid.dx32"]).max()), "of",
+          float(np.abs(out["mid.dx32"]).max()))
     tr, loss, variables = _loop_trace(m16, OPERATORS["underwater_physical_revised"])
     for k, v in tr.items():
         out["loop." + k] = v
