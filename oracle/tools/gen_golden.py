@@ -19,6 +19,8 @@ Sections (SURVEY.md section 8c recipe):
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
+  full_unet.npz       (round 4) the full 552.8 M-parameter architecture through the real reference at 256 x 256 (every 4th pixel of y and
+                      of the input gradient + norms, two timesteps)
   fp16_reference.npz  (round 4) the reference with convert_to_fp16() applied, on CPU: tiny UNet forward / input gradient and the
                       10-step guided loop in fp16, next to the fp32 reference on the same inputs
 """
@@ -322,6 +324,44 @@ def gen_fp16():
     np.savez_compressed(os.path.join(OUT, "fp16_reference.npz"), **out)
 
 
+FULL_KW = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True, class_cond=False,
+               use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4, num_head_channels=64, num_heads_upsample=-1,
+               use_scale_shift_norm=True, dropout=0.0, resblock_updown=True, use_fp16=False, use_new_attention_order=False,
+               model_path="", pretrain_model="osmosis")
+
+
+def gen_full_unet():
+    """The REAL architecture (osmosis_sample_config.yaml: 552.8 M parameters, channel_mult (1,1,2,2,4,4) chosen by create_model for
+    image_size 256, attention at 32 / 16 / 8 with 64-wide heads) through the real reference on CPU, seeded weights
+    (oracle.unet_ref.seeded_state_dict(cfg, 1234)), x = 0.7 randn(seed 0) at 1 x 4 x 256 x 256, two timesteps.  The fixture keeps
+    every 4th pixel of y and of d(sum(y w))/dx plus their norms: small, and enough to pin a full-size forward / backward (one wrong
+    layer changes every pixel)."""
+    cfg = UNetConfig.from_create_model_kwargs(**FULL_KW)
+    sd = seeded_state_dict(cfg, seed=1234)
+    m = R_unet.create_model(**FULL_KW)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval()
+    assert sum(p.numel() for p in m.parameters()) == 552_821_000
+    g = torch.Generator().manual_seed(0)
+    x = 0.7 * torch.randn(1, 4, 256, 256, generator=g)
+    w = torch.randn(1, 8, 256, 256, generator=g)
+    out = {"seed": np.array(0), "x_scale": np.array(0.7), "stride": np.array(4), "x_abs_sum": np.array(float(x.double().abs().sum()))}
+    for t in (37.0, 999.0):
+        xr = x.clone().requires_grad_(True)
+        y = m(xr, torch.tensor([t]))
+        (dx,) = torch.autograd.grad((y * w).sum(), xr)
+        tag = f"t{int(t)}"
+        out[tag + ".y_sub"] = npy(y)[:, :, ::4, ::4]
+        out[tag + ".dx_sub"] = npy(dx)[:, :, ::4, ::4]
+        out[tag + ".y_l2"] = np.array(float(y.double().pow(2).sum().sqrt()))
+        out[tag + ".dx_l2"] = np.array(float(dx.double().pow(2).sum().sqrt()))
+        out[tag + ".y_max"] = np.array(float(y.abs().max()))
+        out[tag + ".dx_max"] = np.array(float(dx.abs().max()))
+        print(tag, "y max", out[tag + ".y_max"], "dx max", out[tag + ".dx_max"])
+    np.savez_compressed(os.path.join(OUT, "full_unet.npz"), **out)
+
+
 def gen_prior():
     """Unconditional RGBD-prior sampler (osmosis_utils/diffusion.py:59-130): last 6 steps of the
     1000-step chain (t = 6..1) on the tiny seeded UNet.  The reference only defines its return values
@@ -455,5 +495,6 @@ if __name__ == "__main__":
     gen_postprocess()
     gen_ps()
     gen_fp16()
+    gen_full_unet()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

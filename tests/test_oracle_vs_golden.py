@@ -162,3 +162,33 @@ def test_fp16_reference_fixture_is_consistent():
     gap = float(np.abs(g["y16"] - g["y32"]).max()) / float(np.abs(g["y32"]).max())
     assert 5e-4 < gap < 1e-2            # really fp16 (not a silently un-converted model), and no worse than fp16
     assert g["loop.trace.x0"].shape == (10, 1, 4, 32, 32) and np.isfinite(g["loop.final_img"]).all()
+
+
+def test_full_size_oracle_vs_reference_golden():
+    """The oracle's restatement at the FULL architecture (552.8 M parameters, channel_mult picked for image_size 256, attention at
+    32 / 16 / 8 with 64-wide heads) against tests/golden/full_unet.npz, which the real reference produced on CPU
+    (oracle/tools/gen_golden.py full_unet): every 4th pixel of y and of the input gradient, and their norms, at t = 37 and 999.
+    Until round 4 the full-size oracle was pinned only through the tiny configurations."""
+    g = dict(np.load(os.path.join(GOLD, "full_unet.npz")))
+    kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True, class_cond=False,
+              use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4, num_head_channels=64, num_heads_upsample=-1,
+              use_scale_shift_norm=True, dropout=0.0, resblock_updown=True, use_fp16=False, use_new_attention_order=False,
+              model_path="", pretrain_model="osmosis")
+    cfg = U.UNetConfig.from_create_model_kwargs(**kw)
+    sd = U.seeded_state_dict(cfg, 1234)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = float(g["x_scale"]) * torch.randn(1, 4, 256, 256, generator=gen)
+    w = torch.randn(1, 8, 256, 256, generator=gen)
+    assert abs(float(x.double().abs().sum()) - float(g["x_abs_sum"])) < 1e-6 * float(g["x_abs_sum"])
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    st = int(g["stride"])
+    for t in (37, 999):
+        xr = x.clone().requires_grad_(True)
+        y = U.unet_forward(sd, cfg, xr, torch.tensor([float(t)]))
+        (dx,) = torch.autograd.grad((y * w).sum(), xr)
+        tag = f"t{t}"
+        ey = float((y.detach()[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".y_sub"])).abs().max())
+        ed = float((dx[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".dx_sub"])).abs().max())
+        assert ey < 2e-5 * float(g[tag + ".y_max"]) and ed < 2e-5 * float(g[tag + ".dx_max"]), (t, ey, ed)
+        assert abs(float(y.double().pow(2).sum().sqrt()) - float(g[tag + ".y_l2"])) < 1e-5 * float(g[tag + ".y_l2"])
+        assert abs(float(dx.double().pow(2).sum().sqrt()) - float(g[tag + ".dx_l2"])) < 1e-5 * float(g[tag + ".dx_l2"])

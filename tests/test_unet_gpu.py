@@ -103,6 +103,37 @@ def test_full_size_unet_256_vs_oracle(create_model):
         assert ed < 1e-4 * max(1.0, float(dxr.abs().max()))
 
 
+def test_full_size_unet_256_vs_reference_golden(create_model):
+    """Round 4: the full 552.8 M-parameter network on the HIP path against vectors the REAL reference produced
+    (tests/golden/full_unet.npz: every 4th pixel of y and of the input gradient + their norms, t = 37 and 999), in the three
+    conv arithmetics -- no oracle in between."""
+    g = dict(np.load(os.path.join(GOLD, "full_unet.npz")))
+    kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
+              class_cond=False, use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4,
+              num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+              resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path="",
+              pretrain_model="osmosis")
+    m, cfg, sd = build(create_model, kw, seed=1234)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = float(g["x_scale"]) * torch.randn(1, 4, 256, 256, generator=gen)
+    w = torch.randn(1, 8, 256, 256, generator=gen)
+    st = int(g["stride"])
+    for mode in ("f32", "bf16x6", "f16x3"):
+        m.conv_mode = mode
+        for t in (37, 999):
+            xd = x.to(DEV).requires_grad_(True)
+            yd = m(xd, torch.tensor([float(t)], device=DEV))
+            (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+            tag = f"t{t}"
+            ey = float((yd.detach().cpu()[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".y_sub"])).abs().max())
+            ed = float((dxd.cpu()[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".dx_sub"])).abs().max())
+            l2y = float(yd.detach().double().pow(2).sum().sqrt())
+            print(f"{mode} t={t}: vs the real reference: y {ey:.2e} (max {float(g[tag + '.y_max']):.2f})  dx {ed:.2e} "
+                  f"(max {float(g[tag + '.dx_max']):.2f})  |y|_2 {l2y:.4f} vs {float(g[tag + '.y_l2']):.4f}")
+            assert ey < 1e-4 * max(1.0, float(g[tag + ".y_max"])) and ed < 1e-4 * max(1.0, float(g[tag + ".dx_max"]))
+            assert abs(l2y - float(g[tag + ".y_l2"])) < 1e-5 * float(g[tag + ".y_l2"])
+
+
 def test_cpu_model_refuses_to_run(create_model):
     m = create_model(**TINY_KW)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
