@@ -21,6 +21,7 @@ Sections (SURVEY.md section 8c recipe):
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
   full_unet.npz       (round 4) the full 552.8 M-parameter architecture through the real reference at 256 x 256 (every 4th pixel of y and
                       of the input gradient + norms, two timesteps)
+  full_step.npz       (round 4) two guided steps of the real reference's loop with the full network (t = 299, then 0): subsampled traces
   fp16_reference.npz  (round 4) the reference with convert_to_fp16() applied, on CPU: tiny UNet forward / input gradient and the
                       10-step guided loop in fp16, next to the fp32 reference on the same inputs
 """
@@ -362,6 +363,63 @@ def gen_full_unet():
     np.savez_compressed(os.path.join(OUT, "full_unet.npz"), **out)
 
 
+def gen_full_step():
+    """TWO guided steps of the real reference's p_sample_loop with the FULL 552.8 M-parameter network at 256 x 256: the sampler is
+    built on use_timesteps = {0, 299}, so the first step runs the network at t = 299 (where bench.py's timed window starts; phi
+    is updated: 20 inner iterations) and the second at t = 0; revised underwater operator, x_T = 0.5 randn(seed 0) (bounded, so
+    that the seeded network's pred_xstart stays inside the physical model's range), y ~ U(-0.8, 0.8) (seed 7).  The noise is NOT
+    stored: it is the reference's own torch.randn_like draws after torch.manual_seed(0) (measurement-shaped, then image-shaped,
+    per step), which a test reproduces with the same calls.  Kept: every 4th pixel of the per-step tensors, losses, phi."""
+    cfg = UNetConfig.from_create_model_kwargs(**FULL_KW)
+    sd = seeded_state_dict(cfg, seed=1234)
+    m = R_unet.create_model(**FULL_KW)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    spec = OPERATORS["underwater_physical_revised"]
+    operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
+    cond = get_conditioning_method("osmosis", operator, get_noise(name="clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    sampler = R_gd.get_sampler("ddpm")(use_timesteps=(0, 299), betas=R_gd.get_named_beta_schedule("linear", 1000),
+                                       model_mean_type="epsilon", model_var_type="learned_range", dynamic_threshold=False,
+                                       clip_denoised=False, rescale_timesteps=False)
+    assert list(sampler.timestep_map) == [0, 299]
+    x_T = 0.5 * torch.randn(1, 4, 256, 256, generator=torch.Generator().manual_seed(0))
+    y = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
+    trace = []
+    orig_cond = cond.conditioning
+
+    def traced(**kw):
+        rec = {"x_in": kw["x_prev"].detach().clone(), "x0": kw["x_0_hat"].detach().clone(), "mean": kw["x_t"].detach().clone()}
+        ret = orig_cond(**kw)
+        rec["x_guided"] = ret[0].detach().clone()
+        rec["loss"] = np.array(ret[1], dtype=np.float32)
+        rec["phi"] = {k: v.detach().clone() for k, v in ret[2].items()}
+        rec["grad"] = ret[3].clone()
+        trace.append(rec)
+        return ret
+
+    torch.manual_seed(0)
+    img, variables, loss, x0 = sampler.p_sample_loop(
+        model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced, record=False, save_root=None,
+        pretrain_model="osmosis", rgb_guidance=False, sample_pattern=PATTERN)
+    assert len(trace) == 2
+    st = 4
+    out = {"stride": np.array(st), "final_img_sub": npy(img)[:, :, ::st, ::st], "final_x0_sub": npy(x0)[:, :, ::st, ::st],
+           "final_loss": np.array(loss, dtype=np.float32), "timestep_map": np.array(sampler.timestep_map, dtype=np.int64),
+           "x_T_abs_sum": np.array(float(x_T.double().abs().sum())), "y_abs_sum": np.array(float(y.double().abs().sum()))}
+    for k, v in variables.items():
+        out[f"final.{k}"] = npy(v)
+    for key in ("x_in", "x0", "mean", "x_guided", "grad"):
+        out[f"trace.{key}_sub"] = np.stack([npy(r[key])[:, :, ::st, ::st] for r in trace])
+        out[f"trace.{key}_max"] = np.array([float(r[key].abs().max()) for r in trace])
+    out["trace.loss"] = np.stack([r["loss"] for r in trace])
+    for k in trace[0]["phi"]:
+        out[f"trace.{k}"] = np.stack([npy(r["phi"][k]) for r in trace])
+    print("full-size guided steps: losses", out["trace.loss"].ravel(), "max |x0|", out["trace.x0_max"], "max |grad|", out["trace.grad_max"],
+          {k: npy(v).ravel().round(4) for k, v in variables.items()})
+    assert np.isfinite(out["final_img_sub"]).all() and np.isfinite(out["trace.loss"]).all()
+    np.savez_compressed(os.path.join(OUT, "full_step.npz"), **out)
+
+
 def gen_prior():
     """Unconditional RGBD-prior sampler (osmosis_utils/diffusion.py:59-130): last 6 steps of the
     1000-step chain (t = 6..1) on the tiny seeded UNet.  The reference only defines its return values
@@ -496,5 +554,6 @@ if __name__ == "__main__":
     gen_ps()
     gen_fp16()
     gen_full_unet()
+    gen_full_step()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

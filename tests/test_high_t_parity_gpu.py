@@ -218,3 +218,57 @@ def test_teacher_forced_guided_step_at_high_t(setup):
     if out:
         with open(out, "w") as f:
             json.dump(rows, f, indent=1)
+
+
+def test_full_size_guided_steps_vs_the_real_reference(setup):
+    """Two guided steps with the FULL network against the REAL reference's p_sample_loop (tests/golden/full_step.npz, produced on
+    CPU by oracle/tools/gen_golden.py full_step; no oracle in between): sampler on use_timesteps = {0, 299} -- the first step runs
+    the network at t = 299 with the 20-iteration phi update, the second at t = 0 --, x_T = 0.5 randn(seed 0), y ~ U(-0.8, 0.8),
+    the reference's own noise draws (torch.manual_seed(0), measurement-shaped then image-shaped per step).  Every 4th pixel of
+    x_t / pred_xstart / the unclipped gradient per step, loss and phi, in three arithmetics; tolerance: north_star's 1e-3."""
+    from osmosis_diffusion_code_amd.guided_diffusion import condition_methods as CM
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
+    model, ucfg, sd, _gt, _y = setup
+    cfg = BC.SAMPLE
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "full_step.npz")))
+    st = int(g["stride"])
+    x_T = 0.5 * torch.randn(1, 4, 256, 256, generator=torch.Generator().manual_seed(0))
+    y = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
+    assert abs(float(x_T.double().abs().sum()) - float(g["x_T_abs_sum"])) < 1e-6 * float(g["x_T_abs_sum"])
+    torch.manual_seed(0)
+    noises = []
+    for _ in range(2):
+        torch.randn_like(y)                              # q_sample's unused draw (SURVEY F7)
+        noises.append(torch.randn_like(x_T))
+    nd = torch.stack(noises).to(DEV)
+    for mode in MODES:
+        model.conv_mode = mode
+        opc = dict(cfg["measurement"]["operator"])
+        name = opc.pop("name")
+        op = M.get_operator(name, device=DEV, batch_size=1, **opc)
+        cond = CM.get_conditioning_method("osmosis", op, M.get_noise("clean"), **cfg["conditioning"]["params"],
+                                          **cfg["sample_pattern"], **cfg["aux_loss"])
+        sampler = gd.get_sampler("ddpm")(use_timesteps=(0, 299), betas=gd.get_named_beta_schedule("linear", 1000),
+                                         model_mean_type="epsilon", model_var_type="learned_range", dynamic_threshold=False,
+                                         clip_denoised=False, rescale_timesteps=False)
+        assert list(sampler.timestep_map) == [int(v) for v in g["timestep_map"]]
+        trace = []
+        img, variables, loss, x0 = sampler.p_sample_loop(
+            model=model, x_start=x_T.to(DEV), measurement=y.to(DEV), measurement_cond_fn=cond.conditioning, record=False,
+            save_root=None, pretrain_model="osmosis", rgb_guidance=False, sample_pattern=cfg["sample_pattern"],
+            noise_fn=lambda k, shape: nd[k], trace=trace)
+        sub = lambda t: t.detach().cpu()[:, :, ::st, ::st]      # noqa: E731
+        e = {k: max(float((sub(trace[i][tk]) - torch.from_numpy(g[f"trace.{k}_sub"][i])).abs().max()) for i in range(2))
+             for k, tk in (("x_in", "x_in"), ("x0", "x0"), ("grad", "grad"))}
+        e_fin = float((sub(img) - torch.from_numpy(g["final_img_sub"])).abs().max())
+        e_x0f = float((sub(x0) - torch.from_numpy(g["final_x0_sub"])).abs().max())
+        print(f"{mode}: full-size guided steps vs the real reference: x_t {e['x_in']:.2e}  pred_xstart {e['x0']:.2e}  grad {e['grad']:.2e} "
+              f"(max {float(g['trace.grad_max'].max()):.1f})  final x {e_fin:.2e}  final pred_xstart {e_x0f:.2e}  loss {float(loss[0]):.4f} vs "
+              f"{float(g['final_loss'][0]):.4f}")
+        assert e["x_in"] < TOL and e["x0"] < TOL and e_fin < TOL and e_x0f < TOL
+        assert e["grad"] < 2e-4 * float(g["trace.grad_max"].max())
+        assert abs(float(loss[0]) - float(g["final_loss"][0])) < 1e-4 * abs(float(g["final_loss"][0]))
+        for k in ("phi_a", "phi_b", "phi_inf"):
+            assert np.allclose(variables[k].cpu().numpy().ravel(), g["final." + k].ravel(), atol=5e-6), (k, mode)
+    model.conv_mode = "f16x3"
