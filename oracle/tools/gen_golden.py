@@ -375,7 +375,14 @@ def gen_full_step():
     m = R_unet.create_model(**FULL_KW)
     m.load_state_dict(sd, strict=True)
     m.eval()
-    spec = OPERATORS["underwater_physical_revised"]
+    # the headline operator at stride 4; the operators of BASELINE configs 3 and 5 at stride 8 (smaller fixtures)
+    for opname, st, fname in (("underwater_physical_revised", 4, "full_step.npz"), ("underwater_physical", 8, "full_step_underwater_physical.npz"),
+                              ("haze_physical", 8, "full_step_haze_physical.npz")):
+        _gen_full_step_one(m, opname, st, fname)
+
+
+def _gen_full_step_one(m, opname, st, fname):
+    spec = OPERATORS[opname]
     operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
     cond = get_conditioning_method("osmosis", operator, get_noise(name="clean"), **spec["cond"], **PATTERN, **spec["aux"])
     sampler = R_gd.get_sampler("ddpm")(use_timesteps=(0, 299), betas=R_gd.get_named_beta_schedule("linear", 1000),
@@ -402,7 +409,6 @@ def gen_full_step():
         model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced, record=False, save_root=None,
         pretrain_model="osmosis", rgb_guidance=False, sample_pattern=PATTERN)
     assert len(trace) == 2
-    st = 4
     out = {"stride": np.array(st), "final_img_sub": npy(img)[:, :, ::st, ::st], "final_x0_sub": npy(x0)[:, :, ::st, ::st],
            "final_loss": np.array(loss, dtype=np.float32), "timestep_map": np.array(sampler.timestep_map, dtype=np.int64),
            "x_T_abs_sum": np.array(float(x_T.double().abs().sum())), "y_abs_sum": np.array(float(y.double().abs().sum()))}
@@ -414,10 +420,10 @@ def gen_full_step():
     out["trace.loss"] = np.stack([r["loss"] for r in trace])
     for k in trace[0]["phi"]:
         out[f"trace.{k}"] = np.stack([npy(r["phi"][k]) for r in trace])
-    print("full-size guided steps: losses", out["trace.loss"].ravel(), "max |x0|", out["trace.x0_max"], "max |grad|", out["trace.grad_max"],
+    print(opname, "full-size guided steps: losses", out["trace.loss"].ravel(), "max |x0|", out["trace.x0_max"], "max |grad|", out["trace.grad_max"],
           {k: npy(v).ravel().round(4) for k, v in variables.items()})
     assert np.isfinite(out["final_img_sub"]).all() and np.isfinite(out["trace.loss"]).all()
-    np.savez_compressed(os.path.join(OUT, "full_step.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_prior():

@@ -220,7 +220,9 @@ def test_teacher_forced_guided_step_at_high_t(setup):
             json.dump(rows, f, indent=1)
 
 
-def test_full_size_guided_steps_vs_the_real_reference(setup):
+@pytest.mark.parametrize("fname,cfg_name", [("full_step.npz", "SAMPLE"), ("full_step_underwater_physical.npz", "SIMULATION"),
+                                            ("full_step_haze_physical.npz", "HAZE")])
+def test_full_size_guided_steps_vs_the_real_reference(setup, fname, cfg_name):
     """Two guided steps with the FULL network against the REAL reference's p_sample_loop (tests/golden/full_step.npz, produced on
     CPU by oracle/tools/gen_golden.py full_step; no oracle in between): sampler on use_timesteps = {0, 299} -- the first step runs
     the network at t = 299 with the 20-iteration phi update, the second at t = 0 --, x_T = 0.5 randn(seed 0), y ~ U(-0.8, 0.8),
@@ -230,8 +232,8 @@ def test_full_size_guided_steps_vs_the_real_reference(setup):
     from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
     from osmosis_diffusion_code_amd.guided_diffusion import measurements as M
     model, ucfg, sd, _gt, _y = setup
-    cfg = BC.SAMPLE
-    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "full_step.npz")))
+    cfg = getattr(BC, cfg_name)          # operator / guidance settings of BASELINE config 2 | 3 | 5 (B = 1, fp32 storage)
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", fname)))
     st = int(g["stride"])
     x_T = 0.5 * torch.randn(1, 4, 256, 256, generator=torch.Generator().manual_seed(0))
     y = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
@@ -269,6 +271,6 @@ def test_full_size_guided_steps_vs_the_real_reference(setup):
         assert e["x_in"] < TOL and e["x0"] < TOL and e_fin < TOL and e_x0f < TOL
         assert e["grad"] < 2e-4 * float(g["trace.grad_max"].max())
         assert abs(float(loss[0]) - float(g["final_loss"][0])) < 1e-4 * abs(float(g["final_loss"][0]))
-        for k in ("phi_a", "phi_b", "phi_inf"):
+        for k in variables:
             assert np.allclose(variables[k].cpu().numpy().ravel(), g["final." + k].ravel(), atol=5e-6), (k, mode)
     model.conv_mode = "f16x3"

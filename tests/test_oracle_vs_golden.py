@@ -205,14 +205,18 @@ def _reference_noise_draws(n_steps, y_shape, x_shape, seed=0):
     return out
 
 
-def test_full_size_guided_steps_oracle_vs_reference_golden():
+@pytest.mark.parametrize("fname,cfg_name", [("full_step.npz", "SAMPLE"), ("full_step_underwater_physical.npz", "SIMULATION"),
+                                            ("full_step_haze_physical.npz", "HAZE")])
+def test_full_size_guided_steps_oracle_vs_reference_golden(fname, cfg_name):
     """Two guided steps of the loop with the FULL network (t = 299 with the 20-iteration phi update, then t = 0) -- the oracle's
-    p_sample_loop against tests/golden/full_step.npz, which the real reference's p_sample_loop produced on CPU."""
-    g = dict(np.load(os.path.join(GOLD, "full_step.npz")))
-    kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True, class_cond=False,
-              use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4, num_head_channels=64, num_heads_upsample=-1,
-              use_scale_shift_norm=True, dropout=0.0, resblock_updown=True, use_fp16=False, use_new_attention_order=False,
-              model_path="", pretrain_model="osmosis")
+    p_sample_loop against tests/golden/full_step*.npz, which the real reference's p_sample_loop produced on CPU, for the operator /
+    guidance settings of BASELINE configs 2 (revised underwater), 3 (underwater, original depth, val_loss 40) and 5 (haze)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import baseline_configs as BC
+    c = getattr(BC, cfg_name)
+    g = dict(np.load(os.path.join(GOLD, fname)))
+    kw = dict(BC.UNET)
     cfg = U.UNetConfig.from_create_model_kwargs(**kw)
     sd = U.seeded_state_dict(cfg, 1234)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
@@ -221,13 +225,16 @@ def test_full_size_guided_steps_oracle_vs_reference_golden():
     assert abs(float(x_T.double().abs().sum()) - float(g["x_T_abs_sum"])) < 1e-6 * float(g["x_T_abs_sum"])
     noises = _reference_noise_draws(2, y.shape, x_T.shape)
     tb = D.Tables(D.named_beta_schedule("linear", 1000), (0, 299))
-    rop = D.PhysOperator("underwater_physical_revised", batch_size=1, depth_type="gamma", value="1.4,1.4,1",
-                         phi_a="1.1,0.95,0.95", phi_b="0.95, 0.8, 0.8", phi_inf="0.14, 0.29, 0.49")
-    rg = D.OsmosisGuidance(rop, n_iter=20, scale="7,7,7,0.9", gradient_clip="True,0.005", aux={"avrg_loss": 0.5, "val_loss": 20})
-    pattern = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0, n_iter=20,
-                   start_guidance=1, stop_guidance=0)
+    opc = dict(c["measurement"]["operator"])
+    name = opc.pop("name")
+    opc.pop("optimizer", None)
+    rop = D.PhysOperator(name, batch_size=1, **opc)
+    p = c["conditioning"]["params"]
+    rg = D.OsmosisGuidance(rop, n_iter=20, scale=p["scale"], gradient_clip=p["gradient_clip"], loss_function=p["loss_function"],
+                           loss_weight=p["loss_weight"], weight_function=p["weight_function"], aux=c["aux_loss"]["aux_loss"])
     trace = []
-    img, variables, loss, x0 = D.p_sample_loop(lambda x, t: U.unet_forward(sd, cfg, x, t), tb, x_T, y, rg, pattern, noises, trace)
+    img, variables, loss, x0 = D.p_sample_loop(lambda x, t: U.unet_forward(sd, cfg, x, t), tb, x_T, y, rg, c["sample_pattern"],
+                                               noises, trace)
     st = int(g["stride"])
     assert float((img[:, :, ::st, ::st] - torch.from_numpy(g["final_img_sub"])).abs().max()) < 1e-4
     assert float((x0[:, :, ::st, ::st] - torch.from_numpy(g["final_x0_sub"])).abs().max()) < 1e-4
