@@ -42,12 +42,25 @@
 #ifndef W8_PRIO_BUILD
 #define W8_PRIO_BUILD 0  // measurement builds: s_setprio level around the V build of a unit (0: none)
 #endif
+#ifndef W8_PIPE
+#define W8_PIPE 1        // f16x3: the LDS reads of a V build are issued ONE UNIT before its arithmetic (inline-asm ds_read_b128, waited
+                         // for by hand), so their latency runs under the previous unit's MFMAs instead of stalling the wave
+#endif
+#ifndef W8_PIPE_MIN
+#define W8_PIPE_MIN 8
+#endif
 constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
 
 // HP ("f16x3", NP = 2): the two planes of V and of U are IEEE halfs of the operands scaled into the fp16 range -- V by
 // 2^ex from the per-image max |x| the caller supplies (IGemmParams::xmax; |V| <= 4 max |x| -> 2^14), U by the power of two
 // stored behind its image (pack_weight_wino_kernel) -- three fp16 MFMAs per product, the result rescaled (exactly) in the
 // epilogue.
+#ifdef W8_STAMP   // measurement build: s_memtime (100 MHz) at the phase boundaries of the first 64 workgroups' waves -> osm_w8_stamps
+__device__ unsigned long long osm_w8_stamps[64 * 8 * 16];
+#define OSM_W8_STAMP(k_) if (HP && blockIdx.x < 64 && lane == 0) osm_w8_stamps[(blockIdx.x * 8 + wave) * 16 + (k_)] = __builtin_readcyclecounter();
+#else
+#define OSM_W8_STAMP(k_)
+#endif
 template <int NP, bool GNF, bool HP = false>
 __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Uglob, IGemmParams p) {
@@ -60,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 3, wh = wave >> 2;
+  OSM_W8_STAMP(0)
   const int lr = lane & 31, lk = lane >> 5;
 
   // ---- XCD-aware tile mapping.  Workgroups that share an XCD (a contiguous id range) run in step; ids enumerate
@@ -133,9 +147,24 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   // tile and sg = -1 | +1 | -1 | -1.  Lane = tile (lr >> 3, lr & 7) of a 32-tile block, channel half lk.
   const int tyl = lr >> 3, txl = lr & 7;
   const int rx = wr == 0 ? 0 : (wr == 2 ? 2 : 1), ry = wr == 2 ? 1 : (wr == 3 ? 3 : 2);
-  const float sg = wr == 1 ? 1.f : -1.f;
+  const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(wr == 1 ? 0x3f800000 : (int)0xbf800000));
   const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
   const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
+
+  // (starting the first slab's global loads HERE, ahead of the max |x| fold, was measured: the loaded registers live across the
+  // fold and the loop then spills -- +7 % on the class)
+  float4 ra[W8_NJ];
+  uint4 uq[2][2][NP];       // [local xi][column tile][plane]: loaded two units ahead into the registers the previous slab's
+                            // same xi released (a second slab-deep set was measured: +8..12 % time, it spills)
+  const bool use_pipe = HP && W8_PIPE && !GNF && (p.K & 15) == 0 && kc1 - kc0 >= W8_PIPE_MIN;
+  // raw staging of the pipelined loop: buffer loads relative to the image (padding pixels carry an out-of-range offset and
+  // come back as zeros: no mask; the slab's channel offset is the scalar offset: no address arithmetic), scale from an SGPR,
+  // buffer parity a compile-time constant (the loop is unrolled by two: every LDS address is base + immediate).  K % 16 == 0.
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(sbaseA), 0, (int)min((long long)p.H * p.W * rowB, 0x7fffffffLL), 0x00020000);
+  unsigned aoff[W8_NJ];
+#pragma unroll
+  for (int j = 0; j < W8_NJ; ++j) aoff[j] = ((vmask >> j) & 1u) ? voff[j] + (unsigned)(q4 * 4 * ACT_B) : 0x80000000u;
 
   // HP: x 2^ex brings the largest |x| of the image (OSM_MAXABS_PARTS partial maxima, as bit patterns) to [2^11, 2^12)
   float xscale = 1.f, oscale = 1.f;
@@ -156,18 +185,17 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(12 - ex, 100); }   // (denormal maxima: 2^ex stays finite)
     xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
     oscale = ldexpf(1.f, -ex) / p.wscale[0];
+    xscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xscale)));   // wave-uniform: SGPRs
+    oscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oscale)));
   }
   float mscale[W8_NJ];
 #pragma unroll
   for (int j = 0; j < W8_NJ; ++j) mscale[j] = ((vmask >> j) & 1u) ? xscale : 0.f;
-  float4 ra[W8_NJ];
   float4 gm, gs, gb;        // fused GroupNorm: mean | rstd * gamma | beta of this thread's channel quad
   gm = gs = gb = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gtab = GNF ? p.gn_table + (long long)img * 4 * p.K : nullptr;
   // the shared t column costs 16 registers: the 3-plane arithmetic has none to spare (it would spill 16)
   constexpr int TSH = (W8_TSHARE && (HP || NP < 3)) ? 1 : 0;
-  uint4 uq[2][2][NP];       // [local xi][column tile][plane]: loaded two units ahead into the registers the previous slab's
-                            // same xi released (a second slab-deep set was measured: +8..12 % time, it spills)
   uint4 va[2][NP];          // A fragments, [unit parity][plane]
   float4 ts[2][2];          // the t column both xi of this wave use, [tile block][channel quad] (W8_TSHARE)
 
@@ -350,10 +378,160 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       OSM_W8_FENCE()
     }
   };
-  if (kc1 > kc0) {
-    if (wh == 0) slab_loop(std::integral_constant<int, 0>{});
-    else slab_loop(std::integral_constant<int, 1>{});
+
+  // ---- W8_PIPE: the same units, software-pipelined at HALF-build granularity.  A build is two independent halves (channel quads
+  // hq = 0 | 1 of the lane's 8 channels -> the .xy | .zw words of both A planes); the LDS reads of a half are issued half a unit
+  // before its arithmetic, into the four registers the previous half just released, and three MFMAs of the running unit sit
+  // between them.  The reads are inline asm -- the compiler neither sinks them down to their use nor counts them (LDS returns in
+  // order, so its own lgkmcnt waits only become more conservative); OSM_W8P_WAIT is the hand-placed wait, tied to the
+  // destination registers by "+v" operands (cdna_hip_programming.md, asm loads, form ii).
+#define OSM_W8P_RD(dst_, addr_, slot_)                                                     \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"((slot_) * 16));
+  // reads of half hq_ of the build of tile block tb_ from the raw slab with x / y row base addresses ax_ / ay_:
+  // column ca_ -> rd[0..1] (if na_), column cb_ -> rd[2..3] (if nb_)
+#define OSM_W8P_READS(hq_, ax_, ay_, buf_, tb_, ca_, cb_, na_, nb_)                              \
+  if (na_) {                                                                               \
+    OSM_W8P_RD(rd[0], ax_, ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + ((ca_) & 1) * 10 + ((ca_) >> 1)) \
+    OSM_W8P_RD(rd[1], ay_, ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + ((ca_) & 1) * 10 + ((ca_) >> 1)) \
+  }                                                                                        \
+  if (nb_) {                                                                               \
+    OSM_W8P_RD(rd[2], ax_, ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + ((cb_) & 1) * 10 + ((cb_) >> 1)) \
+    OSM_W8P_RD(rd[3], ay_, ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + ((cb_) & 1) * 10 + ((cb_) >> 1)) \
   }
+#define OSM_W8P_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rd[0]), "+v"(rd[1]), "+v"(rd[2]), "+v"(rd[3]));
+  // arithmetic of half hq_ from rd: V = t[a] + sb t[b] -> words 2 hq_, 2 hq_ + 1 of va[par_][plane];
+  // keep_ 1: t[b] -> ts[tb_][hq_]; use_ 1: t[b] from ts[tb_][hq_], 2: t[a] from there
+#define OSM_W8P_MATH(hq_, par_, sb_, tb_, keep_, use_)                                     \
+  {                                                                                        \
+    OSM_W8P_WAIT()                                                                         \
+    float4 ta_, tb2_;                                                                      \
+    if ((use_) == 2) ta_ = ts[tb_][hq_];                                                   \
+    else ta_ = make_float4(fmaf(sg, rd[1][0], rd[0][0]), fmaf(sg, rd[1][1], rd[0][1]),     \
+                           fmaf(sg, rd[1][2], rd[0][2]), fmaf(sg, rd[1][3], rd[0][3]));    \
+    if ((use_) == 1) tb2_ = ts[tb_][hq_];                                                  \
+    else tb2_ = make_float4(fmaf(sg, rd[3][0], rd[2][0]), fmaf(sg, rd[3][1], rd[2][1]),    \
+                            fmaf(sg, rd[3][2], rd[2][2]), fmaf(sg, rd[3][3], rd[2][3]));   \
+    if (keep_) ts[tb_][hq_] = tb2_;                                                        \
+    const float4 v_ = make_float4(ta_.x + (sb_) * tb2_.x, ta_.y + (sb_) * tb2_.y, ta_.z + (sb_) * tb2_.z, ta_.w + (sb_) * tb2_.w); \
+    uint2 vh_[2];                                                                          \
+    split_f16x2(v_, vh_);                                                                  \
+    if ((hq_) == 0) { va[par_][0].x = vh_[0].x; va[par_][0].y = vh_[0].y; va[par_][1].x = vh_[1].x; va[par_][1].y = vh_[1].y; } \
+    else            { va[par_][0].z = vh_[0].x; va[par_][0].w = vh_[0].y; va[par_][1].z = vh_[1].x; va[par_][1].w = vh_[1].y; } \
+  }
+  // half of the 6 MFMAs of unit (jj_, tb_): plane pairs (1,0), then (0,1) on column tile 0 | (0,1) on tile 1, then (0,0)
+#define OSM_W8P_MMA(half_, par_, jj_, tb_)                                                 \
+  if ((half_) == 0) {                                                                      \
+    acc[jj_][tb_][0] = mma16h(va[par_][1], uq[jj_][0][0], acc[jj_][tb_][0]);               \
+    acc[jj_][tb_][1] = mma16h(va[par_][1], uq[jj_][1][0], acc[jj_][tb_][1]);               \
+    acc[jj_][tb_][0] = mma16h(va[par_][0], uq[jj_][0][1], acc[jj_][tb_][0]);               \
+  } else {                                                                                 \
+    acc[jj_][tb_][1] = mma16h(va[par_][0], uq[jj_][1][1], acc[jj_][tb_][1]);               \
+    acc[jj_][tb_][0] = mma16h(va[par_][0], uq[jj_][0][0], acc[jj_][tb_][0]);               \
+    acc[jj_][tb_][1] = mma16h(va[par_][0], uq[jj_][1][0], acc[jj_][tb_][1]);               \
+  }
+#define OSM_W8P_LOAD_RAW(cc_, j_)                                                          \
+  ra[j_] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)aoff[j_], (cc_) * (16 * ACT_B), 0));
+#define OSM_W8P_STORE_RAW(buf_, j_)                                                        \
+  raw[(buf_) * (4 * WN_QP) + woff[j_]] = make_float4(ra[j_].x * xscale, ra[j_].y * xscale, ra[j_].z * xscale, ra[j_].w * xscale);
+  auto slab_loop_p = [&](auto hc) __attribute__((always_inline)) {
+    constexpr int H = decltype(hc)::value;
+    constexpr int CA0 = H ? 2 : 0, CB0 = H ? 1 : 2;
+    constexpr int CA1 = 1, CB1 = H ? 3 : 2;
+    constexpr float SB1 = H ? -1.f : 1.f;
+    constexpr int USE1 = H ? 2 : 1;            // the shared column is operand b of the second xi for h = 0, operand a for h = 1
+    constexpr int NA1 = H ? 0 : 1, NB1 = H ? 1 : 0;     // second xi: only the column that is not shared is read
+    osm::floatx4_t rd[4];
+    const unsigned txa = (unsigned)(size_t)t_x, tya = (unsigned)(size_t)t_y;
+    const int k1 = min(kc0 + 1, kc1 - 1);
+    OSM_W8P_LOAD_RAW(kc0, 0) OSM_W8P_LOAD_RAW(kc0, 1) OSM_W8P_LOAD_RAW(kc0, 2)
+    OSM_W8_LOAD_U(kc0, 0)
+    OSM_W8P_STORE_RAW(0, 0) OSM_W8P_STORE_RAW(0, 1) OSM_W8P_STORE_RAW(0, 2)
+    OSM_W8P_LOAD_RAW(k1, 0) OSM_W8P_LOAD_RAW(k1, 1) OSM_W8P_LOAD_RAW(k1, 2)
+    __syncthreads();
+    OSM_W8P_READS(0, txa, tya, 0, 0, CA0, CB0, 1, 1)
+    OSM_W8P_MATH(0, 0, -1.f, 0, 1, 0)
+    OSM_W8P_READS(1, txa, tya, 0, 0, CA0, CB0, 1, 1)
+    OSM_W8P_MATH(1, 0, -1.f, 0, 1, 0)
+    OSM_W8P_READS(0, txa, tya, 0, 1, CA0, CB0, 1, 1)
+    OSM_W8_FENCE()
+    // one slab; P = the parity of its LDS buffer (slab c - kc0 lives in buffer (c - kc0) & 1)
+    auto slab = [&](auto pc, const int c) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value, Q = 1 - P;
+      const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
+      // unit 0 = MFMAs of (xi 0, block 0) | arithmetic of (xi 0, block 1); U of xi 1 for this slab
+      OSM_W8_LOAD_U(c, 1)
+      OSM_W8P_STORE_RAW(Q, 0) OSM_W8P_LOAD_RAW(c2, 0)
+      OSM_W8P_MATH(0, 1, -1.f, 1, 1, 0)
+      OSM_W8P_READS(1, txa, tya, P, 1, CA0, CB0, 1, 1)
+      OSM_W8P_MMA(0, 0, 0, 0)
+      OSM_W8_FENCE()
+      OSM_W8P_MATH(1, 1, -1.f, 1, 1, 0)
+      OSM_W8P_READS(0, txa, tya, P, 0, CA1, CB1, NA1, NB1)
+      OSM_W8P_MMA(1, 0, 0, 0)
+      OSM_W8_FENCE()
+#ifdef W8_XBAR
+      __syncthreads();          // measurement build: a second barrier per slab (what does the lockstep cost?)
+#endif
+      // unit 1 = (xi 0, block 1) | arithmetic of (xi 1, block 0)
+      OSM_W8P_STORE_RAW(Q, 1) OSM_W8P_LOAD_RAW(c2, 1)
+      OSM_W8P_MATH(0, 0, SB1, 0, 0, USE1)
+      OSM_W8P_READS(1, txa, tya, P, 0, CA1, CB1, NA1, NB1)
+      OSM_W8P_MMA(0, 1, 0, 1)
+      OSM_W8_FENCE()
+      OSM_W8P_MATH(1, 0, SB1, 0, 0, USE1)
+      OSM_W8P_READS(0, txa, tya, P, 1, CA1, CB1, NA1, NB1)
+      OSM_W8P_MMA(1, 1, 0, 1)
+      OSM_W8_FENCE()
+      // unit 2 = (xi 1, block 0) | arithmetic of (xi 1, block 1) | barrier | first reads of slab c + 1; U of xi 0 for the next slab
+      OSM_W8_LOAD_U(c1, 0)
+      OSM_W8P_STORE_RAW(Q, 2) OSM_W8P_LOAD_RAW(c2, 2)
+      OSM_W8P_MATH(0, 1, SB1, 1, 0, USE1)
+      OSM_W8P_READS(1, txa, tya, P, 1, CA1, CB1, NA1, NB1)
+      OSM_W8P_MMA(0, 0, 1, 0)
+      OSM_W8_FENCE()
+      OSM_W8P_MATH(1, 1, SB1, 1, 0, USE1)
+      OSM_W8_FENCE()
+      __syncthreads();          // raw(c + 1) is complete in its buffer; every read of raw(c) has returned (the waits above)
+      OSM_W8P_READS(0, txa, tya, Q, 0, CA0, CB0, 1, 1)
+      OSM_W8P_MMA(1, 0, 1, 0)
+      OSM_W8_FENCE()
+      // unit 3 = (xi 1, block 1) | arithmetic of (xi 0, block 0) of slab c + 1
+      OSM_W8P_MATH(0, 0, -1.f, 0, 1, 0)
+      OSM_W8P_READS(1, txa, tya, Q, 0, CA0, CB0, 1, 1)
+      OSM_W8P_MMA(0, 1, 1, 1)
+      OSM_W8_FENCE()
+      OSM_W8P_MATH(1, 0, -1.f, 0, 1, 0)
+      OSM_W8P_READS(0, txa, tya, Q, 1, CA0, CB0, 1, 1)
+      OSM_W8P_MMA(1, 1, 1, 1)
+      OSM_W8_FENCE()
+    };
+    for (int c = kc0; c < kc1; c += 2) {
+      slab(std::integral_constant<int, 0>{}, c);
+      if (c + 1 >= kc1) break;
+      slab(std::integral_constant<int, 1>{}, c + 1);
+    }
+    OSM_W8P_WAIT()               // the reads issued by the last half unit land before their registers are reused
+  };
+  OSM_W8_STAMP(1)
+  if (kc1 > kc0) {
+    // the pipelined loop pays from ~8 slabs per workgroup (its prologue is two dependent LDS round trips longer)
+    if (use_pipe) {
+      if constexpr (HP && W8_PIPE && !GNF) {
+        if (wh == 0) slab_loop_p(std::integral_constant<int, 0>{});
+        else slab_loop_p(std::integral_constant<int, 1>{});
+      }
+    } else {
+      if (wh == 0) slab_loop(std::integral_constant<int, 0>{});
+      else slab_loop(std::integral_constant<int, 1>{});
+    }
+  }
+#undef OSM_W8P_RD
+#undef OSM_W8P_LOAD_RAW
+#undef OSM_W8P_STORE_RAW
+#undef OSM_W8P_READS
+#undef OSM_W8P_MMA
+#undef OSM_W8P_WAIT
+#undef OSM_W8P_MATH
 #undef OSM_W8_LOAD_RAW
 #undef OSM_W8_LOAD_TAB
 #undef OSM_W8_STORE_RAW
@@ -364,6 +542,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #undef OSM_W8_UNIT
 #undef OSM_W8_FENCE
 
+  OSM_W8_STAMP(2)
   if ((W8_ABL & 4) && p.alpha != 12345.f) return;      // measurement build: no epilogue
   // ---- Y = A^T M A.  xi columns: s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 -> this wave's partials p0 | p1:
   //   h = 0 (M0, M1): (M0 + M1, M1);   h = 1 (M2, M3): (M2, M2 + M3), the latter subtracted.
@@ -396,70 +575,102 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     sc[0] = StatCol{tm.x, tr.x, tg.x, tbb.x}; sc[1] = StatCol{tm.y, tr.y, tg.y, tbb.y};
     sc[2] = StatCol{tm.z, tr.z, tg.z, tbb.z}; sc[3] = StatCol{tm.w, tr.w, tg.w, tbb.w};
   }
+  // Straight-line code: the wave-uniform choices (column pair h, the signs of the row / column sums, residual / accumulate /
+  // statistics) are made ONCE per round, not per element -- as per-element scalar branches the epilogue was ~260 branches per
+  // workgroup and cost a quarter of the kernel (measured by running it twice).
+  // signs of the six partial planes a finishing wave sums: xi rows + + + (oy = 0) | + - - (oy = 1); the second column partial
+  // of the h = 1 waves enters negated
+  float sgn[3][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+      sgn[k][h2] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+          ((oy == 0 || k == 0) != (h2 == 1 && ox == 1)) ? 0x3f800000 : (int)0xbf800000));
+  const bool ok = nok && xok;
+  // write phase of round a_: h = 0: (M0 + M1, M1);  h = 1: (M2, M2 + M3)
+  auto put = [&](auto whc, const int a_) __attribute__((always_inline)) {
+    constexpr int WH = decltype(whc)::value;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        // h = 0: (M0 + M1, M1);  h = 1: (M2, M2 + M3) -- the second is SUBTRACTED by the finishing waves.  A real (scalar)
-        // branch per wave: as selects this was 128 v_cndmask per wave
-        const float m0 = acc[0][a][b][e], m1 = acc[1][a][b][e];
-        float* r0_ = red + (((wave * 2 + 0) * 2 + b) * 16 + e) * 64 + lane;
-        float* r1_ = red + (((wave * 2 + 1) * 2 + b) * 16 + e) * 64 + lane;
-        if (wh == 0) {
-          asm volatile("" ::: "memory");
-          *r0_ = m0 + m1;
-          *r1_ = m1;
-        } else {
-          *r0_ = m0;
-          *r1_ = m0 + m1;
-          asm volatile("" ::: "memory");
-        }
+        const float m0 = a_ == 0 ? acc[0][0][b][e] : acc[0][1][b][e], m1 = a_ == 0 ? acc[1][0][b][e] : acc[1][1][b][e];
+        red[(((wave * 2 + 0) * 2 + b) * 16 + e) * 64 + lane] = WH == 0 ? m0 + m1 : m0;
+        red[(((wave * 2 + 1) * 2 + b) * 16 + e) * 64 + lane] = WH == 0 ? m1 : m0 + m1;
       }
-    __syncthreads();
+  };
+  // sum of tile row 4 a_ + i_ (e' = 4 i_ + e_lo) for this wave's (oy, ox, column tile), rescaled
+  auto gather = [&](const int i_) __attribute__((always_inline)) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                 // e' = 4 i + e_lo: tile row 4 a + i of the patch
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const float4 s = *reinterpret_cast<const float4*>(red_rd + (((h2 * 4 + oy + k) * 4) * 16 + 4 * i_) * 64);
+        v.x = fmaf(sgn[k][h2], s.x, v.x); v.y = fmaf(sgn[k][h2], s.y, v.y);
+        v.z = fmaf(sgn[k][h2], s.z, v.z); v.w = fmaf(sgn[k][h2], s.w, v.w);
+      }
+    if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
+    return v;
+  };
+  // finishing phase of round a_.  MODE 0: split-K partial;  1: y = alpha v + bias (+ residual if RES, + y if ACC);  2: the
+  // general form with column statistics (runtime residual / accumulate)
+  auto finish = [&](auto modec, auto resc, auto accc, const int a_) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
+    constexpr bool RES = decltype(resc)::value != 0, ACC = decltype(accc)::value != 0;
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const float4 s = *reinterpret_cast<const float4*>(red_rd + (((h2 * 4 + oy + k) * 4) * 16 + 4 * i) * 64);
-          // xi rows: + + + (oy = 0) | + - - (oy = 1); the second column partial of the h = 1 waves enters negated
-          if ((oy == 0 || k == 0) != (h2 == 1 && ox == 1)) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
-          else { v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w; }
-        }
-      if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
-      const int dy = 8 * a + 2 * i;
+    for (int i = 0; i < 4; ++i) {
+      float4 v = gather(i);
+      const int dy = 8 * a_ + 2 * i;
       if (y0 + oy + dy >= p.H) continue;          // wave-uniform
-      const bool ok = nok && xok;
       const int po = dy * p.W + dx;
-      if (partial) {
+      if constexpr (MODE == 0) {
         if (ok) *reinterpret_cast<float4*>(wbase + po * p.N + n) = v;
       } else {
         act_t* __restrict__ op = obase + po * (int)p.ldc + n;
         v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
-        if (rbase && ok) {
-          const float4 r = osm::ld4(rbase + po * (int)p.ldr + n);
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-        if (p.accumulate && ok) {
-          const float4 r = osm::ld4(op);
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-        if (ok) osm::st4(op, v);
-        if (stats && ok) {
-          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
-          stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, st1[0], st2[0]);
-          stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, st1[1], st2[1]);
-          stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, st1[2], st2[2]);
-          stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, st1[3], st2[3]);
+        if (ok) {
+          if (MODE == 2 ? rbase != nullptr : RES) {
+            const float4 r = osm::ld4(rbase + po * (int)p.ldr + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          if (MODE == 2 ? p.accumulate != 0 : ACC) {
+            const float4 r = osm::ld4(op);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          osm::st4(op, v);
+          if constexpr (MODE == 2) {
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
+            stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, st1[0], st2[0]);
+            stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, st1[1], st2[1]);
+            stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, st1[2], st2[2]);
+            stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, st1[3], st2[3]);
+          }
         }
       }
     }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+#ifndef W8_EPI_REP
+#define W8_EPI_REP 1        // measurement builds: the epilogue executed this many times
+#endif
+  for (int rep_ = 0; rep_ < W8_EPI_REP; ++rep_)
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    OSM_W8_STAMP(3 + 5 * a)
+    __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
+    OSM_W8_STAMP(4 + 5 * a)
+    if (wh == 0) put(I0{}, a); else put(I1{}, a);
+    OSM_W8_STAMP(5 + 5 * a)
+    __syncthreads();
+    OSM_W8_STAMP(6 + 5 * a)
+    if (partial) finish(I0{}, I0{}, I0{}, a);
+    else if (stats) finish(I2{}, I0{}, I0{}, a);
+    else if (rbase) { if (p.accumulate) finish(I1{}, I1{}, I1{}, a); else finish(I1{}, I1{}, I0{}, a); }
+    else { if (p.accumulate) finish(I1{}, I0{}, I1{}, a); else finish(I1{}, I0{}, I0{}, a); }
+    OSM_W8_STAMP(7 + 5 * a)
   }
   if (stats) {       // workgroup-uniform
 #pragma unroll

@@ -879,3 +879,9 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
   return OSM_OK;
 }
 #endif   // !OSM_ACT_F16
+
+#if defined(W8_STAMP) && !defined(OSM_ACT_F16)
+extern "C" int osm_debug_w8_stamps(unsigned long long* host) {   // measurement build only (tools/w8_stamps.py)
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(osm_w8_stamps), sizeof(unsigned long long) * 64 * 8 * 16);
+}
+#endif

@@ -71,10 +71,18 @@ __device__ __forceinline__ float sub_h_hi(unsigned h, float x) {
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
   return r;
 }
+// packed pair of second-plane halfs: (half)(x0 - lo(h)) | (half)(x1 - hi(h)) << 16.  The difference is exact in fp32, so the
+// single rounding of v_fma_mixlo / mixhi_f16 gives the bits of cvt_pk_f16(sub_h_lo, sub_h_hi) in 2 instructions instead of 3
+__device__ __forceinline__ unsigned resid_pk_f16(unsigned h, float x0, float x1) {
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(x1));
+  return r;
+}
 __device__ __forceinline__ void split_f16x2(float4 x, uint2 (&pl)[2]) {
   const unsigned a = cvt_pk_f16(x.x, x.y), b = cvt_pk_f16(x.z, x.w);
   pl[0] = make_uint2(a, b);
-  pl[1] = make_uint2(cvt_pk_f16(sub_h_lo(a, x.x), sub_h_hi(a, x.y)), cvt_pk_f16(sub_h_lo(b, x.z), sub_h_hi(b, x.w)));
+  pl[1] = make_uint2(resid_pk_f16(a, x.x, x.y), resid_pk_f16(b, x.z, x.w));
 }
 __device__ __forceinline__ f32x16 mma16h(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);

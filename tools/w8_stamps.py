@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Phase timing of the f16x3 Winograd kernel from s_memtime stamps (a -DW8_STAMP build of the library, OSM_LIB=...):
+prologue | K loop | epilogue round 0 / 1: wait at barrier, write phase, wait, finishing phase.  100 MHz ticks -> microseconds.
+
+    OSM_LIB=tools/variants/libosm_stamp.so python tools/w8_stamps.py --shape 1,256,256,256,256,3
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from osmosis_diffusion_code_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="1,256,256,256,256,3")
+    a = ap.parse_args()
+    B, H, W, Cin, Cout, k = (int(v) for v in a.shape.split(","))
+    dev, M = "cuda:0", B * H * W
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(M, Cin, device=dev, generator=g)
+    w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, device=dev, generator=g)
+    y = torch.empty(M, Cout, device=dev)
+    wfmt = ops.WFMT["f16x3"] | ops.WINOGRAD
+    wf, _ = ops.pack_conv_weight_winograd(w, wfmt=wfmt & 7)
+    xm = torch.empty(B * ops.MAXABS_PARTS, device=dev)
+    ops.maxabs(ops.Mat.of(x), B, xm)
+    sk = ops.conv_splitk(B, H, W, Cin, Cout, k, wfmt)
+    ws = torch.empty(sk * M * Cout, device=dev) if sk > 1 else None
+    for _ in range(5):
+        ops.conv2d(ops.Mat.of(x), wf, b, ops.Mat.of(y), B, H, W, k, splitk=sk, splitk_ws=ws, wfmt=wfmt, x_maxabs=xm)
+    torch.cuda.synchronize()
+    buf = np.zeros(64 * 8 * 16, dtype=np.uint64)
+    lib = _lib.load()
+    rc = lib.osm_debug_w8_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
+    assert rc == 0, rc
+    t = buf.reshape(64, 8, 16).astype(np.float64) * 0.01      # microseconds
+    names = ["prologue", "K loop", "(to epilogue)", "r0 barrier wait", "r0 write", "r0 barrier wait", "r0 finish",
+             "r1 (gap)", "r1 barrier wait", "r1 write", "r1 barrier wait", "r1 finish"]
+    d = np.diff(t[:, :, :13], axis=2)
+    print(f"shape {a.shape} splitk {sk}: per-phase microseconds, mean over 64 workgroups x 8 waves (min .. max)")
+    for i, n in enumerate(names):
+        print(f"  {n:18s} {d[:, :, i].mean():8.2f}  ({d[:, :, i].min():.2f} .. {d[:, :, i].max():.2f})")
+    print(f"  total              {(t[:, :, 12] - t[:, :, 0]).mean():8.2f}")
+
+
+if __name__ == "__main__":
+    main()
