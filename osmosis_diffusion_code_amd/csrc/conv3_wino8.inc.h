@@ -61,7 +61,7 @@ __device__ unsigned long long osm_w8_stamps[64 * 8 * 16];
 #else
 #define OSM_W8_STAMP(k_)
 #endif
-template <int NP, bool GNF, bool HP = false>
+template <int NP, bool GNF, bool HP = false, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Uglob, IGemmParams p) {
   // 128 KB: the two raw slabs (46 KB) during the slab loop, the 8-wave exchange buffer of the epilogue after it
@@ -151,12 +151,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
   const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
 
-  // (starting the first slab's global loads HERE, ahead of the max |x| fold, was measured: the loaded registers live across the
-  // fold and the loop then spills -- +7 % on the class)
+  // (starting the first slab's global loads HERE, ahead of the max |x| fold, was measured twice: hipcc then spills ~30 registers
+  // around the fold and inside the K loop -- +7 % on the class)
   float4 ra[W8_NJ];
   uint4 uq[2][2][NP];       // [local xi][column tile][plane]: loaded two units ahead into the registers the previous slab's
                             // same xi released (a second slab-deep set was measured: +8..12 % time, it spills)
-  const bool use_pipe = HP && W8_PIPE && !GNF && (p.K & 15) == 0 && kc1 - kc0 >= W8_PIPE_MIN;
+  constexpr bool use_pipe = HP && W8_PIPE && !GNF && PIPE;    // the host picks PIPE: K % 16 == 0 and >= W8_PIPE_MIN slabs per workgroup
   // raw staging of the pipelined loop: buffer loads relative to the image (padding pixels carry an out-of-range offset and
   // come back as zeros: no mask; the slab's channel offset is the scalar offset: no address arithmetic), scale from an SGPR,
   // buffer parity a compile-time constant (the loop is unrolled by two: every LDS address is base + immediate).  K % 16 == 0.
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       constexpr int P = decltype(pc)::value, Q = 1 - P;
       const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
       // unit 0 = MFMAs of (xi 0, block 0) | arithmetic of (xi 0, block 1); U of xi 1 for this slab
+#ifndef W8_ULATE     // measurement build W8_ULATE: the U fragments are requested ONE unit ahead instead of two
       OSM_W8_LOAD_U(c, 1)
+#endif
       OSM_W8P_STORE_RAW(Q, 0) OSM_W8P_LOAD_RAW(c2, 0)
       OSM_W8P_MATH(0, 1, -1.f, 1, 1, 0)
       OSM_W8P_READS(1, txa, tya, P, 1, CA0, CB0, 1, 1)
@@ -473,6 +475,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       __syncthreads();          // measurement build: a second barrier per slab (what does the lockstep cost?)
 #endif
       // unit 1 = (xi 0, block 1) | arithmetic of (xi 1, block 0)
+#ifdef W8_ULATE
+      OSM_W8_LOAD_U(c, 1)
+#endif
       OSM_W8P_STORE_RAW(Q, 1) OSM_W8P_LOAD_RAW(c2, 1)
       OSM_W8P_MATH(0, 0, SB1, 0, 0, USE1)
       OSM_W8P_READS(1, txa, tya, P, 0, CA1, CB1, NA1, NB1)
@@ -483,7 +488,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       OSM_W8P_MMA(1, 1, 0, 1)
       OSM_W8_FENCE()
       // unit 2 = (xi 1, block 0) | arithmetic of (xi 1, block 1) | barrier | first reads of slab c + 1; U of xi 0 for the next slab
+#ifndef W8_ULATE
       OSM_W8_LOAD_U(c1, 0)
+#endif
       OSM_W8P_STORE_RAW(Q, 2) OSM_W8P_LOAD_RAW(c2, 2)
       OSM_W8P_MATH(0, 1, SB1, 1, 0, USE1)
       OSM_W8P_READS(1, txa, tya, P, 1, CA1, CB1, NA1, NB1)
@@ -496,6 +503,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       OSM_W8P_MMA(1, 0, 1, 0)
       OSM_W8_FENCE()
       // unit 3 = (xi 1, block 1) | arithmetic of (xi 0, block 0) of slab c + 1
+#ifdef W8_ULATE
+      OSM_W8_LOAD_U(c1, 0)
+#endif
       OSM_W8P_MATH(0, 0, -1.f, 0, 1, 0)
       OSM_W8P_READS(1, txa, tya, Q, 0, CA0, CB0, 1, 1)
       OSM_W8P_MMA(0, 1, 1, 1)
@@ -515,11 +525,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   OSM_W8_STAMP(1)
   if (kc1 > kc0) {
     // the pipelined loop pays from ~8 slabs per workgroup (its prologue is two dependent LDS round trips longer)
-    if (use_pipe) {
-      if constexpr (HP && W8_PIPE && !GNF) {
-        if (wh == 0) slab_loop_p(std::integral_constant<int, 0>{});
-        else slab_loop_p(std::integral_constant<int, 1>{});
-      }
+    if constexpr (use_pipe) {
+      if (wh == 0) slab_loop_p(std::integral_constant<int, 0>{});
+      else slab_loop_p(std::integral_constant<int, 1>{});
     } else {
       if (wh == 0) slab_loop(std::integral_constant<int, 0>{});
       else slab_loop(std::integral_constant<int, 1>{});

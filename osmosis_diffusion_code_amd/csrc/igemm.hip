@@ -529,7 +529,12 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
       p.wscale = reinterpret_cast<const float*>(Up + 2LL * 16 * p.ksteps * p.nt32 * 512);
       if (p.gn_table)    // x_maxabs is the range of x, not of act(GroupNorm(x)): the scale would be wrong
         return osm::fail(OSM_ERR_UNSUPPORTED, "the f16x3 Winograd image does not take a fused GroupNorm input (gn_table)");
-      hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true>), gw, dim3(512), 0, st, p.A, Up, p);
+      // the software-pipelined K loop: 16-channel slabs without a tail, and enough of them per workgroup to pay for its prologue
+      const int per = (p.ksteps + p.splitk - 1) / p.splitk;
+      if (W8_PIPE && (p.K & 15) == 0 && per >= W8_PIPE_MIN)
+        hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true, true>), gw, dim3(512), 0, st, p.A, Up, p);
+      else
+        hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true, false>), gw, dim3(512), 0, st, p.A, Up, p);
     } else if (wfmt == 3) { OSM_WINO_LAUNCH(3) } else { OSM_WINO_LAUNCH(2) }
 #endif
 #undef OSM_WINO_LAUNCH
