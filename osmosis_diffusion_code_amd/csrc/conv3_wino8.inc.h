@@ -46,6 +46,11 @@
 #define W8_PIPE 1        // f16x3: the LDS reads of a V build are issued ONE UNIT before its arithmetic (inline-asm ds_read_b128, waited
                          // for by hand), so their latency runs under the previous unit's MFMAs instead of stalling the wave
 #endif
+#ifndef W8_YPRIO
+#define W8_YPRIO 3        // units (bit mask) in which the younger half of the workgroup (waves 4-7) runs at s_setprio 1: both waves of a SIMD
+                         // issue by age otherwise, the older half reached the slab barrier ~25 % earlier and waited there (time stamps:
+                         // barrier wait 17 -> 12 % of the loop); 0 = off
+#endif
 #ifndef W8_PIPE_MIN
 #define W8_PIPE_MIN 8
 #endif
@@ -57,9 +62,14 @@ constexpr int W8_NJ = 3;                     // raw staging pieces per thread an
 // epilogue.
 #ifdef W8_STAMP   // measurement build: s_memtime (100 MHz) at the phase boundaries of the first 64 workgroups' waves -> osm_w8_stamps
 __device__ unsigned long long osm_w8_stamps[64 * 8 * 16];
+__device__ unsigned long long osm_w8_slab_stamps[64 * 8 * 160];   // [workgroup][wave][slab][unit 0..3 start, barrier passed]
+__device__ unsigned long long osm_w8_fine_stamps[8 * 32 * 16];     // workgroup 0: [wave][slab][step inside unit 0]
+#define OSM_W8_FINE_STAMP(c_, k_) if (blockIdx.x == 0 && lane == 0 && (c_) - kc0 < 32) osm_w8_fine_stamps[(wave * 32 + ((c_) - kc0)) * 16 + (k_)] = __builtin_readcyclecounter();
+#define OSM_W8_SLAB_STAMP(c_, k_) if (blockIdx.x < 64 && lane == 0 && (c_) - kc0 < 32) osm_w8_slab_stamps[((blockIdx.x * 8 + wave) * 32 + ((c_) - kc0)) * 5 + (k_)] = __builtin_readcyclecounter();
 #define OSM_W8_STAMP(k_) if (HP && blockIdx.x < 64 && lane == 0) osm_w8_stamps[(blockIdx.x * 8 + wave) * 16 + (k_)] = __builtin_readcyclecounter();
 #else
 #define OSM_W8_STAMP(k_)
+#define OSM_W8_SLAB_STAMP(c_, k_)
 #endif
 template <int NP, bool GNF, bool HP = false, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __restrict__ Aglob,
@@ -246,6 +256,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
             : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(             \
                   ursrc, (int)u_lane, (int)(so_ + (unsigned)q2 * u_plane + (unsigned)b * u_nt), 0)); \
   }
+// one U fragment (column tile b_, plane q2_) of local xi jj_ for slab cc_
+#define OSM_W8_LOAD_U1(cc_, jj_, b_, q2_)                                                  \
+  uq[jj_][b_][q2_] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(     \
+      ursrc, (int)u_lane, (int)((unsigned)(4 * wr + 2 * wh + (jj_)) * u_xi + (unsigned)(cc_) * u_slab + (unsigned)(q2_) * u_plane + (unsigned)(b_) * u_nt), 0));
 // A fragments of unit (local xi jj_, tile block tb_) from the raw slab at slot offset bo_: V = t[ca] + sb t[cb],
 // t[c] = x[c] + sg y[c] (column c of the tile = parity c & 1, slot txl + (c >> 1)), split into NP planes.
 // The two xi of a wave share one t column (h = 0: t2, h = 1: t1): the FIRST build of a tile block (local xi 0, where the
@@ -458,15 +472,19 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     auto slab = [&](auto pc, const int c) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value, Q = 1 - P;
       const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
+      if constexpr (H == 1 && W8_YPRIO != 0) __builtin_amdgcn_s_setprio((W8_YPRIO >> 0) & 1);
+      OSM_W8_SLAB_STAMP(c, 0)
       // unit 0 = MFMAs of (xi 0, block 0) | arithmetic of (xi 0, block 1); U of xi 1 for this slab
-#ifndef W8_ULATE     // measurement build W8_ULATE: the U fragments are requested ONE unit ahead instead of two
-      OSM_W8_LOAD_U(c, 1)
-#endif
-      OSM_W8P_STORE_RAW(Q, 0) OSM_W8P_LOAD_RAW(c2, 0)
+      // (the eight U fragments of a slab are requested one per half unit, in the order the MFMAs use them, each into the register
+      // its last MFMA just released: as two bursts of four, all eight waves queued at the address unit at the same moment --
+      // ~350 cycles per burst before a wave got its loads out, measured with time stamps)
+      OSM_W8_LOAD_U1(c, 1, 0, 0)
+      OSM_W8P_STORE_RAW(Q, 0)
       OSM_W8P_MATH(0, 1, -1.f, 1, 1, 0)
       OSM_W8P_READS(1, txa, tya, P, 1, CA0, CB0, 1, 1)
       OSM_W8P_MMA(0, 0, 0, 0)
       OSM_W8_FENCE()
+      OSM_W8_LOAD_U1(c, 1, 1, 0) OSM_W8P_LOAD_RAW(c2, 0)
       OSM_W8P_MATH(1, 1, -1.f, 1, 1, 0)
       OSM_W8P_READS(0, txa, tya, P, 0, CA1, CB1, NA1, NB1)
       OSM_W8P_MMA(1, 0, 0, 0)
@@ -474,42 +492,46 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #ifdef W8_XBAR
       __syncthreads();          // measurement build: a second barrier per slab (what does the lockstep cost?)
 #endif
+      if constexpr (H == 1 && W8_YPRIO != 0) __builtin_amdgcn_s_setprio((W8_YPRIO >> 1) & 1);
+      OSM_W8_SLAB_STAMP(c, 1)
       // unit 1 = (xi 0, block 1) | arithmetic of (xi 1, block 0)
-#ifdef W8_ULATE
-      OSM_W8_LOAD_U(c, 1)
-#endif
-      OSM_W8P_STORE_RAW(Q, 1) OSM_W8P_LOAD_RAW(c2, 1)
+      OSM_W8_LOAD_U1(c, 1, 0, 1)
+      OSM_W8P_STORE_RAW(Q, 1)
       OSM_W8P_MATH(0, 0, SB1, 0, 0, USE1)
       OSM_W8P_READS(1, txa, tya, P, 0, CA1, CB1, NA1, NB1)
       OSM_W8P_MMA(0, 1, 0, 1)
       OSM_W8_FENCE()
+      OSM_W8_LOAD_U1(c, 1, 1, 1) OSM_W8P_LOAD_RAW(c2, 1)
       OSM_W8P_MATH(1, 0, SB1, 0, 0, USE1)
       OSM_W8P_READS(0, txa, tya, P, 1, CA1, CB1, NA1, NB1)
       OSM_W8P_MMA(1, 1, 0, 1)
       OSM_W8_FENCE()
+      if constexpr (H == 1 && W8_YPRIO != 0) __builtin_amdgcn_s_setprio((W8_YPRIO >> 2) & 1);
+      OSM_W8_SLAB_STAMP(c, 2)
       // unit 2 = (xi 1, block 0) | arithmetic of (xi 1, block 1) | barrier | first reads of slab c + 1; U of xi 0 for the next slab
-#ifndef W8_ULATE
-      OSM_W8_LOAD_U(c1, 0)
-#endif
-      OSM_W8P_STORE_RAW(Q, 2) OSM_W8P_LOAD_RAW(c2, 2)
+      OSM_W8_LOAD_U1(c1, 0, 0, 0)
+      OSM_W8P_STORE_RAW(Q, 2)
       OSM_W8P_MATH(0, 1, SB1, 1, 0, USE1)
       OSM_W8P_READS(1, txa, tya, P, 1, CA1, CB1, NA1, NB1)
       OSM_W8P_MMA(0, 0, 1, 0)
       OSM_W8_FENCE()
+      OSM_W8_LOAD_U1(c1, 0, 1, 0) OSM_W8P_LOAD_RAW(c2, 2)
       OSM_W8P_MATH(1, 1, SB1, 1, 0, USE1)
       OSM_W8_FENCE()
+      OSM_W8_SLAB_STAMP(c, 3)
       __syncthreads();          // raw(c + 1) is complete in its buffer; every read of raw(c) has returned (the waits above)
+      OSM_W8_SLAB_STAMP(c, 4)
       OSM_W8P_READS(0, txa, tya, Q, 0, CA0, CB0, 1, 1)
       OSM_W8P_MMA(1, 0, 1, 0)
       OSM_W8_FENCE()
+      if constexpr (H == 1 && W8_YPRIO != 0) __builtin_amdgcn_s_setprio((W8_YPRIO >> 3) & 1);
       // unit 3 = (xi 1, block 1) | arithmetic of (xi 0, block 0) of slab c + 1
-#ifdef W8_ULATE
-      OSM_W8_LOAD_U(c1, 0)
-#endif
+      OSM_W8_LOAD_U1(c1, 0, 0, 1)
       OSM_W8P_MATH(0, 0, -1.f, 0, 1, 0)
       OSM_W8P_READS(1, txa, tya, Q, 0, CA0, CB0, 1, 1)
       OSM_W8P_MMA(0, 1, 1, 1)
       OSM_W8_FENCE()
+      OSM_W8_LOAD_U1(c1, 0, 1, 1)
       OSM_W8P_MATH(1, 0, -1.f, 0, 1, 0)
       OSM_W8P_READS(0, txa, tya, Q, 1, CA0, CB0, 1, 1)
       OSM_W8P_MMA(1, 1, 1, 1)
@@ -521,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       slab(std::integral_constant<int, 1>{}, c + 1);
     }
     OSM_W8P_WAIT()               // the reads issued by the last half unit land before their registers are reused
+    if constexpr (H == 1 && W8_YPRIO != 0) __builtin_amdgcn_s_setprio(0);
   };
   OSM_W8_STAMP(1)
   if (kc1 > kc0) {
@@ -544,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #undef OSM_W8_LOAD_TAB
 #undef OSM_W8_STORE_RAW
 #undef OSM_W8_LOAD_U
+#undef OSM_W8_LOAD_U1
 #undef OSM_W8_BUILD
 #undef OSM_W8_MMA
 #undef OSM_W8_MMA_BODY
@@ -622,11 +646,24 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     if (HP) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
     return v;
   };
-  // finishing phase of round a_.  MODE 0: split-K partial;  1: y = alpha v + bias (+ residual if RES, + y if ACC);  2: the
-  // general form with column statistics (runtime residual / accumulate)
-  auto finish = [&](auto modec, auto resc, auto accc, const int a_) __attribute__((always_inline)) {
+  // the residual / accumulate operands of a round are requested BEFORE its LDS exchange (their global round trips, one per
+  // tile row and serial when issued where they are used, then run under the exchange); zeros where there is nothing to add
+  float4 pre_r[4], pre_a[4];
+  auto prefetch = [&](const int a_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int dy = 8 * a_ + 2 * i;
+      const int po = dy * p.W + dx;
+      const bool live = ok && y0 + oy + dy < p.H;
+      pre_r[i] = pre_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rbase && live) pre_r[i] = osm::ld4(rbase + po * (int)p.ldr + n);
+      if (!partial && p.accumulate && live) pre_a[i] = osm::ld4(obase + po * (int)p.ldc + n);
+    }
+  };
+  // finishing phase of round a_.  MODE 0: split-K partial;  1: y = alpha v + bias + residual + previous y;  2: the same with
+  // column statistics
+  auto finish = [&](auto modec, const int a_) __attribute__((always_inline)) {
     constexpr int MODE = decltype(modec)::value;
-    constexpr bool RES = decltype(resc)::value != 0, ACC = decltype(accc)::value != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = gather(i);
@@ -638,15 +675,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       } else {
         act_t* __restrict__ op = obase + po * (int)p.ldc + n;
         v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
+        v.x += pre_r[i].x; v.y += pre_r[i].y; v.z += pre_r[i].z; v.w += pre_r[i].w;       // (in this order: residual, then y)
+        v.x += pre_a[i].x; v.y += pre_a[i].y; v.z += pre_a[i].z; v.w += pre_a[i].w;
         if (ok) {
-          if (MODE == 2 ? rbase != nullptr : RES) {
-            const float4 r = osm::ld4(rbase + po * (int)p.ldr + n);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          }
-          if (MODE == 2 ? p.accumulate != 0 : ACC) {
-            const float4 r = osm::ld4(op);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          }
           osm::st4(op, v);
           if constexpr (MODE == 2) {
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -667,6 +698,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   for (int rep_ = 0; rep_ < W8_EPI_REP; ++rep_)
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
+    prefetch(a);
     OSM_W8_STAMP(3 + 5 * a)
     __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
     OSM_W8_STAMP(4 + 5 * a)
@@ -674,10 +706,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     OSM_W8_STAMP(5 + 5 * a)
     __syncthreads();
     OSM_W8_STAMP(6 + 5 * a)
-    if (partial) finish(I0{}, I0{}, I0{}, a);
-    else if (stats) finish(I2{}, I0{}, I0{}, a);
-    else if (rbase) { if (p.accumulate) finish(I1{}, I1{}, I1{}, a); else finish(I1{}, I1{}, I0{}, a); }
-    else { if (p.accumulate) finish(I1{}, I0{}, I1{}, a); else finish(I1{}, I0{}, I0{}, a); }
+    if (partial) finish(I0{}, a);
+    else if (stats) finish(I2{}, a);
+    else finish(I1{}, a);
     OSM_W8_STAMP(7 + 5 * a)
   }
   if (stats) {       // workgroup-uniform

@@ -889,4 +889,10 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
 extern "C" int osm_debug_w8_stamps(unsigned long long* host) {   // measurement build only (tools/w8_stamps.py)
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(osm_w8_stamps), sizeof(unsigned long long) * 64 * 8 * 16);
 }
+extern "C" int osm_debug_w8_fine_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(osm_w8_fine_stamps), sizeof(unsigned long long) * 8 * 32 * 16);
+}
+extern "C" int osm_debug_w8_slab_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(osm_w8_slab_stamps), sizeof(unsigned long long) * 64 * 8 * 160);
+}
 #endif

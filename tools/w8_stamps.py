@@ -48,6 +48,28 @@ def main():
     for i, n in enumerate(names):
         print(f"  {n:18s} {d[:, :, i].mean():8.2f}  ({d[:, :, i].min():.2f} .. {d[:, :, i].max():.2f})")
     print(f"  total              {(t[:, :, 12] - t[:, :, 0]).mean():8.2f}")
+    if os.environ.get("W8_FINE") and hasattr(lib, "osm_debug_w8_fine_stamps"):
+        b3 = np.zeros(8 * 32 * 16, dtype=np.uint64)
+        assert lib.osm_debug_w8_fine_stamps(b3.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))) == 0
+        f = b3.reshape(8, 32, 16).astype(np.float64) * 0.01
+        steps = ["U loads", "raw store (waits for its load)", "raw load", "arith 0 (waits for LDS)", "LDS reads", "3 MFMAs", "arith 1 (waits)", "LDS reads", "3 MFMAs"]
+        print("unit 0 step by step (-DW8_FINE: fenced after every step), mean over slabs 2..13:")
+        for w in (0, 5):
+            d = np.diff(f[w, 2:14, :10], axis=1).mean(axis=0)
+            print(f"   wave {w}: " + "  ".join(f"{n} {x:.2f}" for n, x in zip(steps, d)))
+    if hasattr(lib, "osm_debug_w8_slab_stamps"):
+        b2 = np.zeros(64 * 8 * 160, dtype=np.uint64)
+        assert lib.osm_debug_w8_slab_stamps(b2.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))) == 0
+        u = b2.reshape(64, 8, 32, 5).astype(np.float64) * 0.01
+        ns = int((u[0, 0, :, 0] > 0).sum())
+        print(f"K loop, {ns} slabs: per slab [unit 0, unit 1, unit 2 (to the barrier), barrier wait, rest of unit 2 + unit 3], workgroup 0 / wave 0 and wave 5")
+        for w in (0, 5):
+            for c in range(ns - 1):
+                r = u[0, w, c]
+                print(f"   wave {w} slab {c:2d}: " + " ".join(f"{x:6.2f}" for x in (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], u[0, w, c + 1, 0] - r[4])) +
+                      f"   = {u[0, w, c + 1, 0] - r[0]:6.2f}")
+        d = u[:, :, 1:ns, 0] - u[:, :, 0:ns - 1, 0]
+        print(f"   slab time over all 64 x 8 waves: mean {d.mean():.2f}  min {d.min():.2f}  max {d.max():.2f};  barrier wait mean {(u[:, :, :ns, 4] - u[:, :, :ns, 3]).mean():.2f}")
 
 
 if __name__ == "__main__":
