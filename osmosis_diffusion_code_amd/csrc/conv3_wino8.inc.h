@@ -161,8 +161,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
   const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
 
-  // (starting the first slab's global loads HERE, ahead of the max |x| fold, was measured twice: hipcc then spills ~30 registers
-  // around the fold and inside the K loop -- +7 % on the class)
+  // (requesting the first U fragments up here as well was measured: hipcc then spills ~30 registers around the fold and inside
+  // the K loop -- +7 % on the class; the 12 activation registers alone fit)
   float4 ra[W8_NJ];
   uint4 uq[2][2][NP];       // [local xi][column tile][plane]: loaded two units ahead into the registers the previous slab's
                             // same xi released (a second slab-deep set was measured: +8..12 % time, it spills)
@@ -176,6 +176,11 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
 #pragma unroll
   for (int j = 0; j < W8_NJ; ++j) aoff[j] = ((vmask >> j) & 1u) ? voff[j] + (unsigned)(q4 * 4 * ACT_B) : 0x80000000u;
 
+  if constexpr (use_pipe) {   // the first slab's activation loads go out ahead of the max |x| fold: one global round trip instead of two
+#pragma unroll
+    for (int j = 0; j < W8_NJ; ++j)
+      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)aoff[j], kc0 * (16 * ACT_B), 0));
+  }
   // HP: x 2^ex brings the largest |x| of the image (OSM_MAXABS_PARTS partial maxima, as bit patterns) to [2^11, 2^12)
   float xscale = 1.f, oscale = 1.f;
   if (HP) {
@@ -457,8 +462,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
     osm::floatx4_t rd[4];
     const unsigned txa = (unsigned)(size_t)t_x, tya = (unsigned)(size_t)t_y;
     const int k1 = min(kc0 + 1, kc1 - 1);
-    OSM_W8P_LOAD_RAW(kc0, 0) OSM_W8P_LOAD_RAW(kc0, 1) OSM_W8P_LOAD_RAW(kc0, 2)
-    OSM_W8_LOAD_U(kc0, 0)
+    OSM_W8_LOAD_U(kc0, 0)                      // (the activations of slab kc0 were requested before the max |x| fold)
     OSM_W8P_STORE_RAW(0, 0) OSM_W8P_STORE_RAW(0, 1) OSM_W8P_STORE_RAW(0, 2)
     OSM_W8P_LOAD_RAW(k1, 0) OSM_W8P_LOAD_RAW(k1, 1) OSM_W8P_LOAD_RAW(k1, 2)
     __syncthreads();
