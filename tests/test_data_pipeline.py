@@ -34,6 +34,7 @@ def test_transform_chain_matches_oracle(h, w):
 
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "resize_chain.npz")
+GOLD_ATEN = os.path.join(os.path.dirname(__file__), "golden", "resize_chain_aten.npz")   # oracle/tools/gen_resize_aten_golden.py
 
 
 def _aten_chain(img_u8_hwc, size):
@@ -74,6 +75,21 @@ def test_transform_chain_matches_golden(k):
     for name, v in (("product", got.numpy()), ("numpy fp32", want)):
         assert np.allclose(v[:, 112:144, 112:144], g[f"out256_win_{k}"], atol=tol), name
         assert abs(float(v.astype(np.float64).sum()) - float(g[f"out256_sum_{k}"])) < tol * 3 * 256 * 256, name
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_transform_chain_is_bit_exact_vs_committed_aten_vectors(k):
+    """next to the float64 golden (tolerance 2e-4) the product chain is held BIT FOR BIT to committed vectors of the
+    ATen operator torchvision 0.14.x dispatches to (generated once by oracle/tools/gen_resize_aten_golden.py; provenance in the
+    file) -- vectors that do not move with the code under test."""
+    g, a = np.load(GOLD), np.load(GOLD_ATEN)
+    assert "ATen interpolate" in str(a["generator"]) and "torch " in str(a["generator"])
+    img = g[f"img_{k}"]
+    got32 = D.default_transform(32)(Image.fromarray(img)).numpy()
+    got256 = D.default_transform(256)(Image.fromarray(img)).numpy()[:, 112:144, 112:144]
+    assert np.array_equal(got32, a[f"out32_{k}"]), (str(a["generator"]), float(np.abs(got32 - a[f"out32_{k}"]).max()))
+    assert np.array_equal(got256, a[f"out256_win_{k}"]), (str(a["generator"]), float(np.abs(got256 - a[f"out256_win_{k}"]).max()))
+    assert np.allclose(a[f"out32_{k}"], g[f"out32_{k}"], atol=2e-4)        # and the committed ATen vectors agree with the float64 ones
 
 
 def test_resize_rule_and_center_crop_offsets():
