@@ -505,6 +505,8 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
           (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
       return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 4-element vectors: ldy, ldr multiples of 4, aligned y / res / bias");
     const int nimg = p.M / (p.H * p.W);
+    if ((long long)p.H * p.W * p.lda * (long long)sizeof(act_t) > 0xffffffffLL)
+      return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel addresses an image by 32-bit byte offsets: H * W * ldx * sizeof(x) must be < 4 GiB");
     p.mtiles = nimg * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     p.ntiles = (p.N + 63) / 64;
     p.nchunks = p.ksteps;                       // 16-channel slabs
@@ -531,7 +533,9 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
         return osm::fail(OSM_ERR_UNSUPPORTED, "the f16x3 Winograd image does not take a fused GroupNorm input (gn_table)");
       // the software-pipelined K loop: 16-channel slabs without a tail, and enough of them per workgroup to pay for its prologue
       const int per = (p.ksteps + p.splitk - 1) / p.splitk;
-      if (W8_PIPE && (p.K & 15) == 0 && per >= W8_PIPE_MIN)
+      // (its staging addresses activations by 32-bit buffer offsets relative to the image, out-of-range = padding: < 2 GiB per image)
+      const long long img_bytes = (long long)p.H * p.W * p.lda * (long long)sizeof(act_t);
+      if (W8_PIPE && (p.K & 15) == 0 && per >= W8_PIPE_MIN && img_bytes < 0x7fffffffLL)
         hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true, true>), gw, dim3(512), 0, st, p.A, Up, p);
       else
         hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true, false>), gw, dim3(512), 0, st, p.A, Up, p);
