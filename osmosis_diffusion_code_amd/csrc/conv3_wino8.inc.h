@@ -52,7 +52,7 @@
                          // barrier wait 17 -> 12 % of the loop); 0 = off
 #endif
 #ifndef W8_PIPE_MIN
-#define W8_PIPE_MIN 8
+#define W8_PIPE_MIN 4
 #endif
 constexpr int W8_NJ = 3;                     // raw staging pieces per thread and slab (1296 pieces, 512 threads)
 
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   };
   OSM_W8_STAMP(1)
   if (kc1 > kc0) {
-    // the pipelined loop pays from ~8 slabs per workgroup (its prologue is two dependent LDS round trips longer)
+    // (the host launches this instance from W8_PIPE_MIN slabs per workgroup: its prologue is two dependent LDS round trips longer)
     if constexpr (use_pipe) {
       if (wh == 0) slab_loop_p(std::integral_constant<int, 0>{});
       else slab_loop_p(std::integral_constant<int, 1>{});

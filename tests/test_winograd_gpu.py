@@ -35,7 +35,7 @@ CASES = [  # B, Cin, Cout, H, W, splitk
     (1, 64, 64, 16, 16, 1), (2, 32, 96, 16, 32, 1), (1, 96, 160, 24, 40, 1), (1, 40, 64, 17, 19, 1),   # ragged patch, Cin tail
     (2, 64, 128, 32, 32, 2), (1, 256, 64, 16, 16, 4), (1, 128, 192, 40, 24, 3), (1, 16, 64, 64, 64, 1),
     (1, 512, 512, 32, 32, 8), (3, 64, 64, 18, 30, 1),
-    # >= 8 slabs of 16 channels per workgroup: the software-pipelined K loop of the f16x3 kernel (odd / even slab counts, ragged
+    # >= 4 slabs of 16 channels per workgroup (also (1, 256, 64, 16, 16, 4), (1, 512, 512, 32, 32, 8) above): the software-pipelined K loop of the f16x3 kernel (odd / even slab counts, ragged
     # patches, split-K with a shorter last share)
     (1, 144, 64, 16, 16, 1), (1, 272, 96, 20, 36, 1), (2, 288, 64, 16, 16, 2), (1, 400, 64, 17, 16, 3), (1, 256, 256, 32, 48, 1)]
 
