@@ -217,7 +217,7 @@ int osm_gn_fwd_coop(const float* x, long long ldx, float* y, long long ldy, int 
  * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
                 const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
-                void* stream);
+                float* maxabs_in /* as in osm_gn_fwd; NULL = off */, void* stream);
 /* Statistics from column sums emitted by the producing convolution (osm_conv_desc.colsum, [B][nchunk][2][C]):
  * mode 0: stats[B][G][2] = (mean, rstd) of the tensor (+ the per-channel table [B][4][C] when table != NULL, as
  * osm_gn_prep);  mode 1: stats = (sum dxh / n, sum dxh xh / n), the two means of the GroupNorm backward (gstats). */
@@ -387,7 +387,7 @@ int osm_gn_fwd_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ld
                  long long ldfilm, int silu, float* maxabs_out /* must be NULL */, float* maxabs_in /* must be NULL */, void* stream);
 int osm_gn_prep_h(const osm_half_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
                   const float* gamma, const float* beta, const float* film, long long ldfilm, float* table,
-                  void* stream);
+                  float* maxabs_in /* must be NULL */, void* stream);
 int osm_gn_bwd_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
                  const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                  const float* stats, const float* gamma, const float* beta, const float* film,

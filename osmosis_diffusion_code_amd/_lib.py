@@ -89,7 +89,7 @@ _SIGS = {
     "osm_gn_stats": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P],
     "osm_gn_apply": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P],
     "osm_gn_fwd": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P],
-    "osm_gn_prep": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _P, _P],
+    "osm_gn_prep": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _P, _P, _P],
     "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
     "osm_gn_coop_plan": [_I, _I, _I, _I, _I],
     "osm_gn_coop_set": [C.c_char_p, _LL],

@@ -652,8 +652,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   };
   // the residual / accumulate operands of a round are requested BEFORE its LDS exchange (their global round trips, one per
   // tile row and serial when issued where they are used, then run under the exchange); zeros where there is nothing to add
-  float4 pre_r[4], pre_a[4];
-  auto prefetch = [&](const int a_) __attribute__((always_inline)) {
+  // (MODE 3, backward statistics: so is the GroupNorm input the reductions need -- as four dependent round trips inside the
+  // finishing phase it made OSM_FUSE_STATS=all a net loss)
+  float4 pre_r[4], pre_a[4], pre_x[4];
+  const bool silu_on = p.stat_silu != 0;
+  auto prefetch = [&](auto modec, const int a_) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int dy = 8 * a_ + 2 * i;
@@ -662,10 +666,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       pre_r[i] = pre_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rbase && live) pre_r[i] = osm::ld4(rbase + po * (int)p.ldr + n);
       if (!partial && p.accumulate && live) pre_a[i] = osm::ld4(obase + po * (int)p.ldc + n);
+      if constexpr (MODE == 3) {
+        pre_x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sxbase && live) pre_x[i] = osm::ld4(sxbase + po * (int)p.ld_sx + n);
+      }
     }
   };
   // finishing phase of round a_.  MODE 0: split-K partial;  1: y = alpha v + bias + residual + previous y;  2: the same with
-  // column statistics
+  // forward column statistics;  3: with the backward ones
   auto finish = [&](auto modec, const int a_) __attribute__((always_inline)) {
     constexpr int MODE = decltype(modec)::value;
 #pragma unroll
@@ -683,37 +691,46 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
         v.x += pre_a[i].x; v.y += pre_a[i].y; v.z += pre_a[i].z; v.w += pre_a[i].w;
         if (ok) {
           osm::st4(op, v);
-          if constexpr (MODE == 2) {
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sxbase) xv = osm::ld4(sxbase + po * (int)p.ld_sx + n);
-            stat_add(p.stat_mode, p.stat_silu, sc[0], (float)(act_t)v.x, xv.x, st1[0], st2[0]);
-            stat_add(p.stat_mode, p.stat_silu, sc[1], (float)(act_t)v.y, xv.y, st1[1], st2[1]);
-            stat_add(p.stat_mode, p.stat_silu, sc[2], (float)(act_t)v.z, xv.z, st1[2], st2[2]);
-            stat_add(p.stat_mode, p.stat_silu, sc[3], (float)(act_t)v.w, xv.w, st1[3], st2[3]);
+          if constexpr (MODE == 2) {          // forward statistics of the tensor as stored
+            stat_add(1, 0, sc[0], (float)(act_t)v.x, 0.f, st1[0], st2[0]);
+            stat_add(1, 0, sc[1], (float)(act_t)v.y, 0.f, st1[1], st2[1]);
+            stat_add(1, 0, sc[2], (float)(act_t)v.z, 0.f, st1[2], st2[2]);
+            stat_add(1, 0, sc[3], (float)(act_t)v.w, 0.f, st1[3], st2[3]);
+          } else if constexpr (MODE == 3) {   // the two backward reductions (no per-element scalar branches: learned 42)
+            const float4 xv = pre_x[i];
+            stat_add_bwd(silu_on, sc[0], (float)(act_t)v.x, xv.x, st1[0], st2[0]);
+            stat_add_bwd(silu_on, sc[1], (float)(act_t)v.y, xv.y, st1[1], st2[1]);
+            stat_add_bwd(silu_on, sc[2], (float)(act_t)v.z, xv.z, st1[2], st2[2]);
+            stat_add_bwd(silu_on, sc[3], (float)(act_t)v.w, xv.w, st1[3], st2[3]);
           }
         }
       }
     }
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
 #ifndef W8_EPI_REP
 #define W8_EPI_REP 1        // measurement builds: the epilogue executed this many times
 #endif
   for (int rep_ = 0; rep_ < W8_EPI_REP; ++rep_)
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    prefetch(a);
-    OSM_W8_STAMP(3 + 5 * a)
-    __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
-    OSM_W8_STAMP(4 + 5 * a)
-    if (wh == 0) put(I0{}, a); else put(I1{}, a);
-    OSM_W8_STAMP(5 + 5 * a)
-    __syncthreads();
-    OSM_W8_STAMP(6 + 5 * a)
-    if (partial) finish(I0{}, a);
-    else if (stats) finish(I2{}, a);
-    else finish(I1{}, a);
-    OSM_W8_STAMP(7 + 5 * a)
+    auto round = [&](auto modec) __attribute__((always_inline)) {
+      prefetch(modec, a);
+      OSM_W8_STAMP(3 + 5 * a)
+      __syncthreads();     // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
+      OSM_W8_STAMP(4 + 5 * a)
+      if (wh == 0) put(I0{}, a); else put(I1{}, a);
+      OSM_W8_STAMP(5 + 5 * a)
+      __syncthreads();
+      OSM_W8_STAMP(6 + 5 * a)
+      finish(modec, a);
+      OSM_W8_STAMP(7 + 5 * a)
+    };
+    if (partial) round(I0{});
+    else if (stats && sxbase) round(I3{});
+    else if (stats) round(I2{});
+    else round(I1{});
   }
   if (stats) {       // workgroup-uniform
 #pragma unroll

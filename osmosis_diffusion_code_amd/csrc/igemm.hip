@@ -88,6 +88,16 @@ __device__ __forceinline__ void stat_add(int mode, int silu, const StatCol& c, f
   }
 }
 
+// mode 2 of stat_add with the SiLU choice as a select (straight-line code for unrolled epilogues)
+__device__ __forceinline__ void stat_add_bwd(bool silu, const StatCol& c, float v, float xv, float& s1, float& s2) {
+  const float xh = (xv - c.mean) * c.rstd;
+  const float z = xh * c.g + c.b;
+  float d = osm::dsilu_f(z);
+  asm("" : "+v"(d));            // computed unconditionally: no scalar branch around it
+  const float dxh = v * (silu ? d : 1.0f) * c.g;
+  s1 += dxh;
+  s2 += dxh * xh;
+}
 
 #ifndef OSM_ACT_F16
 // NARROW (N <= 64, e.g. attention P V with 64-wide heads): the four waves split the 128 rows (32 each) and

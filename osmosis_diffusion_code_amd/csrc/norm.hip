@@ -886,13 +886,14 @@ extern "C" int OSM_FN(osm_gn_stats)(const abi_act_t* x, long long ldx, int B, in
 
 extern "C" int OSM_FN(osm_gn_prep)(const abi_act_t* x, long long ldx, int B, int HW, int C, int G, float eps, float* part,
                            float* stats, const float* gamma, const float* beta, const float* film,
-                           long long ldfilm, float* table, void* stream) {
+                           long long ldfilm, float* table, float* maxabs_in, void* stream) {
   OSM_REQUIRE(x && part && stats && gamma && beta && table, "osm_gn_prep: null pointer");
   OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_prep: ldfilm smaller than 2*C");
   GNArgs a{};
   a.x = OSM_CACT(x); a.ldx = ldx; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.part = part;
   int rc = check_common(a, "osm_gn_prep");
   if (rc) return rc;
+  if ((rc = set_maxabs_in(a, maxabs_in, "osm_gn_prep"))) return rc;
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, false);
   if (rc) return rc;
   const int n = B * G;

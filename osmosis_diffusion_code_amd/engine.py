@@ -258,15 +258,19 @@ class UNetEngine:
         self._fwd_graph = self._bwd_graph = None
         # GN apply inside the consuming 3x3 conv (needs the halo-tile kernel, which OSM_CONV_HALO=0 switches off)
         self.fuse_gn = os.environ.get("OSM_FUSE_GN", "1") != "0" and os.environ.get("OSM_CONV_HALO", "1") != "0"
-        # GroupNorm reductions as column sums from the epilogue of the producing conv.  OSM_FUSE_STATS = "fwd" (default):
-        # the forward statistics of a ResBlock's second GroupNorm come from its first convolution; "all": also the two
-        # backward reductions, from the data-gradient convolutions (measured a net loss: the epilogue must re-read the
-        # GroupNorm input with 4-byte accesses: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1); "0": neither
+        # GroupNorm reductions as column sums from the epilogue of the producing conv.  OSM_FUSE_STATS = "fwd" (default of the
+        # fp16-storage family): the forward statistics of a ResBlock's second GroupNorm come from its first convolution; "wino"
+        # (default of the fp32-storage family, round 4): also the two backward reductions, from the data-gradient convolutions
+        # the WINOGRAD kernel serves -- its epilogue owns 16-byte column groups and requests the GroupNorm input before its LDS
+        # exchange (same-box A/B of the step: -0.13 ... -0.15 ms at B = 1, -1.4 ms at B = 8; with the four dependent loads inside
+        # the finishing phase it was +0.18 ms); "all": from the direct halo-tile kernel as well (4-byte accesses in the MFMA C
+        # layout: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1, round 2; fp16 family +0.9 ms at B = 32); "0": neither
         self.winograd_min_hw = int(os.environ.get("OSM_WINOGRAD_MIN_HW", "16"))   # smallest H, W served by the Winograd kernel
-        fs = os.environ.get("OSM_FUSE_STATS", "fwd")
+        fs = os.environ.get("OSM_FUSE_STATS", "fwd" if self.adt == torch.float16 else "wino")
         self.fuse_gn_wino = os.environ.get("OSM_FUSE_GN_WINO", "0") == "1"
         self.fuse_stats = self.fuse_gn and fs != "0"
-        self.fuse_stats_bwd = self.fuse_stats and fs == "all"
+        self.fuse_stats_bwd = self.fuse_stats and fs in ("all", "wino")
+        self.fuse_stats_bwd_direct = self.fuse_stats and fs == "all"
         self._check_xmax = os.environ.get("OSM_CHECK_XMAX", "0") == "1"
         self._attn_half = self.adt == torch.float16 and os.environ.get("OSM_ATTN_F16", "1") != "0"
 
@@ -422,7 +426,8 @@ class UNetEngine:
         """OSM_FUSE_STATS=all: may the data-gradient convolution of `cv` emit the two GroupNorm-backward reductions of the
         GroupNorm in front of `cv`?  Needs the per-channel table of that GroupNorm kept from the forward pass."""
         H, W = hw
-        return self._gn_fusable(cv, hw) or (self._is_wino(cv, hw) and self._is_wino(cv, hw, dgrad=True) and H * W > 1024)
+        return (self.fuse_stats_bwd_direct and self._gn_fusable(cv, hw)) or \
+            (self._is_wino(cv, hw) and self._is_wino(cv, hw, dgrad=True) and H * W > 1024)
 
     def _gn_stats_from_conv(self, cv: _Conv, hw) -> bool:
         """May the convolution that produces a tensor also emit the column sums for the GroupNorm `cv` reads it through?"""
@@ -460,8 +465,9 @@ class UNetEngine:
             else:
                 ops.gn_finalize_cols(cs[0], cs[1], B, H * W, x.cols, G, st, mode=0)
             ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
-        elif table is not None:     # the table is kept for the backward (OSM_FUSE_STATS=all)
-            ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film)
+        elif table is not None:     # the table is kept for the backward (OSM_FUSE_STATS=wino / all)
+            ops.gn_prep(x, B, H * W, G, self.gn_part, st, norm.g, norm.b, table, film=film, maxabs_in=xin_max)
+            xin_max = None
             ops.gn_apply(x, a, B, H * W, G, st, norm.g, norm.b, film=film, silu=True, maxabs=xm)
         else:
             # xin_max: the caller asked for max |x| of the INPUT as well (it has checked that this branch is the one taken)
@@ -536,7 +542,7 @@ class UNetEngine:
             # the skip connection's 1x1 convolution reads x itself: where it has an f16x3 image, the statistics pass of the first
             # GroupNorm (which reads every element of x anyway) leaves max |x| behind for it -- so it runs AFTER that pass
             xin = None
-            if blk.skip is not None and blk.skip.wf16 is not None and HW >= 4096 and HW % 128 == 0 and tab1 is None and \
+            if blk.skip is not None and blk.skip.wf16 is not None and HW >= 4096 and HW % 128 == 0 and \
                     not self._gn_fusable(blk.c1, hw) and ops.gn_nchunk(HW) <= ops.MAXABS_PARTS:
                 xin = self._xmax_slot("skip")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,

@@ -273,11 +273,12 @@ def gn_fwd(x: Mat, y: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, fi
          fp, ldf, int(silu), ptr(maxabs), ptr(maxabs_in), _s(), keep=(x.t, y.t, part, stats, gamma, beta, film, maxabs, maxabs_in))
 
 
-def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5):
-    """statistics (-> `stats`) + per-channel table [B][4][C] that conv2d(gn_table=...) applies while staging."""
+def gn_prep(x: Mat, B: int, HW: int, G: int, part, stats, gamma, beta, table, film=None, eps: float = 1e-5, maxabs_in=None):
+    """statistics (-> `stats`) + per-channel table [B][4][C] that conv2d(gn_table=...) applies while staging (or that a
+    data-gradient convolution's epilogue uses for the GroupNorm-backward reductions).  maxabs_in: as in gn_fwd."""
     fp, ldf = _film(film)
     call("osm_gn_prep" + _fam(x.t), x.p, x.ld, B, HW, x.cols, G, eps, ptr(part), ptr(stats), ptr(gamma), ptr(beta), fp, ldf,
-         ptr(table), _s(), keep=(x.t, part, stats, gamma, beta, film, table))
+         ptr(table), ptr(maxabs_in), _s(), keep=(x.t, part, stats, gamma, beta, film, table, maxabs_in))
 
 
 def _addends(addend, addend2):
