@@ -633,7 +633,9 @@ __global__ __launch_bounds__(512) void gn_reg_kernel(GNArgs a) {
   const int c = g * a.gs + 4 * tv;
   const bool film = a.film != nullptr;
   const long long row0 = (long long)b * a.HW;
-  float4 xr[NV], dr[MODE == 1 ? NV : 1];
+  // (backward: the addends are requested here as well -- after the two barriers of the reduction they were one more dependent
+  // memory round trip of a ~7-16 us kernel; an addend that aliases `out` is read by the thread that later writes the element)
+  float4 xr[NV], dr[MODE == 1 ? NV : 1], ar[MODE == 1 ? NV : 1];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int p = p0 + k * pstep;
@@ -644,6 +646,12 @@ __global__ __launch_bounds__(512) void gn_reg_kernel(GNArgs a) {
     if (MODE == 1) {
       const float4 u = osm::ld4(a.dy + row * a.lddy + c);
       dr[k] = live ? u : make_float4(0.f, 0.f, 0.f, 0.f);
+      ar[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.addend) ar[k] = osm::ld4(a.addend + row * a.ldadd + c);
+      if (a.addend2) {
+        const float4 w = osm::ld4(a.addend2 + row * a.ldadd2 + c);
+        ar[k].x += w.x; ar[k].y += w.y; ar[k].z += w.z; ar[k].w += w.w;
+      }
     }
   }
   float ga[4], be[4], sc[4], sh[4];
@@ -744,15 +752,7 @@ __global__ __launch_bounds__(512) void gn_reg_kernel(GNArgs a) {
       }
     } else {
       const float dxv[4] = {dr[k].x, dr[k].y, dr[k].z, dr[k].w};      // dxh of the first sweep
-      float av[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.addend) {
-        const float4 w = osm::ld4(a.addend + (row0 + p) * a.ldadd + c);
-        av[0] = w.x; av[1] = w.y; av[2] = w.z; av[3] = w.w;
-      }
-      if (a.addend2) {
-        const float4 w = osm::ld4(a.addend2 + (row0 + p) * a.ldadd2 + c);
-        av[0] += w.x; av[1] += w.y; av[2] += w.z; av[3] += w.w;
-      }
+      const float av[4] = {ar[k].x, ar[k].y, ar[k].z, ar[k].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xh = (xv[e] - mean) * rstd;
