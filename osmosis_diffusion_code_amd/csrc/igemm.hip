@@ -334,6 +334,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(IGemmParams p) 
   const long long i = (long long)blockIdx.x * 64 + lane;       // float4 index
   const bool live = i < slice / 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the finishing wave requests its residual / previous-output operands WITH its partials (after the LDS fold's barrier they were
+  // one more dependent memory round trip of a ~5 us kernel)
+  const int nv = p.N / 4;
+  const int n = (int)(i % nv) * 4;
+  const long long m = i / nv;
+  act_t* c = p.C + m * p.ldc + n;
+  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && kg == 0) {
+    if (p.res) r4 = osm::ld4(p.res + m * p.ldr + n);
+    if (p.accumulate) c4 = osm::ld4(c);
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[e] = p.bias[n + e];
+    }
+  }
   if (live) {
     const float* w = p.ws + i * 4;
 #pragma unroll 4
@@ -347,15 +363,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(IGemmParams p) 
   if (kg != 0 || !live) return;
   const float4 a = red[0][lane], b = red[1][lane], c2 = red[2][lane], d = red[3][lane];
   float v[4] = {(a.x + b.x) + (c2.x + d.x), (a.y + b.y) + (c2.y + d.y), (a.z + b.z) + (c2.z + d.z), (a.w + b.w) + (c2.w + d.w)};
-  const int nv = p.N / 4;
-  const int n = (int)(i % nv) * 4;
-  const long long m = i / nv;
-  act_t* c = p.C + m * p.ldc + n;
-  const float4 r4 = p.res ? osm::ld4(p.res + m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 c4 = p.accumulate ? osm::ld4(c) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f)) + rv[e] + cv[e];
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha + bq[e]) + rv[e] + cv[e];
   osm::st4(c, make_float4(v[0], v[1], v[2], v[3]));
 }
 
