@@ -71,25 +71,6 @@ __device__ __forceinline__ void frag_gather(const float* __restrict__ X, long lo
   const float4 b = make_float4(p[8 * ld], p[9 * ld], p[10 * ld], p[11 * ld]);
   split_frag8<NP>(a, b, f);
 }
-// The same two access patterns as RAW loads (8 fp32 per lane), so that a loop can request every operand of an iteration before
-// it uses the first (round 4: as load -> split -> MFMA per fragment an iteration was 5-6 DEPENDENT memory round trips and the
-// kernels were bound by exactly that chain), and the split of a raw fragment.
-struct Raw8 { float4 a, b; };
-__device__ __forceinline__ Raw8 raw_row(const float* __restrict__ X, long long ld, long long row, int col, int s, int h) {
-  const float* p = X + row * ld + col + 16 * s + 8 * h;
-  return Raw8{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
-}
-__device__ __forceinline__ Raw8 raw_gather(const float* __restrict__ X, long long ld, long long row0, int col, int s, int h) {
-  const float* p = X + (row0 + 16 * s + 4 * h) * ld + col;
-  return Raw8{make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]), make_float4(p[8 * ld], p[9 * ld], p[10 * ld], p[11 * ld])};
-}
-template <int NP>
-__device__ __forceinline__ void split_raw(const Raw8& r, float scale, uint4 (&f)[NP]) {
-  float4 a = r.a, b = r.b;
-  a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
-  b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
-  split_frag8<NP>(a, b, f);
-}
 // accumulator registers [8 s .. 8 s + 7] -> fragment of step s
 template <int NP>
 __device__ __forceinline__ void frag_acc(const f32x16& c, int s, uint4 (&f)[NP]) {
@@ -260,25 +241,12 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
   const int kw = a.T / a.nw;
   const int kend = wave < a.nw ? (wave + 1) * kw : 0;
   for (int kb = wave * kw; kb < kend; kb += 32) {
-    // every operand of this key block is requested before the first is used: the K / V rows (consumed first), then the K gathers
-    Raw8 kr[4], vr[4], kg0[2], kg1[2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kr[s] = raw_row(K, ld, rb + kb + lr, 0, s, h);
-      vr[s] = raw_row(V, ld, rb + kb + lr, 0, s, h);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      kg0[t] = raw_gather(K, ld, rb + kb, lr, t, h);
-      kg1[t] = raw_gather(K, ld, rb + kb, 32 + lr, t, h);
-    }
-    __builtin_amdgcn_sched_barrier(0);     // (hipcc otherwise sinks each load down to its use)
     f32x16 st = zero16(), dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 kf[NP], vf[NP];
-      split_raw<NP>(kr[s], 1.f, kf);
-      split_raw<NP>(vr[s], 1.f, vf);
+      frag_row(K, ld, rb + kb + lr, 0, s, h, 1.f, kf);
+      frag_row(V, ld, rb + kb + lr, 0, s, h, 1.f, vf);
 #pragma unroll
       for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
@@ -293,8 +261,8 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
     for (int t = 0; t < 2; ++t) {
       uint4 sf[NP], k0[NP], k1[NP];
       frag_acc(st, t, sf);
-      split_raw<NP>(kg0[t], 1.f, k0);
-      split_raw<NP>(kg1[t], 1.f, k1);
+      frag_gather(K, ld, rb + kb, lr, t, h, k0);
+      frag_gather(K, ld, rb + kb, 32 + lr, t, h, k1);
 #pragma unroll
       for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
