@@ -134,6 +134,44 @@ def test_full_size_unet_256_vs_reference_golden(create_model):
             assert abs(l2y - float(g[tag + ".y_l2"])) < 1e-5 * float(g[tag + ".y_l2"])
 
 
+@pytest.mark.parametrize("conv_mode", ["f16x3", "bf16x6"])
+def test_groupnorm_reduction_sources_agree_at_full_size(create_model, monkeypatch, conv_mode):
+    """Round 4 (third session): the GroupNorm reductions may come from their own passes (OSM_FUSE_STATS=0), from the forward convolutions'
+    epilogues (fwd), additionally from the Winograd data-gradient epilogues (wino: the default of the fp32-storage family) or from the
+    direct kernel's as well (all).  Every source must give the reference's input gradient (golden of the REAL reference, full size) and
+    the sources must agree with each other to summation-order noise."""
+    g = dict(np.load(os.path.join(GOLD, "full_unet.npz")))
+    kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
+              class_cond=False, use_checkpoint=False, attention_resolutions="32, 16, 8", num_heads=4,
+              num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+              resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path="",
+              pretrain_model="osmosis")
+    m, cfg, sd = build(create_model, kw, seed=1234)
+    m.conv_mode = conv_mode
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = float(g["x_scale"]) * torch.randn(1, 4, 256, 256, generator=gen)
+    w = torch.randn(1, 8, 256, 256, generator=gen)
+    st, tag = int(g["stride"]), "t37"
+    out = {}
+    for mode in ("0", "fwd", "wino", "all"):
+        monkeypatch.setenv("OSM_FUSE_STATS", mode)
+        m._engines = {}                      # the switch is read when an engine is built
+        xd = x.to(DEV).requires_grad_(True)
+        yd = m(xd, torch.tensor([37.0], device=DEV))
+        (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+        ey = float((yd.detach().cpu()[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".y_sub"])).abs().max())
+        ed = float((dxd.cpu()[:, :, ::st, ::st] - torch.from_numpy(g[tag + ".dx_sub"])).abs().max())
+        print(f"{conv_mode} OSM_FUSE_STATS={mode}: vs the real reference: y {ey:.2e}  dx {ed:.2e} (max {float(g[tag + '.dx_max']):.2f})")
+        assert ey < 1e-4 * max(1.0, float(g[tag + ".y_max"])) and ed < 1e-4 * max(1.0, float(g[tag + ".dx_max"]))
+        out[mode] = (yd.detach().clone(), dxd.clone())
+    m._engines = {}
+    for mode in ("fwd", "wino", "all"):
+        dy = float((out[mode][0] - out["0"][0]).abs().max()) / max(1.0, float(out["0"][0].abs().max()))
+        dd = float((out[mode][1] - out["0"][1]).abs().max()) / max(1.0, float(out["0"][1].abs().max()))
+        print(f"{conv_mode} {mode} vs own passes: y {dy:.2e}  dx {dd:.2e} (relative to the maxima)")
+        assert dy < 2e-5 and dd < 2e-5
+
+
 def test_cpu_model_refuses_to_run(create_model):
     m = create_model(**TINY_KW)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
