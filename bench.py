@@ -607,6 +607,8 @@ def main():
                                             "contraction is bf16x6 (exact three-term bf16 split, six MFMAs).  Tests hold both to the same "
                                             "4e-6 against fp64; `same_workload_bf16x6` is this run in bf16x6 everywhere")
                    if args.conv_mode == "f16x3" else None, "parallelism": f"images[rank::{world}] (no collective on the path)",
+                   "groupnorm_reductions": os.environ.get("OSM_FUSE_STATS", "wino") + " (OSM_FUSE_STATS; wino = forward statistics and the "
+                                           "backward reductions of GroupNorm from the Winograd convolutions' epilogues)",
                    "finite_outputs": finite},
         "images_per_sec_at_1000_steps": round(units / dt / 1000.0, 6),
         # how the ranks met (barrier, gather of per-rank times): "rccl" | "gloo" | "files" ("none" at N = 1); the data path has
