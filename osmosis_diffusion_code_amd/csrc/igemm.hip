@@ -385,14 +385,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s[e] = 0.f;
     const float* w = p.ws + i * VEC;
-    for (int k = 0; k < p.splitk; ++k) {
-      if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(w + k * slice);
-        s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
-      } else {
-        s[0] += w[k * slice];
-      }
-    }
+    // residual / previous output are requested BEFORE the walk over the partials (behind it they were one more dependent round trip)
     const int b1 = z % p.nb1, b2 = z / p.nb1;
     const long long coff = b1 * p.sC1 + b2 * p.sC2;
     act_t* c = p.C + coff + (long long)m * p.ldc + n;
@@ -406,6 +399,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
     } else {
       rv[0] = rs ? osm::ld1(rs) : 0.f;
       cv[0] = p.accumulate ? osm::ld1(c) : 0.f;
+    }
+    for (int k = 0; k < p.splitk; ++k) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(w + k * slice);
+        s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+      } else {
+        s[0] += w[k * slice];
+      }
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s[e] = (s[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f)) + rv[e] + cv[e];
