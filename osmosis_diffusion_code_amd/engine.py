@@ -271,6 +271,8 @@ class UNetEngine:
         self.fuse_stats = self.fuse_gn and fs != "0"
         self.fuse_stats_bwd = self.fuse_stats and fs in ("all", "wino")
         self.fuse_stats_bwd_direct = self.fuse_stats and fs == "all"
+        # smallest H * W whose Winograd data-gradients carry the backward reductions (below 64 x 64 the one-launch GroupNorm is cheaper)
+        self.stats_bwd_min_hw = int(os.environ.get("OSM_STATS_BWD_MIN_HW", "1025"))
         self._check_xmax = os.environ.get("OSM_CHECK_XMAX", "0") == "1"
         self._attn_half = self.adt == torch.float16 and os.environ.get("OSM_ATTN_F16", "1") != "0"
 
@@ -427,7 +429,7 @@ class UNetEngine:
         GroupNorm in front of `cv`?  Needs the per-channel table of that GroupNorm kept from the forward pass."""
         H, W = hw
         return (self.fuse_stats_bwd_direct and self._gn_fusable(cv, hw)) or \
-            (self._is_wino(cv, hw) and self._is_wino(cv, hw, dgrad=True) and H * W > 1024)
+            (self._is_wino(cv, hw) and self._is_wino(cv, hw, dgrad=True) and H * W >= self.stats_bwd_min_hw)
 
     def _gn_stats_from_conv(self, cv: _Conv, hw) -> bool:
         """May the convolution that produces a tensor also emit the column sums for the GroupNorm `cv` reads it through?"""
