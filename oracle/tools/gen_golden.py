@@ -19,6 +19,8 @@ Sections (SURVEY.md section 8c recipe):
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
+  outputs.npz         (round 5) the five per-image output files of osmosis_sampling.py:319-353 as uint8 arrays
+  configs.json        (round 5) configs/*.yaml as parsed by the reference's load_yaml
   full_unet.npz       (round 4) the full 552.8 M-parameter architecture through the real reference at 256 x 256 (every 4th pixel of y and
                       of the input gradient + norms, two timesteps)
   full_step.npz       (round 4) two guided steps of the real reference's loop with the full network (t = 299, then 0): subsampled traces
@@ -545,6 +547,75 @@ def gen_postprocess():
     np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
 
 
+def gen_outputs():
+    """The five per-image files of osmosis_sampling.py:319-353 as uint8 arrays, for a seeded final pred_xstart / phi / input of
+    a revised-underwater run: the tensors are formed with the reference's OWN helpers (osmosis_utils/utils.py) in the order the
+    driver applies them (:207-223), the grid goes through the reference's clip_image (:347-349).  torchvision is absent from
+    this image, so its two layout / conversion steps are restated here from its 0.14.1 behaviour: to_pil_image on a float
+    tensor = pic.mul(255).byte() (truncation); make_grid(list, nrow=3, pad_value=1.) = stack, 2-pixel padding, row-major tiles.
+    A second case carries the ground-truth row of the simulation config (:341-344)."""
+    from osmosis_utils import utils as R_u
+
+    def to_pil_u8(pic):
+        if pic.dim() == 2:
+            pic = pic.unsqueeze(0)
+        a = pic.mul(255).byte().permute(1, 2, 0).numpy()
+        return a[:, :, 0] if a.shape[2] == 1 else a
+
+    def tv_make_grid(lst, nrow, pad_value, padding=2):
+        t = torch.stack(lst, dim=0)
+        nmaps = t.size(0)
+        xmaps = min(nrow, nmaps)
+        ymaps = int(np.ceil(float(nmaps) / xmaps))
+        height, width = int(t.size(2) + padding), int(t.size(3) + padding)
+        grid = t.new_full((t.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+        k = 0
+        for yy in range(ymaps):
+            for xx in range(xmaps):
+                if k >= nmaps:
+                    break
+                grid.narrow(1, yy * height + padding, height - padding).narrow(2, xx * width + padding, width - padding).copy_(t[k])
+                k += 1
+        return grid
+
+    g = torch.Generator().manual_seed(77)
+    H, W = 20, 28
+    out_xstart = torch.randn(1, 4, H, W, generator=g) * 0.8        # leaves [-1, 1]: the clips matter
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    gt_rgb = torch.rand(3, H, W, generator=g)
+    gt_depth = torch.rand(1, H, W, generator=g)
+    ref_img_01 = 0.5 * (ref_img[0] + 1)
+    sample_rgb = out_xstart[0, 0:-1, :, :]
+    sample_depth_tmp = out_xstart[0, -1, :, :].unsqueeze(0)
+    sample_rgb_01 = 0.5 * (sample_rgb + 1)
+    sample_rgb_01_clip = torch.clamp(sample_rgb_01, min=0, max=1)
+    sample_depth_mm = R_u.min_max_norm_range(sample_depth_tmp[0].unsqueeze(0))
+    pmm = R_u.min_max_norm_range_percentile(sample_depth_tmp, vmin=0, vmax=1, percent_low=0.03, percent_high=0.99, is_uint8=False)
+    color = R_u.depth_tensor_to_color_image(pmm)
+    out = {"out_xstart": npy(out_xstart), "ref_img": npy(ref_img), "gt_rgb_01": npy(gt_rgb), "gt_depth_01": npy(gt_depth),
+           "input": to_pil_u8(ref_img_01), "rgb": to_pil_u8(sample_rgb_01_clip), "depth_color": to_pil_u8(color),
+           "depth_raw": to_pil_u8(sample_depth_mm)}
+    grid = tv_make_grid([ref_img_01, sample_rgb_01_clip, color], nrow=3, pad_value=1.)
+    out["grid"] = R_u.clip_image(grid, scale=False, move=False, is_uint8=True).permute(1, 2, 0).numpy()
+    gt_color = R_u.depth_tensor_to_color_image(gt_depth)
+    grid6 = tv_make_grid([ref_img_01, sample_rgb_01_clip, color, torch.zeros_like(sample_rgb_01), gt_rgb, gt_color], nrow=3, pad_value=1.)
+    out["grid_gt"] = R_u.clip_image(grid6, scale=False, move=False, is_uint8=True).permute(1, 2, 0).numpy()
+    np.savez_compressed(os.path.join(OUT, "outputs.npz"), **out)
+
+
+def gen_configs():
+    """The reference's shipped YAML configurations parsed by ITS loader (osmosis_utils/utils.py:357-360, yaml.FullLoader), as JSON:
+    pins tests/baseline_configs.py (hand transcriptions) and sampling.load_config (values only; no YAML text is stored)."""
+    import json
+    from osmosis_utils import utils as R_u
+    cfgs = {}
+    for f in sorted(os.listdir("/root/reference/configs")):
+        if f.endswith(".yaml"):
+            cfgs[f] = R_u.load_yaml(os.path.join("/root/reference/configs", f))
+    with open(os.path.join(OUT, "configs.json"), "w") as fh:
+        json.dump(cfgs, fh, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                 # regenerate selected sections only: gen_golden.py postprocess prior ...
@@ -557,6 +628,8 @@ if __name__ == "__main__":
     gen_loops()
     gen_prior()
     gen_postprocess()
+    gen_outputs()
+    gen_configs()
     gen_ps()
     gen_fp16()
     gen_full_unet()

@@ -664,8 +664,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
       const int po = dy * p.W + dx;
       const bool live = ok && y0 + oy + dy < p.H;
       pre_r[i] = pre_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rbase && live) pre_r[i] = osm::ld4(rbase + po * (int)p.ldr + n);
-      if (!partial && p.accumulate && live) pre_a[i] = osm::ld4(obase + po * (int)p.ldc + n);
+      if constexpr (MODE != 0) {      // (a split-K partial round adds nothing: no loads -- ADVICE r04)
+        if (rbase && live) pre_r[i] = osm::ld4(rbase + po * (int)p.ldr + n);
+        if (p.accumulate && live) pre_a[i] = osm::ld4(obase + po * (int)p.ldc + n);
+      }
       if constexpr (MODE == 3) {
         pre_x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sxbase && live) pre_x[i] = osm::ld4(sxbase + po * (int)p.ld_sx + n);

@@ -503,7 +503,12 @@ bool halo_enabled() {
 }
 
 // Winograd F(2x2, 3x3) path (conv3_wino.inc.h): 3x3, split-bf16 image in the Winograd domain, fp32 activations
-bool wino_shape_ok(int H, int W, int K, int N) { return H >= 16 && W >= 16 && K >= 16 && N >= 64 && N % 32 == 0; }
+// (an image is addressed by 32-bit byte offsets: H * W * ldx * sizeof(x) < 4 GiB is checked at launch; the shape query below
+// refuses images whose DENSE size already reaches 1 GiB, which leaves room for row strides up to 4 Cin -- callers with wider
+// strides compare H * W * ldx * sizeof(x) themselves, as engine._conv does, and take the direct kernel instead)
+bool wino_shape_ok(int H, int W, int K, int N) {
+  return H >= 16 && W >= 16 && K >= 16 && N >= 64 && N % 32 == 0 && (long long)H * W * K * 4 < (1LL << 30);
+}
 
 int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bool wino = false) {
   p.mtiles = (p.M + BM - 1) / BM;

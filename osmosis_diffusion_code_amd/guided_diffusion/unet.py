@@ -22,6 +22,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
+from .. import torch_ops
 from ..engine import UNetEngine, UNetWeights, activation_bytes_per_image
 
 NUM_CLASSES = 1000
@@ -251,31 +252,21 @@ class UNetModel(nn.Module):
             raise ValueError(f"expected x [B,{self.in_channels},H,W], got {tuple(x.shape)}")
         B, _, H, W = x.shape
         eng = self.engine(B, H, W)
-        return _UNetFunction.apply(x, timesteps, eng)
-
-
-class _UNetFunction(torch.autograd.Function):
-    """x -> UNet(x, t); backward = data gradient only (kernels: engine.backward)."""
-
-    @staticmethod
-    def forward(ctx, x, timesteps, eng):
-        out = eng.forward(x, timesteps, need_grad=x.requires_grad)
-        ctx.eng = eng
-        ctx.ticket = eng.ticket
-        return out.clone()
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        eng = ctx.eng
-        if eng.ticket != ctx.ticket:
-            raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
-        return eng.backward(grad_out.contiguous()).clone(), None, None
+        # the dispatcher-visible operator (torch_ops.py: schema, fake-tensor and autograd registrations; C ABI underneath)
+        out, _ticket = torch.ops.osmosis.unet_fwd(x, timesteps, torch_ops.engine_handle(eng))
+        return out
 
 
 def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,
                  use_checkpoint=False, attention_resolutions="16", num_heads=1, num_head_channels=-1,
                  num_heads_upsample=-1, use_scale_shift_norm=False, dropout=0, resblock_updown=False,
-                 use_fp16=False, use_new_attention_order=False, model_path="", pretrain_model=""):
+                 use_fp16=False, use_new_attention_order=False, model_path="", pretrain_model="", strict_checkpoint=None):
+    """unet.py:27-99 of the reference, same argument digestion.  `strict_checkpoint` (default: the OSM_STRICT_CHECKPOINT
+    environment variable, else False): when true a checkpoint that cannot be read or does not fit the architecture RAISES; when
+    false the reference's behaviour is kept literally (unet.py:94-97: print the exception, continue with random weights) --
+    which turns a mistyped `model_path` into a fast sampler of garbage, so production launchers should set it."""
+    if strict_checkpoint is None:
+        strict_checkpoint = os.environ.get("OSM_STRICT_CHECKPOINT", "0").lower() not in ("", "0", "false", "no")
     if channel_mult == "":
         table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
         if image_size not in table:
@@ -308,6 +299,9 @@ def create_model(image_size, num_channels, num_res_blocks, channel_mult="", lear
                       use_new_attention_order=use_new_attention_order)
     try:
         model.load_state_dict(torch.load(model_path, map_location="cpu"))
-    except Exception as e:  # same behaviour as the reference: warn and continue with random init
-        print(f"Got exception: {e} / Randomly initialize")
+    except Exception as e:
+        if strict_checkpoint:
+            raise RuntimeError(f"create_model: checkpoint {model_path!r} could not be loaded into the {pretrain_model or 'rgb'} "
+                               f"UNet ({type(e).__name__}: {e}); strict_checkpoint / OSM_STRICT_CHECKPOINT is set") from e
+        print(f"Got exception: {e} / Randomly initialize")  # same behaviour as the reference: warn and continue with random init
     return model

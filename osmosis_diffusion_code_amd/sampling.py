@@ -7,8 +7,13 @@
 
 `cfg` is the parsed YAML of the reference (`configs/osmosis_sample_config.yaml`): keys `measurement`
 {operator, noise}, `conditioning` {method, params}, `diffusion`, `sample_pattern`, `aux_loss`, `unet_model`,
-`manual_seed`, `degamma_input`, `rgb_guidance`.  File output (PNG grids, logger) stays with the caller.
+`manual_seed`, `degamma_input`, `rgb_guidance`.
+
+    load_config(path)                       the YAML file -> that dictionary (osmosis_utils/utils.py:357-360,466-476)
+    save_outputs(post, out_dir, name, ...)  the files the reference writes per image (osmosis_sampling.py:319-353)
 """
+import os
+
 import numpy as np
 import torch
 
@@ -78,6 +83,95 @@ def postprocess(out_xstart, variable_dict, ref_img, operator_cfg, loss=None):
         loss=None if loss is None else np.asarray(loss),
     )
     return out
+
+
+def load_config(path):
+    """The reference's `arguments_from_file` (osmosis_utils/utils.py:466-476 -> load_yaml :357-360): the YAML file as a plain
+    dictionary (the reference copies the same keys onto an argparse.Namespace; `restore_image(s)` reads them by key).
+    yaml.FullLoader like the reference, so `1e-5` stays the STRING the operators parse themselves and `32, 16, 8` a string."""
+    import yaml
+    with open(path) as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    if not isinstance(cfg, dict):
+        raise ValueError(f"{path}: expected a mapping at the top level of the configuration file")
+    return cfg
+
+
+def _to_pil_u8(t):
+    """torchvision.transforms.functional.to_pil_image on a float tensor [C,H,W] (0.14.1, functional.py:257-340 as the
+    reference uses it at osmosis_sampling.py:321-337): `pic.mul(255).byte()` -- TRUNCATION, not rounding -- then HWC;
+    one channel -> mode 'L', three -> 'RGB'."""
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3 or t.shape[0] not in (1, 3):
+        raise ValueError(f"pic should be 2/3 dimensional with 1 or 3 channels. Got {tuple(t.shape)}")
+    if t.is_floating_point():
+        t = t.mul(255).byte()
+    arr = t.permute(1, 2, 0).contiguous().numpy()
+    return arr[:, :, 0] if arr.shape[2] == 1 else arr
+
+
+def make_grid(tensors, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid (0.14.1) for a list of equally sized [C,H,W] tensors, normalize=False: the list is stacked
+    (dtype promotion as torch.stack does it: the viridis depth is float64), single-channel images are repeated to three, tile k
+    sits at row k // xmaps, column k % xmaps of a (pad_value)-filled canvas with `padding` pixels before every tile and after
+    the last one."""
+    dt = tensors[0].dtype
+    for t in tensors[1:]:
+        dt = torch.promote_types(dt, t.dtype)
+    x = torch.stack([t.to(dt) for t in tensors], 0)
+    if x.shape[1] == 1:
+        x = x.repeat(1, 3, 1, 1)
+    if x.shape[0] == 1:              # make_grid returns the single image itself (no border)
+        return x[0]
+    n = x.shape[0]
+    xmaps = min(nrow, n)
+    ymaps = (n + xmaps - 1) // xmaps
+    h, w = x.shape[2] + padding, x.shape[3] + padding
+    grid = x.new_full((x.shape[1], h * ymaps + padding, w * xmaps + padding), pad_value)
+    for k in range(n):
+        r, c = divmod(k, xmaps)
+        grid[:, r * h + padding: r * h + padding + x.shape[2], c * w + padding: c * w + padding + x.shape[3]] = x[k]
+    return grid
+
+
+def output_images(post, ref_img, gt_rgb_01=None, gt_depth_01=None):
+    """The uint8 arrays of the five images the reference writes for one restored image (osmosis_sampling.py:319-353):
+    `input` = the reference image in [0,1], `rgb` = the clipped restoration, `depth_color` = viridis of the percentile-normalised
+    depth, `depth_raw` = the min-max-normalised depth (one channel), `grid` = make_grid([input, rgb, depth_color] (+ [zeros,
+    gt rgb, gt depth colour] when a ground truth exists: :341-344), nrow=3, pad_value=1.) through the reference's
+    clip_image(scale=False, move=False, is_uint8=True) (clamp, truncate)."""
+    ref01 = 0.5 * (ref_img.detach().cpu()[0] + 1)
+    col = depth_color(post)
+    tiles = [ref01, post["rgb_01_clip"], col]
+    if gt_rgb_01 is not None:
+        tiles += [torch.zeros_like(post["rgb_01"]), gt_rgb_01, utilso.depth_tensor_to_color_image(gt_depth_01)]
+    grid = make_grid(tiles, nrow=3, pad_value=1.0)
+    grid = (grid * 255).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    return {"input": _to_pil_u8(ref01), "rgb": _to_pil_u8(post["rgb_01_clip"]), "depth_color": _to_pil_u8(col),
+            "depth_raw": _to_pil_u8(post["depth_mm"]), "grid": grid}
+
+
+def save_outputs(post, ref_img, out_dir, name, global_ii=0, save_singles=True, save_grids=True, gt_rgb_01=None,
+                 gt_depth_01=None):
+    """Writes what the reference writes for one image (osmosis_sampling.py:84-104 directory layout, :319-353 files):
+    `<out_dir>/single_images/{input,rgb,depth_color,depth_raw}/<name>.png` and `<out_dir>/grid_results/<name>_g<ii>_grid.png`.
+    Returns {kind: path}.  (`<name>_process.png` is written by the sampler itself when `record` is on.)"""
+    from PIL import Image
+    imgs = output_images(post, ref_img, gt_rgb_01, gt_depth_01)
+    paths = {}
+    if save_singles:
+        for kind in ("input", "rgb", "depth_color", "depth_raw"):
+            d = os.path.join(out_dir, "single_images", kind)
+            os.makedirs(d, exist_ok=True)
+            paths[kind] = os.path.join(d, f"{name}.png")
+            Image.fromarray(imgs[kind], mode="L" if imgs[kind].ndim == 2 else "RGB").save(paths[kind])
+    if save_grids:
+        d = os.path.join(out_dir, "grid_results")
+        os.makedirs(d, exist_ok=True)
+        paths["grid"] = os.path.join(d, f"{name}_g{global_ii}_grid.png")
+        Image.fromarray(imgs["grid"], mode="RGB").save(paths["grid"])
+    return paths
 
 
 def depth_color(post):

@@ -52,6 +52,10 @@ def gather_per_image(values: Sequence[float], n_items: int, device=None) -> List
 #   "rccl"  -- torch.distributed backend "nccl" (= RCCL on ROCm), device tensors, one rank per GPU over xGMI;
 #   "gloo"  -- torch.distributed backend "gloo", host tensors over TCP on 127.0.0.1;
 #   "files" -- one small JSON file per rank and round in a node-local directory (the contract is ONE node), polled.
+# The directory may be REUSED (OSM_SYNC_DIR, or a (run id, port, parent pid) collision): rank 0 empties it and then publishes a
+# job token {its pid, that process's kernel start time, a random nonce}; a peer accepts a token only while that very process
+# is alive (one node: /proc), every payload carries the nonce and a file with another nonce -- a previous job's -- is ignored
+# (a stale vote_* / g<N> file was accepted as this run's).  close() removes what the job wrote.
 # Agreement on the transport itself goes through that directory, so every rank takes the same branch even when the failure
 # is one-sided.  A transport whose probe raises OR does not finish in `probe_timeout_s` (a hang) counts as failed; a
 # hung RCCL probe thread is abandoned (daemon) and `device_sync_safe` turns False: callers then synchronise their own
@@ -66,6 +70,7 @@ class RankSync:
         self.transport, self.failures = "none", {}
         self.device_sync_safe = True
         self._round = 0
+        self._mine = []             # files this rank wrote (removed by close())
         self._group = None
         self._dist_up = False
         if self.world == 1:
@@ -77,6 +82,7 @@ class RankSync:
         os.makedirs(sync_dir, exist_ok=True)
         self.dir = sync_dir
         self._timeout = float(probe_timeout_s)
+        self._nonce = self._agree_on_nonce()
         force_fail = set(force_fail) | set(filter(None, os.environ.get("OSM_SYNC_FORCE_FAIL", "").split(",")))
         for name in self.ORDER:
             if name == "files":
@@ -91,6 +97,55 @@ class RankSync:
                 break
             if ok:
                 self.failures[name] = "failed on rank(s) %s" % [r for r, v in enumerate(votes) if v[0] != 1.0]
+
+    @property
+    def round(self) -> int:
+        """Rounds (barriers + gathers) this rank has entered; equal on all ranks between two primitives."""
+        return self._round
+
+    # -- job token ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _proc_start(pid: int):
+        """Kernel start time (clock ticks since boot, /proc/<pid>/stat field 22) of a live process, None if it is gone."""
+        try:
+            with open("/proc/%d/stat" % pid) as f:
+                return int(f.read().rsplit(")", 1)[1].split()[19])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _agree_on_nonce(self) -> str:
+        import json
+        import os
+        import time
+        import uuid
+        path = os.path.join(self.dir, "token_r0.json")
+        if self.rank == 0:
+            for f in os.listdir(self.dir):          # whatever an earlier job left behind (its ranks are gone: see below)
+                try:
+                    os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+            tok = {"pid": os.getpid(), "start": self._proc_start(os.getpid()), "born": time.time(), "nonce": uuid.uuid4().hex}
+            with open(path + ".tmp", "w") as f:
+                json.dump(tok, f)
+            os.replace(path + ".tmp", path)
+            return tok["nonce"]
+        t0, limit = time.monotonic(), max(600.0, 4 * self._timeout)
+        my_born = time.time()
+        while True:
+            try:
+                with open(path) as f:
+                    tok = json.load(f)
+                # this job's token is the one whose writer is still running (pid + kernel start time identify a process on
+                # the node); without /proc: a token not older than this process by more than two minutes
+                alive = self._proc_start(int(tok["pid"]))
+                if (alive is not None and alive == tok["start"]) or (tok["start"] is None and tok["born"] > my_born - 120.0):
+                    return str(tok["nonce"])
+            except (OSError, ValueError, KeyError, TypeError):
+                pass
+            if time.monotonic() - t0 > limit:
+                raise RuntimeError("RankSync: rank 0 never published a job token in %s" % self.dir)
+            time.sleep(0.001)
 
     # -- probes -------------------------------------------------------------------------------------------------------
     def _run_with_timeout(self, fn):
@@ -160,10 +215,7 @@ class RankSync:
         import json
         import os
         import time
-        path = os.path.join(self.dir, "%s_r%d.json" % (tag, self.rank))
-        with open(path + ".tmp", "w") as f:
-            json.dump([float(v) for v in values], f)
-        os.replace(path + ".tmp", path)            # atomic: a reader sees the whole file or none
+        self._file_post(tag, values)               # atomic: a reader sees the whole file or none
         out, t0 = [None] * self.world, time.monotonic()
         limit = timeout_s if timeout_s is not None else max(600.0, 4 * self._timeout)
         while True:
@@ -171,8 +223,10 @@ class RankSync:
                 if out[r] is None:
                     try:
                         with open(os.path.join(self.dir, "%s_r%d.json" % (tag, r))) as f:
-                            out[r] = json.load(f)
-                    except (FileNotFoundError, ValueError):
+                            rec = json.load(f)
+                        if isinstance(rec, dict) and rec.get("n") == self._nonce:     # another nonce: a previous job's file
+                            out[r] = rec["v"]
+                    except (FileNotFoundError, ValueError, KeyError):
                         pass
             if all(o is not None for o in out):
                 return out
@@ -194,8 +248,9 @@ class RankSync:
         import os
         path = os.path.join(self.dir, "%s_r%d.json" % (tag, self.rank))
         with open(path + ".tmp", "w") as f:
-            json.dump([float(v) for v in values], f)
+            json.dump({"n": self._nonce, "v": [float(v) for v in values]}, f)
         os.replace(path + ".tmp", path)
+        self._mine.append(path)
 
     def all_gather(self, values: Sequence[float]) -> List[List[float]]:
         """Every rank passes the same number of floats; returns the per-rank lists in rank order."""
@@ -250,7 +305,16 @@ class RankSync:
             torch.cuda.current_stream(self.device).synchronize()
 
     def close(self) -> None:
-        if self.world == 1 or not self._dist_up:
+        if self.world == 1:
+            return
+        import os
+        for path in self._mine:         # (peers have read a round's files before they could enter the next one)
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        self._mine = []
+        if not self._dist_up:
             return
         import torch.distributed as dist
         try:

@@ -60,7 +60,7 @@ HAZE = dict(
     aux_loss=dict(aux_loss={"avrg_loss": 0.5, "val_loss": 20}),
     measurement=dict(
         operator=dict(name="haze_physical", optimizer="sgd", depth_type="gamma", value="1.4,1.4,1",
-                      phi_ab="1.0", phi_ab_eta="1e-5", phi_ab_learn_flag=True,
+                      phi_ab=1.0, phi_ab_eta="1e-5", phi_ab_learn_flag=True,
                       phi_inf="0.14, 0.29, 0.49", phi_inf_eta="1e-5", phi_inf_learn_flag=True),
         noise=dict(name="clean")))
 

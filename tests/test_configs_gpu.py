@@ -215,9 +215,10 @@ def test_full_size_guided_step_vs_oracle(full_model):
         e_g = float((trace[0]["grad"].cpu() - r_grad).abs().max())
         print(f"full-size guided step vs oracle: x_(t-1) {e_img:.2e}  pred_xstart {e_x0:.2e}  "
               f"grad {e_g:.2e} (max {gmax:.2e})  loss {float(loss[0]):.5f} vs {float(np.asarray(r_loss).ravel()[0]):.5f}")
-        assert e_img < 1e-3 and e_x0 < 1e-3
-        assert e_g < 2e-4 * gmax + 1e-9
-        assert abs(float(loss[0]) - float(np.asarray(r_loss).ravel()[0])) < 1e-3 * abs(float(loss[0]))
+        # bars = ~5x what is measured on MI355X at this low index (x_(t-1) 2.4e-7, pred_xstart 1.2e-7, gradient 2.7e-6 of its maximum)
+        assert e_img < 1.5e-6 and e_x0 < 1e-6
+        assert e_g < 1.5e-5 * gmax + 1e-9
+        assert abs(float(loss[0]) - float(np.asarray(r_loss).ravel()[0])) < 1e-5 * abs(float(loss[0]))
         for k, v in r_vars.items():
             assert torch.allclose(variables[k].cpu().reshape(-1), v.detach().reshape(-1), atol=5e-6), k
     finally:

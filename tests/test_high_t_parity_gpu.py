@@ -189,13 +189,19 @@ def test_teacher_forced_guided_step_at_high_t(setup):
             got = hip_step(model, cfg, x_t, y, idx, noise)
             row = compare(mode, idx, factor, ref, got, rows)
             row["x_t_scale"] = sc
-            assert row["pred_xstart_err"] < TOL, row
-            if idx == top:      # loss ~1e16 there: see `x_prev_err_determined` in compare()
-                assert row["x_prev_err_determined"] < TOL and row["flipped_pixels"] <= row["undetermined_pixels"], row
-            else:
-                assert row["x_prev_err"] < TOL, row
-            assert row["grad_err"] < 2e-4 * row["grad_max"] + 1e-9, row
-            assert abs(row["loss"] - row["loss_ref"]) < 1e-3 * abs(row["loss_ref"]), row
+            # Bars = <= 5x what this test measures on MI355X (profiles/r04_high_t_parity.json, re-measured in round 5; VERDICT r04
+            # weak 1: the old bars -- 1e-3 everywhere -- let a 10x accuracy regression pass).  The network's error (eps: 2-7e-6 in
+            # every arithmetic) enters pred_xstart times sqrt(1 / alphabar - 1): measured 7.1e-6 / 1.7e-5 / 1.9e-4 at idx 299 /
+            # 500 / 800 (exact-fp32 MFMA, the least accurate of the three)
+            assert row["pred_xstart_err"] < 2.5e-5 * max(1.0, factor), row
+            if idx == top:      # loss ~1e16 there: see `x_prev_err_determined` in compare()   (measured: 2.1e-7, 3-5 pixels flip)
+                assert row["x_prev_err_determined"] < 1.2e-6 and row["flipped_pixels"] <= 25, row
+                assert row["flipped_pixels"] <= row["undetermined_pixels"], row
+            else:               # measured 1.7e-5 (idx 299), 1.9e-4 (idx 500: the +-clip amplifies a 1e-5 gradient error)
+                assert row["x_prev_err"] < (8e-5 if idx == 299 else TOL), row
+            # gradient vs the oracle's, relative to its maximum: measured 4.6e-6 / 1.2e-5 / 1.1e-4
+            assert row["grad_err"] < {299: 2.5e-5, 500: 6e-5}.get(idx, 2e-4) * row["grad_max"] + 1e-9, row
+            assert abs(row["loss"] - row["loss_ref"]) < 5e-5 * abs(row["loss_ref"]), row
             for k, v in ref["variables"].items():
                 assert torch.allclose(got["variables"][k].reshape(-1), v.reshape(-1), atol=5e-6), (k, mode, idx)
 
@@ -210,8 +216,10 @@ def test_teacher_forced_guided_step_at_high_t(setup):
         got = hip_step(model, cfg, x_t, y, idx, noise, guided=False)
         row = compare(mode, idx, factor, ref, got, rows, guided=False)
         # pred_xstart is O(100) here: 1e-3 absolute is 1e-5 of its scale; the fp32 oracle itself is no better than that
-        assert row["pred_xstart_err"] < max(TOL, 2e-5 * row["x0_scale"]), row
-        assert row["x_prev_err"] < TOL, row
+        # measured 6.6e-4 (exact-fp32 MFMA) / 3.4e-4 (bf16x6) / 2.9e-4 (f16x3) of a pred_xstart that reaches 758: north_star's 1e-3
+        # holds at the most amplified index of the chain; x_(t-1) itself: 4.8e-7
+        assert row["pred_xstart_err"] < TOL, row
+        assert row["x_prev_err"] < 2.5e-6, row
     model.conv_mode = "f16x3"
 
     out = os.environ.get("OSM_HIGH_T_TABLE")
@@ -268,9 +276,10 @@ def test_full_size_guided_steps_vs_the_real_reference(setup, fname, cfg_name):
         print(f"{mode}: full-size guided steps vs the real reference: x_t {e['x_in']:.2e}  pred_xstart {e['x0']:.2e}  grad {e['grad']:.2e} "
               f"(max {float(g['trace.grad_max'].max()):.1f})  final x {e_fin:.2e}  final pred_xstart {e_x0f:.2e}  loss {float(loss[0]):.4f} vs "
               f"{float(g['final_loss'][0]):.4f}")
-        assert e["x_in"] < TOL and e["x0"] < TOL and e_fin < TOL and e_x0f < TOL
-        assert e["grad"] < 2e-4 * float(g["trace.grad_max"].max())
-        assert abs(float(loss[0]) - float(g["final_loss"][0])) < 1e-4 * abs(float(g["final_loss"][0]))
+        # measured vs the REAL reference: 2.2e-5 (f32) / 6e-6 (bf16x6) / 5.3e-6 (f16x3); gradient 1.5e-6 of its maximum; loss 3e-6
+        assert e["x_in"] < 1e-4 and e["x0"] < 1e-4 and e_fin < 1e-4 and e_x0f < 1e-4
+        assert e["grad"] < 8e-6 * float(g["trace.grad_max"].max())
+        assert abs(float(loss[0]) - float(g["final_loss"][0])) < 1.5e-5 * abs(float(g["final_loss"][0]))
         for k in variables:
             assert np.allclose(variables[k].cpu().numpy().ravel(), g["final." + k].ravel(), atol=5e-6), (k, mode)
     model.conv_mode = "f16x3"

@@ -208,7 +208,7 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
 
 
-def test_create_model_loads_a_checkpoint_file_and_survives_a_bad_path(tmp_path, capsys):
+def test_create_model_loads_a_checkpoint_file_and_survives_a_bad_path(tmp_path, capsys, monkeypatch):
     """N4 / unet.py:86-97: `model_path` is th.load-ed into the module (reference keys, OIHW shapes); any failure is
     caught, reported as 'Got exception: ... / Randomly initialize', and the model is still returned."""
     from oracle import unet_ref as U
@@ -226,6 +226,19 @@ def test_create_model_loads_a_checkpoint_file_and_survives_a_bad_path(tmp_path, 
     m2 = unet.create_model(model_path=str(tmp_path / "missing.pt"), **kw)
     assert "Got exception" in capsys.readouterr().out          # message printed, nothing raised
     assert set(m2.state_dict()) == set(sd)
+    # strict mode (SURVEY section 5 / VERDICT r04 item 8): the same failures RAISE -- a missing file, and a file of another architecture
+    with pytest.raises(RuntimeError, match="could not be loaded"):
+        unet.create_model(model_path=str(tmp_path / "missing.pt"), strict_checkpoint=True, **kw)
+    wrong = {k: v for k, v in sd.items() if not k.startswith("out.")}
+    torch.save(wrong, tmp_path / "wrong.pt")
+    with pytest.raises(RuntimeError, match="could not be loaded"):
+        unet.create_model(model_path=str(tmp_path / "wrong.pt"), strict_checkpoint=True, **kw)
+    monkeypatch.setenv("OSM_STRICT_CHECKPOINT", "1")
+    with pytest.raises(RuntimeError):
+        unet.create_model(model_path=str(tmp_path / "missing.pt"), **kw)
+    unet.create_model(model_path=str(path), **kw)                # a good checkpoint loads in strict mode
+    monkeypatch.setenv("OSM_STRICT_CHECKPOINT", "0")
+    unet.create_model(model_path=str(tmp_path / "missing.pt"), **kw)
 
 
 def test_c_abi_header_is_plain_c_and_links_from_c(tmp_path):

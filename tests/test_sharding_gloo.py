@@ -130,3 +130,43 @@ def test_rank_sync_survives_a_one_sided_failure_after_selection(tmp_path):
     for rank, transport, rows, failures in res:
         assert rows == [[0.0, 100.0], [1.0, 101.0]]
         assert transport == "files" and "gloo" in failures
+
+
+def _stale_worker(rank, world, port, sync_dir, base, keep_files, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from osmosis_diffusion_code_amd.sharding import RankSync
+    if rank == 1:
+        import time
+        time.sleep(1.0)      # rank 1 is late: with stale files in the directory it would have found "its" round already answered
+    s = RankSync(rank, world, device=None, sync_dir=sync_dir, probe_timeout_s=30, force_fail=("rccl", "gloo"))
+    rows = s.all_gather([base + rank])
+    s.barrier()
+    q.put((rank, s.transport, rows, s.round))
+    if not keep_files:
+        s.close()
+
+
+def test_rank_sync_ignores_a_previous_jobs_files(tmp_path):
+    """two jobs in ONE sync directory (OSM_SYNC_DIR reuse): the second job must not read the first job's
+    vote_* / g<N> files.  Job 1 leaves its files behind (no close()); job 2 gathers ITS values, whichever rank is late."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    for base, keep in ((100.0, True), (200.0, False)):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_stale_worker, args=(r, world, port, str(tmp_path), base, keep, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, transport, rows, rounds in res:
+            assert transport == "files" and rounds == 2
+            assert rows == [[base], [base + 1.0]], (base, rows)
+        left = sorted(os.listdir(tmp_path))
+        if keep:
+            assert any(f.startswith("g1_") for f in left)           # the stale files job 2 will have to ignore
+        else:
+            assert left == ["token_r0.json"], left                     # close() removed this job's round files

@@ -99,8 +99,9 @@ def test_full_size_unet_256_vs_oracle(create_model):
         ed = float((dxd.cpu() - dxr).abs().max())
         print(mode, "full-size max-abs err: y", ey, "scale", float(yr.abs().max()), "dx", ed, "scale",
               float(dxr.abs().max()))
-        assert ey < 1e-4 * max(1.0, float(yr.abs().max()))
-        assert ed < 1e-4 * max(1.0, float(dxr.abs().max()))
+        # measured (MI355X): y 4.3e-6 / 2.4e-6 / 2.1e-6, dx 1.44e-5 / 7.0e-6 / 7.0e-6 of 3.9 (f32 / bf16x6 / f16x3): bars = 5x the worst
+        assert ey < 1.7e-5 * max(1.0, float(yr.abs().max()))
+        assert ed < 1.9e-5 * max(1.0, float(dxr.abs().max()))
 
 
 def test_full_size_unet_256_vs_reference_golden(create_model):
@@ -130,8 +131,9 @@ def test_full_size_unet_256_vs_reference_golden(create_model):
             l2y = float(yd.detach().double().pow(2).sum().sqrt())
             print(f"{mode} t={t}: vs the real reference: y {ey:.2e} (max {float(g[tag + '.y_max']):.2f})  dx {ed:.2e} "
                   f"(max {float(g[tag + '.dx_max']):.2f})  |y|_2 {l2y:.4f} vs {float(g[tag + '.y_l2']):.4f}")
-            assert ey < 1e-4 * max(1.0, float(g[tag + ".y_max"])) and ed < 1e-4 * max(1.0, float(g[tag + ".dx_max"]))
-            assert abs(l2y - float(g[tag + ".y_l2"])) < 1e-5 * float(g[tag + ".y_l2"])
+            # measured vs the real reference: y <= 4.2e-6 (max 1.3), dx <= 1.25e-5 (max 3.9), f32 the worst: bars = 5x that
+            assert ey < 1.6e-5 * max(1.0, float(g[tag + ".y_max"])) and ed < 1.6e-5 * max(1.0, float(g[tag + ".dx_max"]))
+            assert abs(l2y - float(g[tag + ".y_l2"])) < 5e-6 * float(g[tag + ".y_l2"])
 
 
 @pytest.mark.parametrize("conv_mode", ["f16x3", "bf16x6"])
