@@ -76,7 +76,7 @@ typedef struct osm_conv_desc {
   const float* stat_x;
   long long ld_sx;
   const float* stat_table;
-  const float* x_maxabs; /* wfmt 4 only ("f16x3" images): [B][OSM_MAXABS_PARTS] partial max |x| of the input from osm_maxabs --
+  const float* x_maxabs; /* wfmt 4 only ("f16x3" images): 16-byte aligned [B][OSM_MAXABS_PARTS] partial max |x| of the input from osm_maxabs --
                           the kernel scales x into the fp16 range by a power of two and undoes it in its epilogue */
 } osm_conv_desc;
 int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream);

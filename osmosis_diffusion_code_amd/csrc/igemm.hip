@@ -525,8 +525,8 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
   if (wino) {
     if (!(taps == 9 && wfmt >= 1 && wfmt <= 4 && wino_shape_ok(p.H, p.W, p.K, p.N)))
       return osm::fail(OSM_ERR_UNSUPPORTED, "Winograd weight image: 3x3, wfmt 1 / 2 / 3 / 4, H, W >= 16, Cin >= 16, Cout >= 64 and a multiple of 32 only");
-    if (wfmt == 4 && !p.xmax)
-      return osm::fail(OSM_ERR_INVALID, "the f16x3 Winograd image (wfmt 4) needs x_maxabs (osm_maxabs of the input)");
+    if (wfmt == 4 && !(p.xmax && osm::aligned16(p.xmax)))
+      return osm::fail(OSM_ERR_INVALID, "the f16x3 Winograd image (wfmt 4) needs x_maxabs (osm_maxabs of the input), 16-byte aligned");
     if (!(p.ldc % 4 == 0 && osm::aligned_act4(p.C) && (!p.res || (p.ldr % 4 == 0 && osm::aligned_act4(p.res))) &&
           (!p.bias || osm::aligned16(p.bias)) && (p.splitk <= 1 || osm::aligned16(p.ws))))
       return osm::fail(OSM_ERR_UNSUPPORTED, "the Winograd kernel stores 4-element vectors: ldy, ldr multiples of 4, aligned y / res / bias");
@@ -633,7 +633,8 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
 #else
     if (wfmt == 4) {     // f16x3 image of a 1x1 layer: two half planes behind a scale word, the input's range from the caller
       if (taps != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 image (wfmt 4 without OSM_WFMT_WINOGRAD) is for 1x1 layers");
-      if (!p.xmax) return osm::fail(OSM_ERR_INVALID, "the f16x3 image (wfmt 4) needs x_maxabs (osm_maxabs of the input)");
+      if (!(p.xmax && osm::aligned16(p.xmax)))
+        return osm::fail(OSM_ERR_INVALID, "the f16x3 image (wfmt 4) needs x_maxabs (osm_maxabs of the input), 16-byte aligned");
       if ((p.H * p.W) % BM != 0)
         return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 kernel needs H * W to be a multiple of %d (one image per tile)", BM);
       p.wscale = reinterpret_cast<const float*>(Bp + 2LL * p.ksteps * p.nt32 * 512);

@@ -1013,6 +1013,8 @@ class BlockEngine(UNetEngine):
         self.out = torch.zeros(B, cout, *self.hwo, **f32)
         self.d_out = torch.zeros(B, cout, *self.hwo, **f32)
         self.emb = torch.zeros(B, ted, **f32)
+        # (the GroupNorm partial-sum workspace is sized by the LARGEST tensor of the plan: an up block's output)
+        self.gn_part = torch.empty(B * ops.gn_nchunk(max(H * W, self.hwo[0] * self.hwo[1])) * G * 2, **f32)
 
     def _to_nchw(self, m: Mat, dst, C, HW):
         if m.t.dtype != torch.float32:          # fp16-storage family: the sampler side of the boundary is fp32 NCHW

@@ -253,8 +253,7 @@ class UNetModel(nn.Module):
         B, _, H, W = x.shape
         eng = self.engine(B, H, W)
         # the dispatcher-visible operator (torch_ops.py: schema, fake-tensor and autograd registrations; C ABI underneath)
-        out, _ticket = torch.ops.osmosis.unet_fwd(x, timesteps, torch_ops.engine_handle(eng))
-        return out
+        return torch.ops.osmosis.unet_fwd(x, timesteps, torch_ops.engine_handle(eng))
 
 
 def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,

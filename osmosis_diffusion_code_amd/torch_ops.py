@@ -5,9 +5,9 @@ custom ops"): the UNet forward / input-gradient plans and the guidance-step kern
 enqueues hand-written gfx950 kernels on the current HIP stream; there is no CPU implementation (the operators are
 registered for the "cuda" device type only, which is HIP on ROCm).
 
-    osmosis::unet_fwd(x, t, engine) -> (out, ticket)        UNetModel.forward (reference unet.py:713-742); differentiable
+    osmosis::unet_fwd(x, t, engine) -> out                  UNetModel.forward (reference unet.py:713-742); differentiable
                                                            w.r.t. x (condition_methods.py:188-191 back-propagates through it)
-    osmosis::unet_bwd_data(grad_out, ticket, engine) -> dx  the recorded data-gradient plan of the same engine
+    osmosis::unet_bwd_data(grad_out, out, engine) -> dx     the recorded data-gradient plan of the same engine
     osmosis::posterior(model_out, x, coef) -> (pred_xstart, mean, log_variance)     gaussian_diffusion.py:349-376 +
                                                            posterior_mean_variance.py (epsilon mean, learned-range variance)
     osmosis::posterior_bwd(g, coef) -> d_model_out         d(pred_xstart)/d(model_out)^T g  (the chain rule into the UNet)
@@ -18,9 +18,10 @@ registered for the "cuda" device type only, which is HIP on ROCm).
                                                            (cm.py:141-184), functional (phi is returned, not updated in place)
 
 `engine` is an integer handle (`engine_handle(eng)`) because operator schemas carry tensors and scalars only; the handle
-table holds weak references, so an engine dies with its model.  `ticket` (0-d int64 on the host) names the forward pass whose
-activations the data-gradient pass needs: a later forward on the same engine invalidates it and `unet_bwd_data` raises
-instead of differentiating through overwritten activations."""
+table holds weak references, so an engine dies with its model.  The forward pass whose activations the data-gradient pass
+needs is named by the tensor that pass returned (`out`): a later forward on the same engine returns another tensor, and
+`unet_bwd_data` then raises instead of differentiating through overwritten activations.  (Outputs are a function of the
+inputs alone -- no counters among them -- so that fake-tensor tracing and `torch.library.opcheck` see a pure operator.)"""
 import weakref
 from typing import List, Tuple
 
@@ -47,45 +48,46 @@ def _engine(handle: int):
 
 # ----------------------------------------------------------------------------------------------------------------- UNet
 @torch.library.custom_op("osmosis::unet_fwd", mutates_args=(), device_types="cuda")
-def unet_fwd(x: torch.Tensor, t: torch.Tensor, engine: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def unet_fwd(x: torch.Tensor, t: torch.Tensor, engine: int) -> torch.Tensor:
     eng = _engine(engine)
     if tuple(x.shape) != tuple(eng.x_in.shape):
         raise OsmosisHipError(f"osmosis::unet_fwd: engine is planned for x {tuple(eng.x_in.shape)}, got {tuple(x.shape)}")
     out = eng.forward(x, t, need_grad=True).clone()
-    return out, torch.tensor(eng.ticket, dtype=torch.int64)
+    # the pass whose activations the engine now holds is named by the tensor it returned (its storage is kept alive by
+    # autograd for as long as a backward through it is possible, so the address cannot be recycled meanwhile)
+    eng.last_out_ptr = out.data_ptr()
+    return out
 
 
 @unet_fwd.register_fake
 def _unet_fwd_fake(x, t, engine):
     eng = _engine(engine)
-    return x.new_empty((x.shape[0], eng.cout, x.shape[2], x.shape[3])), torch.empty((), dtype=torch.int64, device="cpu")
+    return x.new_empty((x.shape[0], eng.cout, x.shape[2], x.shape[3]))
 
 
 @torch.library.custom_op("osmosis::unet_bwd_data", mutates_args=(), device_types="cuda")
-def unet_bwd_data(grad_out: torch.Tensor, ticket: torch.Tensor, engine: int) -> torch.Tensor:
+def unet_bwd_data(grad_out: torch.Tensor, out: torch.Tensor, engine: int) -> torch.Tensor:
+    """`out`: the tensor osmosis::unet_fwd returned for the pass to differentiate (identifies the pass; not read)."""
     eng = _engine(engine)
-    if int(ticket) != eng.ticket:
+    if out.data_ptr() != getattr(eng, "last_out_ptr", None):
         raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
     return eng.backward(grad_out.contiguous()).clone()
 
 
 @unet_bwd_data.register_fake
-def _unet_bwd_fake(grad_out, ticket, engine):
+def _unet_bwd_fake(grad_out, out, engine):
     eng = _engine(engine)
     return grad_out.new_empty((grad_out.shape[0], eng.cin, grad_out.shape[2], grad_out.shape[3]))
 
 
 def _unet_setup(ctx, inputs, output):
     ctx.engine = inputs[2]
-    ctx.save_for_backward(output[1])
-    ctx.set_materialize_grads(False)
+    ctx.save_for_backward(output)
 
 
-def _unet_backward(ctx, grad_out, _grad_ticket):
-    if grad_out is None:
-        return None, None, None
-    (ticket,) = ctx.saved_tensors
-    return torch.ops.osmosis.unet_bwd_data(grad_out, ticket, ctx.engine), None, None
+def _unet_backward(ctx, grad_out):
+    (out,) = ctx.saved_tensors
+    return torch.ops.osmosis.unet_bwd_data(grad_out, out, ctx.engine), None, None
 
 
 unet_fwd.register_autograd(_unet_backward, setup_context=_unet_setup)

@@ -5,8 +5,8 @@ HIP path (engine.BlockEngine: the launch sequences, kernels and weight images of
 gradient, in the three fp32-class conv arithmetics.  VERDICT r04 weak 2 / next 5 (ii): until round 5 these goldens only reached
 the CPU oracle; a wrong kernel showed up as a whole-UNet mismatch and did not localise.
 
-Tolerances: the blocks are 8 x 8 x 64-96 channels with O(1) activations; measured on MI355X (printed by the test):
-f32 <= 1.5e-6, bf16x6 <= 1.5e-6, f16x3 <= 2e-6 of max|ref| ~ 3-6 -> asserted at 1e-5 * max(1, max|ref|)."""
+Tolerances (max-abs, outputs of magnitude 1-8) = 5x what the tests measure on MI355X (they print it): ResBlocks <= 2.6e-6 in every
+arithmetic -> 1.3e-5; attention blocks 2.4e-7 -> 1.2e-6; GroupNorm32 4.8e-7 -> 2.4e-6; timestep embedding 5.6e-5 -> 2.8e-4."""
 import os
 
 import numpy as np
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "blocks.npz")))
 MODES = ["f32", "bf16x6", "f16x3"]
-TOL = 1e-5
+TOL_RES, TOL_ATTN, TOL_GN, TOL_TEMB = 1.3e-5, 1.2e-6, 2.4e-6, 2.8e-4
 
 
 def _need_gpu():
@@ -29,10 +29,10 @@ def _sd(tag):
     return {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in G.items() if k.startswith(tag + ".sd.")}
 
 
-def _check(tag, what, got, ref):
+def _check(tag, what, got, ref, tol):
     err, scale = float((got.cpu() - ref).abs().max()), float(ref.abs().max())
     print(f"{tag} {what}: max-abs err {err:.2e} (max |ref| {scale:.2f})")
-    assert err < TOL * max(1.0, scale), (tag, what, err, scale)
+    assert err < tol, (tag, what, err, scale)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -49,8 +49,8 @@ def test_res_block_vs_reference(tag, kw, mode):
     eng = BlockEngine(p, x.shape[0], x.shape[2], x.shape[3], torch.device(DEV), conv_mode=mode)
     y = eng.forward(x.to(DEV), emb.to(DEV)).clone()
     dx = eng.backward(dy.to(DEV)).clone()
-    _check(f"{tag}/{mode}", "y", y, y_ref)
-    _check(f"{tag}/{mode}", "dx", dx, dx_ref)
+    _check(f"{tag}/{mode}", "y", y, y_ref, TOL_RES)
+    _check(f"{tag}/{mode}", "dx", dx, dx_ref, TOL_RES)
     y2 = eng.forward(x.to(DEV), emb.to(DEV))          # the recorded plan (hipGraph) replays to the same bits
     assert torch.equal(y2, y) and torch.equal(eng.backward(dy.to(DEV)), dx)
 
@@ -69,8 +69,8 @@ def test_attention_block_vs_reference(tag, new, mode):
     eng = BlockEngine(p, x.shape[0], x.shape[2], x.shape[3], torch.device(DEV), conv_mode=mode)
     y = eng.forward(x.to(DEV)).clone()
     dx = eng.backward(dy.to(DEV)).clone()
-    _check(f"{tag}/{mode}", "y", y, y_ref)
-    _check(f"{tag}/{mode}", "dx", dx, dx_ref)
+    _check(f"{tag}/{mode}", "y", y, y_ref, TOL_ATTN)
+    _check(f"{tag}/{mode}", "dx", dx, dx_ref, TOL_ATTN)
 
 
 def test_group_norm32_vs_reference():
@@ -89,8 +89,8 @@ def test_group_norm32_vs_reference():
     st, gst = torch.empty(B * 32 * 2, device=DEV), torch.empty(B * 32 * 2, device=DEV)
     ops.gn_fwd(xm, ym, B, H * W, 32, part, st, w.contiguous(), b.contiguous(), silu=False)
     ops.gn_bwd(xm, dym, dxm, B, H * W, 32, st, w.contiguous(), b.contiguous(), part, gst, silu=False)
-    _check("gn", "y", back(ym.t), torch.from_numpy(G["gn.y"]))
-    _check("gn", "dx", back(dxm.t), torch.from_numpy(G["gn.dx"]))
+    _check("gn", "y", back(ym.t), torch.from_numpy(G["gn.y"]), TOL_GN)
+    _check("gn", "dx", back(dxm.t), torch.from_numpy(G["gn.dx"]), TOL_GN)
 
 
 def test_timestep_embedding_vs_reference():
@@ -104,4 +104,4 @@ def test_timestep_embedding_vs_reference():
         ref = torch.from_numpy(G[f"temb.out{dim}"])
         err = float((out.cpu() - ref).abs().max())
         print(f"timestep_embedding dim {dim}: max-abs err {err:.2e}")
-        assert err < 2e-4          # arguments up to 999 rad: sin / cos of an fp32 product, the reference's own ulp-level freedom
+        assert err < TOL_TEMB      # arguments up to 999 rad: sin / cos of an fp32 product, the reference's own ulp-level freedom
