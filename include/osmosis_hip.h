@@ -34,11 +34,26 @@ int osm_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* osm_last_error(void);
 
 /* ------------------------------------------------------------------ dense contraction
- * One kernel family (fp32 MFMA v_mfma_f32_32x32x2_f32, 128x128x32 LDS-staged tiles) serves
+ * osm_conv2d_nhwc serves
  *   3x3 conv  (nn.py:22-32 conv_nd; unet.py:264,290,561,694)      ksize=3
  *   1x1 conv  (unet.py:301 skip_connection; unet.py:365,373 qkv/proj_out conv1d)  ksize=1
- *   batched attention GEMMs (unet.py:428,432 einsum)               osm_gemm
- * and, with the dgrad weight packing, their input-gradients (autograd of the above).
+ * and, with the dgrad weight image, their input-gradients (autograd of the above); osm_gemm the batched attention GEMMs of the
+ * unfused attention path (unet.py:428,432 einsum).  Which gfx950 kernel runs is decided by the WEIGHT IMAGE the caller hands
+ * over (`wfmt`) and the shape (osm_conv_kernel_kind reports it):
+ *   wfmt 0                    igemm_f32_kernel: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), 128 x 128 x 32 LDS-staged tiles -- the
+ *                             parity arithmetic ("f32"), 157 TFLOP/s roof;
+ *   wfmt 2 / 3                fp32 operands split exactly into 2 / 3 bf16 planes, 3 / 6 v_mfma_f32_32x32x16_bf16 per product
+ *                             ("bf16x3" / "bf16x6", the latter fp32-class): 3x3 layers by conv3_halo_bf16s_kernel (halo tile in
+ *                             LDS, weight fragments straight from L2; 8 x 8 images by its PH = 8 instance), 1x1 layers and
+ *                             ragged shapes by igemm_bf16s_kernel;
+ *   wfmt 4                    "f16x3": both operands as two IEEE-half planes after power-of-two scaling (~22-bit operands), three
+ *                             v_mfma_f32_32x32x16_f16 per product: 1x1 layers with H * W >= 4096 by igemm_bf16s_kernel<1,2,true>;
+ *   wfmt | OSM_WFMT_WINOGRAD  3x3 layers with H, W >= 16 by conv3_wino8_kernel: Winograd F(2x2, 3x3), 16 x 16 pixels x 64
+ *                             output channels per workgroup, input transform in the registers that feed the MFMA, 16/36 of the
+ *                             direct kernel's multiplies -- with wfmt 4 the default of the sampler (the dominant kernel of a step);
+ *   wfmt 1                    the fp16-storage family (`_h` entry points, end of this file): one fp16 MFMA per product.
+ * Split-K layers write fp32 partials to splitk_ws and are finished by splitk_reduce*_kernel (bias, residual, accumulate,
+ * optional column sums) in the same call.
  */
 typedef struct osm_conv_desc {
   const float* x;      /* [B*H*W][ldx] input, Cin channels used                       */
@@ -196,23 +211,6 @@ int osm_gn_apply(const float* x, long long ldx, float* y, long long ldy, int B, 
 int osm_gn_fwd(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
                float* part, float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, float* maxabs_out, float* maxabs_in, void* stream);
-/* Cooperative single-read GroupNorm (round 4): ONE launch that reads x (and dy) ONCE -- the tensor's row chunks stay in the
- * registers of osm_gn_coop_plan(...) workgroups per image while the 32 per-group partial sums travel through `ws`.
- * Same results contract as osm_gn_fwd / osm_gn_bwd (nn.py:17-19,93-100; unet.py:263,287,327-331).
- *   osm_gn_coop_plan     workgroups per image for this shape (mode 0 = forward, 1 = backward), or 0: not applicable (the grid
- *                        would not be resident at once, C not a multiple of 128 or > 2048, G != 32, image < 512 KB) -- use
- *                        osm_gn_fwd / osm_gn_bwd then.
- *   osm_gn_coop_ws_bytes size of `ws`.  ws must be zero-initialised ONCE and then always be used with the SAME
- *                        (B, HW, C, G, mode): one workspace per call site (its slots carry a launch counter).
- * A workgroup that waits longer than OSM_GN_COOP_TIMEOUT_US (2000) for the others recomputes what is missing itself: the call
- * cannot hang when the device is shared, and its results do not depend on which path a workgroup took. */
-int osm_gn_coop_plan(int B, int HW, int C, int G, int mode);
-long long osm_gn_coop_ws_bytes(int B, int HW, int C, int G, int mode);
-/* run-time knobs (defaults from the environment, OSM_GN_COOP*): "on", "kb", "min_kb", "force", "timeout_us" */
-int osm_gn_coop_set(const char* key, long long value);
-int osm_gn_fwd_coop(const float* x, long long ldx, float* y, long long ldy, int B, int HW, int C, int G, float eps,
-                    float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
-                    float* maxabs_out, float* maxabs_in, void* ws, void* stream);
 /* Statistics only + the per-channel table a convolution applies itself (osm_conv_desc.gn_table):
  * table [B][4][C] = mean | rstd | gamma*(1+scale) | beta*(1+scale)+shift.  `stats` is written as by osm_gn_stats. */
 int osm_gn_prep(const float* x, long long ldx, int B, int HW, int C, int G, float eps, float* part, float* stats,
@@ -235,12 +233,6 @@ int osm_gn_bwd(const float* x, long long ldx, const float* dy, long long lddy, f
                const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
                const float* stats, const float* gamma, const float* beta, const float* film,
                long long ldfilm, int silu, float* part, float* gstats, float* maxabs_out, void* stream);
-/* osm_gn_bwd as ONE cooperative launch (see osm_gn_fwd_coop; plan / workspace with mode 1).  dx must not alias x or dy. */
-int osm_gn_bwd_coop(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
-                    const float* addend, long long ldadd, const float* addend2, long long ldadd2, int B, int HW, int C, int G,
-                    const float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
-                    float* gstats, float* maxabs_out, void* ws, void* stream);
-
 /* ------------------------------------------------------------------ resampling (unet.py:186, 215)
  * y[B][H/2][W/2][C] = scale * sum_{2x2} x   (avg-pool: scale=0.25; upsample-backward: scale=1)
  * y[B][2H][2W][C]   = scale * x[h/2][w/2]   (nearest-upsample: scale=1; avg-pool-backward: 0.25) */
@@ -396,16 +388,6 @@ int osm_gn_bwd_apply_h(const osm_half_t* x, long long ldx, const osm_half_t* dy,
                        const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C, int G,
                        const float* stats, const float* gstats, const float* gamma, const float* beta, const float* film,
                        long long ldfilm, int silu, float* maxabs_out /* must be NULL */, void* stream);
-int osm_gn_coop_plan_h(int B, int HW, int C, int G, int mode);
-int osm_gn_coop_set_h(const char* key, long long value);
-long long osm_gn_coop_ws_bytes_h(int B, int HW, int C, int G, int mode);
-int osm_gn_fwd_coop_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int HW, int C, int G, float eps,
-                      float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm, int silu,
-                      float* maxabs_out, float* maxabs_in, void* ws, void* stream);
-int osm_gn_bwd_coop_h(const osm_half_t* x, long long ldx, const osm_half_t* dy, long long lddy, osm_half_t* dx, long long lddx,
-                      const osm_half_t* addend, long long ldadd, const osm_half_t* addend2, long long ldadd2, int B, int HW, int C,
-                      int G, const float* stats, const float* gamma, const float* beta, const float* film, long long ldfilm,
-                      int silu, float* gstats, float* maxabs_out, void* ws, void* stream);
 int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,

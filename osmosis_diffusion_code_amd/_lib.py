@@ -91,10 +91,6 @@ _SIGS = {
     "osm_gn_fwd": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P],
     "osm_gn_prep": [_P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _LL, _P, _P, _P],
     "osm_gn_bwd": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
-    "osm_gn_coop_plan": [_I, _I, _I, _I, _I],
-    "osm_gn_coop_set": [C.c_char_p, _LL],
-    "osm_gn_fwd_coop": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
-    "osm_gn_bwd_coop": [_P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P],
     "osm_pool2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_upsample2x": [_P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
     "osm_resample_pair": [_I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _F, _P],
@@ -122,13 +118,11 @@ _SIGS = {
 }
 # fp16-storage family (activations as IEEE half, `_h` suffix): same argument lists
 for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_gn_bwd_apply", "osm_pool2x2",
-           "osm_gn_coop_plan", "osm_gn_coop_set", "osm_gn_fwd_coop", "osm_gn_bwd_coop",
            "osm_resample_pair", "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
     _SIGS[_n + "_h"] = _SIGS[_n]
 _SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]
 _SIGS["osm_f32_to_half"] = [_P, _LL, _P, _LL, _LL, _I, _P]
-EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems", "osm_winograd_weight_elems",
-                                 "osm_gn_coop_ws_bytes", "osm_gn_coop_ws_bytes_h"])
+EXPORTS = sorted(list(_SIGS) + ["osm_last_error", "osm_packed_weight_elems", "osm_winograd_weight_elems"])
 
 _lib = None
 _lock = threading.Lock()
@@ -155,9 +149,6 @@ def load():
             lib.osm_packed_weight_elems.restype = C.c_longlong
             lib.osm_winograd_weight_elems.argtypes = [_I, _I, _I, _I]
             lib.osm_winograd_weight_elems.restype = C.c_longlong
-            for name in ("osm_gn_coop_ws_bytes", "osm_gn_coop_ws_bytes_h"):
-                getattr(lib, name).argtypes = [_I, _I, _I, _I, _I]
-                getattr(lib, name).restype = C.c_longlong
             lib.osm_last_error.argtypes = []
             lib.osm_last_error.restype = C.c_char_p
             _lib = lib

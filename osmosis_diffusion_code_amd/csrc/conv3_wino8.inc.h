@@ -184,9 +184,17 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   // HP: x 2^ex brings the largest |x| of the image (OSM_MAXABS_PARTS partial maxima, as bit patterns) to [2^11, 2^12)
   float xscale = 1.f, oscale = 1.f;
   if (HP) {
-    static_assert(OSM_MAXABS_PARTS == 1024, "osm::wave_fold_maxabs reads 1024 partial maxima");
+    static_assert(OSM_MAXABS_PARTS == 1024, "two partial maxima per thread");
     const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)img * OSM_MAXABS_PARTS;
-    const unsigned mb = osm::wave_fold_maxabs(xm, lane);     // per wave: no barrier in front of the first staging store
+    unsigned mb = max(xm[tid], xm[tid + 512]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mb = max(mb, red_u[q]);
+    __syncthreads();              // the staging stores that follow reuse smem
     const float mx = __uint_as_float(mb);
     int ex = 0;
     if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(12 - ex, 100); }   // (denormal maxima: 2^ex stays finite)

@@ -38,11 +38,8 @@ __device__ uint4 g_zero_page[2];   // zero-initialised device global (never writ
 // HP ("f16x3", NP = 2, 1x1 layers): the two planes are IEEE halves of x * 2^ex (2^ex from the per-image max |x| the caller
 // supplies, IGemmParams::xmax, brings it to [2^13, 2^14)); the weight image holds halves of w * 2^ew behind a scale word; three
 // fp16 MFMAs per product, the exact power-of-two rescale in the epilogue.  A tile must not straddle two images.
-#ifndef OSM_HP1X1_OCC
-#define OSM_HP1X1_OCC 3     // workgroups per CU the f16x3 1x1 instance is compiled for (register budget 512 / OCC per lane)
-#endif
 template <int TAPS, int NP, bool HP = false>
-__global__ __launch_bounds__(256, HP ? OSM_HP1X1_OCC : 2) void igemm_bf16s_kernel(const act_t* __restrict__ Aglob,
+__global__ __launch_bounds__(256, 2) void igemm_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                               const unsigned short* __restrict__ Bglob,
                                                               IGemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * S_PLANE];   // two A stages
@@ -71,7 +68,14 @@ __global__ __launch_bounds__(256, HP ? OSM_HP1X1_OCC : 2) void igemm_bf16s_kerne
     static_assert(!HP || NP == 2, "f16x3: two half planes");
     static_assert(OSM_MAXABS_PARTS == 1024, "four partial maxima per thread");
     const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)(m0 / (p.H * p.W)) * OSM_MAXABS_PARTS;
-    const unsigned mb = osm::wave_fold_maxabs(xm, lane);     // per wave: no barrier in front of the first staging store
+    unsigned mb = max(max(xm[tid], xm[tid + 256]), max(xm[tid + 512], xm[tid + 768]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+    mb = max(max(red_u[0], red_u[1]), max(red_u[2], red_u[3]));
+    __syncthreads();              // the staging stores that follow reuse smem
     const float mx = __uint_as_float(mb);
     int ex = 0;
     if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(14 - ex, 100); }   // (denormal maxima: 2^ex stays finite)

@@ -876,8 +876,6 @@ int run_small(GNArgs& a, float* finalized, hipStream_t st) {
   return osm::check_launch("gn_small_kernel");
 }
 
-#include "gn_coop.inc.h"
-
 }  // namespace
 
 #ifndef OSM_ACT_F16
@@ -1028,76 +1026,4 @@ extern "C" int OSM_FN(osm_gn_fwd)(const abi_act_t* x, long long ldx, abi_act_t* 
   rc = run_reduce<0>(a, stats, (hipStream_t)stream, !a.fuse);
   if (rc) return rc;
   return run_apply<0>(a, (hipStream_t)stream);
-}
-
-// ---------------------------------------------------------------- cooperative single-read GroupNorm (gn_coop.inc.h)
-extern "C" int OSM_FN(osm_gn_coop_plan)(int B, int HW, int C, int G, int mode) {
-  if (mode != 0 && mode != 1) return 0;
-  return coop_plan(B, HW, C, G, mode).nwg;
-}
-
-// one knob table per storage family (each family is its own translation unit): the fp32 entry point sets both
-extern "C" int OSM_FN(osm_gn_coop_set)(const char* key, long long value) {
-  OSM_REQUIRE(key != nullptr, "osm_gn_coop_set: null key");
-  CoopConfig& c = coop_cfg();
-  const std::string k(key);
-  if (k == "on") c.on = value;
-  else if (k == "kb") c.kb_target = value;
-  else if (k == "min_kb") c.min_kb = value;
-  else if (k == "force") c.force = value;
-  else if (k == "timeout_us") c.timeout_us = value;
-  else if (k == "modes") c.modes = value;
-  else if (k == "max_kb") c.max_kb = value;
-  else return osm::fail(OSM_ERR_INVALID, "osm_gn_coop_set: unknown key '%s' (on, kb, min_kb, max_kb, modes, force, timeout_us)", key);
-  return OSM_OK;
-}
-
-extern "C" long long OSM_FN(osm_gn_coop_ws_bytes)(int B, int HW, int C, int G, int mode) {
-  const int nwg = (mode == 0 || mode == 1) ? coop_plan(B, HW, C, G, mode).nwg : 0;
-  return (long long)B * COOP_G * nwg * 2 * (long long)sizeof(unsigned long long);
-}
-
-extern "C" int OSM_FN(osm_gn_fwd_coop)(const abi_act_t* x, long long ldx, abi_act_t* y, long long ldy, int B, int HW, int C, int G,
-                                       float eps, float* stats, const float* gamma, const float* beta, const float* film,
-                                       long long ldfilm, int silu, float* maxabs_out, float* maxabs_in, void* ws, void* stream) {
-  OSM_REQUIRE(x && y && stats && gamma && beta, "osm_gn_fwd_coop: null pointer");
-  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_fwd_coop: ldfilm smaller than 2*C");
-  OSM_REQUIRE((const void*)x != (const void*)y, "osm_gn_fwd_coop: in-place operation is not supported");
-  GNArgs a{};
-  a.x = OSM_CACT(x); a.ldx = ldx; a.out = OSM_ACT(y); a.ldo = ldy; a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps;
-  a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.ldf = ldfilm; a.silu = silu;
-  int rc = check_common(a, "osm_gn_fwd_coop");
-  if (rc) return rc;
-  if (maxabs_out) {
-    OSM_REQUIRE(!OSM_ACT_IS_F16, "osm_gn_fwd_coop: maxabs_out belongs to the fp32 family");
-    a.maxabs = reinterpret_cast<unsigned*>(maxabs_out);
-  }
-  if (maxabs_in) {
-    OSM_REQUIRE(!OSM_ACT_IS_F16, "osm_gn_fwd_coop: maxabs_in belongs to the fp32 family");
-    a.maxabs_in = reinterpret_cast<unsigned*>(maxabs_in);
-  }
-  return coop_launch<0>(a, ws, stats, (hipStream_t)stream, "osm_gn_fwd_coop");
-}
-
-extern "C" int OSM_FN(osm_gn_bwd_coop)(const abi_act_t* x, long long ldx, const abi_act_t* dy, long long lddy, abi_act_t* dx,
-                                       long long lddx, const abi_act_t* addend, long long ldadd, const abi_act_t* addend2,
-                                       long long ldadd2, int B, int HW, int C, int G, const float* stats, const float* gamma,
-                                       const float* beta, const float* film, long long ldfilm, int silu, float* gstats,
-                                       float* maxabs_out, void* ws, void* stream) {
-  OSM_REQUIRE(x && dy && dx && stats && gamma && beta && gstats, "osm_gn_bwd_coop: null pointer");
-  OSM_REQUIRE(!film || ldfilm >= 2LL * C, "osm_gn_bwd_coop: ldfilm smaller than 2*C");
-  OSM_REQUIRE((const void*)dx != (const void*)x && (const void*)dx != (const void*)dy,
-              "osm_gn_bwd_coop: dx must not alias x or dy (a late workgroup re-reads them)");
-  GNArgs a{};
-  a.x = OSM_CACT(x); a.ldx = ldx; a.dy = OSM_CACT(dy); a.lddy = lddy; a.out = OSM_ACT(dx); a.ldo = lddx;
-  a.addend = OSM_CACT(addend); a.ldadd = ldadd; a.addend2 = OSM_CACT(addend2); a.ldadd2 = ldadd2;
-  a.B = B; a.HW = HW; a.C = C; a.G = G; a.stats = stats; a.gstats = gstats; a.gamma = gamma; a.beta = beta;
-  a.film = film; a.ldf = ldfilm; a.silu = silu;
-  int rc = check_common(a, "osm_gn_bwd_coop");
-  if (rc) return rc;
-  if (maxabs_out) {
-    OSM_REQUIRE(!OSM_ACT_IS_F16, "osm_gn_bwd_coop: maxabs_out belongs to the fp32 family");
-    a.maxabs = reinterpret_cast<unsigned*>(maxabs_out);
-  }
-  return coop_launch<1>(a, ws, gstats, (hipStream_t)stream, "osm_gn_bwd_coop");
 }

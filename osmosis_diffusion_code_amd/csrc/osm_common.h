@@ -116,18 +116,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// max over the OSM_MAXABS_PARTS (1024) partial maxima of one image (bit patterns of non-negative floats), computed by EVERY wave
-// for itself: 4 x 16-byte loads per lane (4 KB per wave, L2 hits) + a 6-step butterfly -- no LDS, no workgroup barrier (as a
-// workgroup-wide fold it cost the f16x3 kernels two barriers and an LDS round trip in front of their first staging store)
-__device__ __forceinline__ unsigned wave_fold_maxabs(const unsigned* __restrict__ xm, int lane) {
-  const uint4* q = reinterpret_cast<const uint4*>(xm) + lane;
-  const uint4 a = q[0], b = q[64], c = q[128], d = q[192];
-  unsigned m = max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w)));
-  m = max(m, max(max(max(c.x, c.y), max(c.z, c.w)), max(max(d.x, d.y), max(d.z, d.w))));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-  return m;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

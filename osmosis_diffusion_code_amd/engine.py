@@ -483,29 +483,15 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ GroupNorm dispatch
     def _gn_fwd(self, x: Mat, y: Mat, HW: int, st, norm: _Norm, film=None, silu=True, maxabs=None, maxabs_in=None):
-        """statistics + normalise (+FiLM) (+SiLU).  Where the cooperative single-read kernel has a plan for the shape (the tensor
-        fits the register file: ONE launch, x read once) it runs, with a workspace of its own per call site; otherwise the
-        one-launch kernels (small tensors) / the chunked two-pass path."""
-        B = self.B
-        half = x.t.dtype == torch.float16
-        if ops.gn_coop_plan(B, HW, x.cols, G, 0, half=half) > 0:
-            ws = ops.gn_coop_workspace(B, HW, x.cols, G, 0, self.dev, half=half)
-            ops.gn_fwd_coop(x, y, B, HW, G, st, norm.g, norm.b, ws, film=film, silu=silu, maxabs=maxabs, maxabs_in=maxabs_in)
-        else:
-            ops.gn_fwd(x, y, B, HW, G, self.gn_part, st, norm.g, norm.b, film=film, silu=silu, maxabs=maxabs,
-                       maxabs_in=maxabs_in)
+        """statistics + normalise (+FiLM) (+SiLU): the one-launch kernels for small tensors, the chunked two-pass path above them.
+        (A cooperative single-read kernel -- one launch, tensor resident in registers, cross-workgroup exchange of the partial sums --
+        existed in round 4: correct, deadlock-free, and +0.16 ... +0.42 ms in the step; removed in round 5, see profiles/NOTES_r01_r04.md.)"""
+        ops.gn_fwd(x, y, self.B, HW, G, self.gn_part, st, norm.g, norm.b, film=film, silu=silu, maxabs=maxabs, maxabs_in=maxabs_in)
 
     def _gn_bwd(self, x: Mat, dy: Mat, dx: Mat, HW: int, st, norm: _Norm, gst, film=None, silu=True, addend=None,
                 addend2=None, maxabs=None):
-        B = self.B
-        half = x.t.dtype == torch.float16
-        if ops.gn_coop_plan(B, HW, x.cols, G, 1, half=half) > 0:
-            ws = ops.gn_coop_workspace(B, HW, x.cols, G, 1, self.dev, half=half)
-            ops.gn_bwd_coop(x, dy, dx, B, HW, G, st, norm.g, norm.b, gst, ws, film=film, silu=silu, addend=addend,
-                            addend2=addend2, maxabs=maxabs)
-        else:
-            ops.gn_bwd(x, dy, dx, B, HW, G, st, norm.g, norm.b, self.gn_part, gst, film=film, silu=silu, addend=addend,
-                       addend2=addend2, maxabs=maxabs)
+        ops.gn_bwd(x, dy, dx, self.B, HW, G, st, norm.g, norm.b, self.gn_part, gst, film=film, silu=silu, addend=addend,
+                   addend2=addend2, maxabs=maxabs)
 
     # ------------------------------------------------------------------ ResBlock
     def _res_fwd(self, blk: _Res, x: Mat, dst: Mat, hw):

@@ -298,49 +298,6 @@ def gn_bwd(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta
                part, gstats, maxabs))
 
 
-# ---- cooperative single-read GroupNorm (csrc/gn_coop.inc.h): one launch, every operand read once
-def gn_coop_plan(B: int, HW: int, C: int, G: int, mode: int, half: bool = False) -> int:
-    """Workgroups per image of the cooperative kernel for this shape (mode 0 forward, 1 backward); 0 = not applicable
-    (the tensor does not fit the register file, unsupported channel count, OSM_GN_COOP=0): use gn_fwd / gn_bwd."""
-    return query("osm_gn_coop_plan" + ("_h" if half else ""), B, HW, C, G, mode)
-
-
-def gn_coop_set(**knobs):
-    """Run-time knobs of the cooperative GroupNorm, both storage families: on, kb (KB of one operand per workgroup), min_kb
-    (smallest image served), force (ignore the residency limit: tests of the bounded wait), timeout_us."""
-    lib = _lib.load()
-    for k, v in knobs.items():
-        for fam in ("", "_h"):
-            rc = getattr(lib, "osm_gn_coop_set" + fam)(k.encode(), int(v))
-            if rc != 0:
-                raise _lib.OsmosisHipError(lib.osm_last_error().decode())
-
-
-def gn_coop_workspace(B: int, HW: int, C: int, G: int, mode: int, device, half: bool = False) -> torch.Tensor:
-    """The zero-initialised exchange buffer of ONE call site: it must always be used with the same (B, HW, C, G, mode) --
-    its slots carry a launch counter that advances in lockstep."""
-    n = getattr(_lib.load(), "osm_gn_coop_ws_bytes" + ("_h" if half else ""))(B, HW, C, G, mode)
-    return torch.zeros(max(1, n // 8), dtype=torch.int64, device=device)
-
-
-def gn_fwd_coop(x: Mat, y: Mat, B: int, HW: int, G: int, stats, gamma, beta, ws, film=None, silu=True, eps: float = 1e-5,
-                maxabs=None, maxabs_in=None):
-    fp, ldf = _film(film)
-    call("osm_gn_fwd_coop" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, HW, x.cols, G, eps, ptr(stats), ptr(gamma),
-         ptr(beta), fp, ldf, int(silu), ptr(maxabs), ptr(maxabs_in), ws.data_ptr(), _s(),
-         keep=(x.t, y.t, stats, gamma, beta, film, maxabs, maxabs_in, ws))
-
-
-def gn_bwd_coop(x: Mat, dy: Mat, dx: Mat, B: int, HW: int, G: int, stats, gamma, beta, gstats, ws, film=None, silu=True,
-                addend: Optional[Mat] = None, addend2: Optional[Mat] = None, maxabs=None):
-    fp, ldf = _film(film)
-    fam = _same_family(x.t, dy.t, dx.t, addend.t if addend is not None else None, addend2.t if addend2 is not None else None)
-    call("osm_gn_bwd_coop" + fam, x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, *_addends(addend, addend2),
-         B, HW, x.cols, G, ptr(stats), ptr(gamma), ptr(beta), fp, ldf, int(silu), ptr(gstats), ptr(maxabs), ws.data_ptr(), _s(),
-         keep=(x.t, dy.t, dx.t, addend.t if addend else None, addend2.t if addend2 else None, stats, gamma, beta, film,
-               gstats, maxabs, ws))
-
-
 def pool2x2(x: Mat, y: Mat, B, H, W, scale=0.25):
     call("osm_pool2x2" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, H, W, x.cols, scale, _s(), keep=(x.t, y.t))
 

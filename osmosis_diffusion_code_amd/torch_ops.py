@@ -7,7 +7,7 @@ registered for the "cuda" device type only, which is HIP on ROCm).
 
     osmosis::unet_fwd(x, t, engine) -> out                  UNetModel.forward (reference unet.py:713-742); differentiable
                                                            w.r.t. x (condition_methods.py:188-191 back-propagates through it)
-    osmosis::unet_bwd_data(grad_out, out, engine) -> dx     the recorded data-gradient plan of the same engine
+    osmosis::unet_bwd_data(grad_out, engine) -> dx          the recorded data-gradient plan of the same engine
     osmosis::posterior(model_out, x, coef) -> (pred_xstart, mean, log_variance)     gaussian_diffusion.py:349-376 +
                                                            posterior_mean_variance.py (epsilon mean, learned-range variance)
     osmosis::posterior_bwd(g, coef) -> d_model_out         d(pred_xstart)/d(model_out)^T g  (the chain rule into the UNet)
@@ -18,10 +18,10 @@ registered for the "cuda" device type only, which is HIP on ROCm).
                                                            (cm.py:141-184), functional (phi is returned, not updated in place)
 
 `engine` is an integer handle (`engine_handle(eng)`) because operator schemas carry tensors and scalars only; the handle
-table holds weak references, so an engine dies with its model.  The forward pass whose activations the data-gradient pass
-needs is named by the tensor that pass returned (`out`): a later forward on the same engine returns another tensor, and
-`unet_bwd_data` then raises instead of differentiating through overwritten activations.  (Outputs are a function of the
-inputs alone -- no counters among them -- so that fake-tensor tracing and `torch.library.opcheck` see a pure operator.)"""
+table holds weak references, so an engine dies with its model.  An engine keeps the activations of its LAST forward pass:
+the autograd node of `unet_fwd` remembers which pass it belongs to (the engine's pass counter, a Python-side attribute, not an
+operator output -- outputs are functions of the inputs alone, so fake-tensor tracing and `torch.library.opcheck` see pure
+operators) and raises instead of differentiating through activations a later forward has overwritten."""
 import weakref
 from typing import List, Tuple
 
@@ -52,11 +52,7 @@ def unet_fwd(x: torch.Tensor, t: torch.Tensor, engine: int) -> torch.Tensor:
     eng = _engine(engine)
     if tuple(x.shape) != tuple(eng.x_in.shape):
         raise OsmosisHipError(f"osmosis::unet_fwd: engine is planned for x {tuple(eng.x_in.shape)}, got {tuple(x.shape)}")
-    out = eng.forward(x, t, need_grad=True).clone()
-    # the pass whose activations the engine now holds is named by the tensor it returned (its storage is kept alive by
-    # autograd for as long as a backward through it is possible, so the address cannot be recycled meanwhile)
-    eng.last_out_ptr = out.data_ptr()
-    return out
+    return eng.forward(x, t, need_grad=True).clone()
 
 
 @unet_fwd.register_fake
@@ -66,28 +62,26 @@ def _unet_fwd_fake(x, t, engine):
 
 
 @torch.library.custom_op("osmosis::unet_bwd_data", mutates_args=(), device_types="cuda")
-def unet_bwd_data(grad_out: torch.Tensor, out: torch.Tensor, engine: int) -> torch.Tensor:
-    """`out`: the tensor osmosis::unet_fwd returned for the pass to differentiate (identifies the pass; not read)."""
-    eng = _engine(engine)
-    if out.data_ptr() != getattr(eng, "last_out_ptr", None):
-        raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
-    return eng.backward(grad_out.contiguous()).clone()
+def unet_bwd_data(grad_out: torch.Tensor, engine: int) -> torch.Tensor:
+    """dL/dx of the engine's LAST forward pass (its activations are what the engine holds)."""
+    return _engine(engine).backward(grad_out.contiguous()).clone()
 
 
 @unet_bwd_data.register_fake
-def _unet_bwd_fake(grad_out, out, engine):
+def _unet_bwd_fake(grad_out, engine):
     eng = _engine(engine)
     return grad_out.new_empty((grad_out.shape[0], eng.cin, grad_out.shape[2], grad_out.shape[3]))
 
 
 def _unet_setup(ctx, inputs, output):
     ctx.engine = inputs[2]
-    ctx.save_for_backward(output)
+    ctx.ticket = _engine(inputs[2]).ticket        # the forward pass this node belongs to (eager mode: checked below)
 
 
 def _unet_backward(ctx, grad_out):
-    (out,) = ctx.saved_tensors
-    return torch.ops.osmosis.unet_bwd_data(grad_out, out, ctx.engine), None, None
+    if _engine(ctx.engine).ticket != ctx.ticket:
+        raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
+    return torch.ops.osmosis.unet_bwd_data(grad_out, ctx.engine), None, None
 
 
 unet_fwd.register_autograd(_unet_backward, setup_context=_unet_setup)

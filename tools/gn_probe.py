@@ -22,15 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--shapes", nargs="*", default=None)
-    ap.add_argument("--coop-kb", nargs="*", type=int, default=[32],
-                    help="also time the cooperative single-read kernel with these KB-per-workgroup targets (empty: skip)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-silu", action="store_true", help="normalise only (how much of a pass is the SiLU / dSiLU arithmetic?)")
     a = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes] if a.shapes else SHAPES
     dev = torch.device("cuda:0")
     G, B = 32, a.batch
-    ops.gn_coop_set(on=0)       # "fwd" / "bwd" rows: the chunked / one-launch kernels; "coop" rows switch it on
     for HW, C in shapes:
         nset = max(2, int(600e6 // (HW * C * 4 * 4)) + 1)
         nset = min(nset, 64)
@@ -80,25 +77,6 @@ def main():
         # GB/s: MINIMAL bytes of the operation (forward: read x, write y; backward: read x, dy, addend, write dx)
         for name, fn, nb in (("fwd", fwd, 2), ("apply", apply, 2), ("bwd", bwd, 4)):
             timed(name, fn, nb)
-        for kb in a.coop_kb:
-            ops.gn_coop_set(on=1, kb=kb, min_kb=0)
-            nf, nbw = ops.gn_coop_plan(B, HW, C, G, 0), ops.gn_coop_plan(B, HW, C, G, 1)
-            if nf > 0:
-                wsf = ops.gn_coop_workspace(B, HW, C, G, 0, dev)
-
-                def cfwd(s):
-                    x, dy, dx, y = s
-                    ops.gn_fwd_coop(ops.Mat.of(x), ops.Mat.of(y), B, HW, G, stats, gamma, beta, wsf, maxabs=mx.view(torch.float32))
-                timed("coop-fwd", cfwd, 2, f"kb={kb} wg={nf}")
-            if nbw > 0:
-                wsb = ops.gn_coop_workspace(B, HW, C, G, 1, dev)
-
-                def cbwd(s):
-                    x, dy, dx, y = s
-                    ops.gn_bwd_coop(ops.Mat.of(x), ops.Mat.of(dy), ops.Mat.of(dx), B, HW, G, stats, gamma, beta, gstats, wsb,
-                                    addend=ops.Mat.of(dx), maxabs=mx.view(torch.float32))
-                timed("coop-bwd", cbwd, 4, f"kb={kb} wg={nbw}")
-            ops.gn_coop_set(on=0)
 
 
 if __name__ == "__main__":
