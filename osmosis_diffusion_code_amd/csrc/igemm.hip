@@ -492,6 +492,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 #include "conv3_halo.inc.h"
 #include "conv3_wino.inc.h"
 #include "conv3_wino8.inc.h"
+#if defined(OSM_WITH_WINO16) && !defined(OSM_ACT_F16)     // measurement builds only (tools/experiments/, profiles/NOTES_r05.md)
+#include "../../tools/experiments/conv3_wino16.inc.h"
+#endif
 
 // OSM_CONV_HALO=0 selects the tap-chunked kernel for 3x3 layers too (A/B measurements only)
 bool halo_enabled() {
@@ -561,6 +564,17 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
       const int per = (p.ksteps + p.splitk - 1) / p.splitk;
       // (its staging addresses activations by 32-bit buffer offsets relative to the image, out-of-range = padding: < 2 GiB per image)
       const long long img_bytes = (long long)p.H * p.W * p.lda * (long long)sizeof(act_t);
+#ifdef OSM_WITH_WINO16   // experiment: the 16-wave, one-xi-per-wave instance for the plain case (tools/experiments/conv3_wino16.inc.h)
+#ifdef W16_FORCE
+      static const bool wino16 = true;
+#else
+      static const bool wino16 = [] { const char* e = std::getenv("OSM_WINO16"); return e && atoi(e) == 1; }();
+#endif
+      if (wino16 && (p.K & 15) == 0 && p.splitk == 1 && !p.colsum && img_bytes < 0x7fffffffLL) {
+        hipLaunchKernelGGL((conv3_wino16_kernel<0>), gw, dim3(1024), 0, st, p.A, Up, p);
+        return osm::check_launch("conv3_wino16_kernel");
+      }
+#endif
       if (W8_PIPE && (p.K & 15) == 0 && per >= W8_PIPE_MIN && img_bytes < 0x7fffffffLL)
         hipLaunchKernelGGL((conv3_wino8_kernel<2, false, true, true>), gw, dim3(512), 0, st, p.A, Up, p);
       else

@@ -1,0 +1,349 @@
+// EXPERIMENT (round 5, VERDICT r04 item 1 design (b)): the f16x3 Winograd F(2x2, 3x3) kernel with SIXTEEN waves per workgroup,
+// one xi per wave (four waves per SIMD, 128 registers each, 64 of them accumulators) -- the only 16-wave split in which neither a
+// U fragment nor a V fragment is loaded / built twice.  Same workgroup tile (16 x 16 pixels x 64 output channels, 16-channel
+// slabs), same staging layout, same weight image as conv3_wino8.inc.h; what changes is who multiplies what:
+//   wave w = 4 r + c: xi row r (two input rows of a tile, as in the 8-wave kernel) and xi COLUMN c:
+//          c = 0: V = t0 - t2;  1: t1 + t2;  2: t2 - t1;  3: t1 - t3     (t = the wave's row of B^T d);  no shared t column
+//   unit   = tile block tb (two per slab): 6 MFMAs (2 column tiles x 3 plane pairs) on one A fragment pair, while the other
+//          tile block's fragments are built (8 LDS reads, 24 FMAs, the split)
+//   out    every wave writes its M_xi (2 column tiles x 16 registers) to LDS, wave (oy, ox, column tile, row half) sums
+//          3 x 3 xi with the signs of A^T . A and stores two tile rows.
+// Serves the plain case only (splitk 1, no column sums): enough to measure whether four waves per SIMD hide the latencies
+// the SQ counters show at two.  RESULT (profiles/NOTES_r05.md section 1): correct; +33 % per launch against the 8-wave kernel
+// (232 vs 170 us at 256^2 256 -> 256); its MFMA-only loop runs in 69 us (0.68 matrix-pipe busy) but build, staging and U loads
+// add their full time back: nothing overlaps.  NOT compiled into the library: a measurement build includes it with
+//     -DOSM_WITH_WINO16 [-DW16_FORCE | OSM_WINO16=1] [-DW16_NOEPI] [-DW16_ABL=..] [-DW16_STAGGER=0] [-DW16_FENCE_MODE=..]
+// through tools/build_variants.sh (igemm.hip includes this file from tools/experiments/).
+#ifndef W16_ABL
+#define W16_ABL 0     // measurement builds (wrong results): 1 no U re-requests inside the loop, 2 no LDS reads / build arithmetic, 4 no raw staging
+#endif
+template <int DUMMY = 0>
+__global__ __launch_bounds__(1024, 1) void conv3_wino16_kernel(const act_t* __restrict__ Aglob, const unsigned short* __restrict__ Uglob,
+                                                                IGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[8 * 2 * 2 * 16 * 64];   // 128 KB: two raw slabs (46 KB), then the exchange buffer
+  float4* raw = reinterpret_cast<float4*>(smem);
+  float* red = smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  const int nt = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int qq = nt >> 3, rr8 = nt & 7, xcd = bid & 7, idx8 = bid >> 3;
+  const int id = (xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq) + idx8;
+  const int grp_sz = p.nb1 * p.mtiles;
+  const int tile_n = (id / grp_sz) * p.nb1 + id % p.nb1, tile_m = (id % grp_sz) / p.nb1;
+  const int tpx = (p.W + 15) >> 4, tpy = (p.H + 15) >> 4;
+  const int tx = tile_m % tpx, ty = (tile_m / tpx) % tpy, img = tile_m / (tpx * tpy);
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int kc0 = 0, kc1 = p.ksteps;
+
+  // ---- raw staging: piece s = tid + 1024 j -> channel quad tid & 3, halo pixel (tid >> 2) + 256 j   (1296 pieces: j = 0, 1)
+  const int q4 = tid & 3;
+  const long long rowB = (long long)p.lda * ACT_B;
+  const char* __restrict__ sbaseA = reinterpret_cast<const char*>(Aglob) + (long long)img * p.H * p.W * rowB;
+  unsigned woff[2], aoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pix = (tid >> 2) + 256 * j;
+    const int r = pix / 18, col = pix - r * 18;
+    const bool in = pix < 324;
+    woff[j] = (unsigned)(q4 * WN_QP + (in ? r * WN_ROWP + (col & 1) * 10 + (col >> 1) : 17 * WN_ROWP + 19));
+    const int y = y0 - 1 + r, x = x0 - 1 + col;
+    const bool ok = in && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    aoff[j] = ok ? (unsigned)((long long)(y * p.W + x) * rowB) + (unsigned)(q4 * 4 * ACT_B) : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(sbaseA), 0, (int)min((long long)p.H * p.W * rowB, 0x7fffffffLL), 0x00020000);
+
+  // ---- U fragments: image [plane][xi][slab][n/32][lane][8]; this wave reads xi = wave
+  const int jn0 = 2 * tile_n;
+  const unsigned u_lane = (unsigned)((jn0 * 64 + lane) * 16);
+  const unsigned u_nt = jn0 + 1 < p.nt32 ? 1024u : 0u;
+  const unsigned u_slab = (unsigned)p.nt32 * 1024u;
+  const unsigned u_xi = u_slab * (unsigned)p.ksteps;
+  const unsigned u_plane = u_xi * 16u;
+  const unsigned u_base = (unsigned)wave * u_xi;
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(Uglob)), 0, 0x7fffffff, 0x00020000);
+
+  f32x16 acc[2][2];          // [tile block][column tile]
+  {
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    f32x16 z16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z16[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        uint4 z = z4;
+        asm("" : "+v"(z.x));
+        acc[a][b] = mma16h(z, z4, z16);
+      }
+  }
+
+  // ---- this wave's row of B^T d (as in the 8-wave kernel): t = x + sg y, (x, y) = input rows (0,2) | (1,2) | (2,1) | (1,3)
+  const int tyl = lr >> 3, txl = lr & 7;
+  const int rx = wr == 0 ? 0 : (wr == 2 ? 2 : 1), ry = wr == 2 ? 1 : (wr == 3 ? 3 : 2);
+  const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(wr == 1 ? 0x3f800000 : (int)0xbf800000));
+  const osm::floatx4_t* t_x = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + rx) * WN_ROWP + txl;
+  const osm::floatx4_t* t_y = reinterpret_cast<const osm::floatx4_t*>(raw) + (2 * lk) * WN_QP + (2 * tyl + ry) * WN_ROWP + txl;
+
+  float4 ra[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)aoff[j], kc0 * (16 * ACT_B), 0));
+
+  float xscale, oscale;
+  {
+    static_assert(OSM_MAXABS_PARTS == 1024, "one partial maximum per thread");
+    const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)img * OSM_MAXABS_PARTS;
+    unsigned mb = xm[tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mb = max(mb, red_u[q]);
+    __syncthreads();
+    const float mx = __uint_as_float(mb);
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(12 - ex, 100); }
+    xscale = mx == mx ? ldexpf(1.f, ex) : mx;
+    oscale = ldexpf(1.f, -ex) / p.wscale[0];
+    xscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xscale)));
+    oscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oscale)));
+  }
+
+  uint4 uq[2][2];            // [column tile][plane]: ONE set -- a fragment is re-requested for the next slab right after its last MFMA
+  uint4 va[2][2];            // [tile block][plane]
+  osm::floatx4_t rd[4];
+#define OSM_W16_LOAD_RAW(cc_)                                                                                          \
+  if (!(W16_ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+    ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)aoff[j], (cc_) * (16 * ACT_B), 0));
+#define OSM_W16_STORE_RAW(buf_)                                                                                        \
+  if (!(W16_ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+    raw[(buf_) * (4 * WN_QP) + woff[j]] = make_float4(ra[j].x * xscale, ra[j].y * xscale, ra[j].z * xscale, ra[j].w * xscale);
+#define OSM_W16_LOAD_U1(b_, q2_, cc_)                                                                                  \
+  if (!(W16_ABL & 1) || (cc_) == kc0) uq[b_][q2_] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(                                       \
+      ursrc, (int)u_lane, (int)(u_base + (unsigned)(cc_) * u_slab + (unsigned)(q2_) * u_plane + (unsigned)(b_) * u_nt), 0));
+  // half hq_ of the A fragments of tile block tb_ from buffer buf_: V = t[CA] + SB t[CB] -> words 2 hq_, 2 hq_ + 1 of both planes
+#define OSM_W16_READS(hq_, tb_, buf_)                                                                                  \
+  {                                                                                                                    \
+    const int oa_ = ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + (CA & 1) * 10 + (CA >> 1);                   \
+    const int ob_ = ((buf_) * 4 + (hq_)) * WN_QP + 8 * (tb_) * WN_ROWP + (CB & 1) * 10 + (CB >> 1);                   \
+    if (!(W16_ABL & 2)) { rd[0] = t_x[oa_]; rd[1] = t_y[oa_]; rd[2] = t_x[ob_]; rd[3] = t_y[ob_]; }                  \
+  }
+#define OSM_W16_MATH(hq_, tb_)                                                                                         \
+  if (!(W16_ABL & 2)) {                                                                                                                  \
+    float4 v_;                                                                                                         \
+    v_.x = fmaf(sg, rd[1][0], rd[0][0]) + SB * fmaf(sg, rd[3][0], rd[2][0]);                                           \
+    v_.y = fmaf(sg, rd[1][1], rd[0][1]) + SB * fmaf(sg, rd[3][1], rd[2][1]);                                           \
+    v_.z = fmaf(sg, rd[1][2], rd[0][2]) + SB * fmaf(sg, rd[3][2], rd[2][2]);                                           \
+    v_.w = fmaf(sg, rd[1][3], rd[0][3]) + SB * fmaf(sg, rd[3][3], rd[2][3]);                                           \
+    uint2 vh_[2];                                                                                                      \
+    split_f16x2(v_, vh_);                                                                                              \
+    if ((hq_) == 0) { va[tb_][0].x = vh_[0].x; va[tb_][0].y = vh_[0].y; va[tb_][1].x = vh_[1].x; va[tb_][1].y = vh_[1].y; } \
+    else            { va[tb_][0].z = vh_[0].x; va[tb_][0].w = vh_[0].y; va[tb_][1].z = vh_[1].x; va[tb_][1].w = vh_[1].y; } \
+  }
+  // the six MFMAs of a tile block, by name: A / B = (V hi, U lo) on column tile 0 / 1;  C, D = (V lo, U hi), (V hi, U hi) on tile 0;
+  // E, F the same on tile 1
+#define OSM_W16_A(tb_) acc[tb_][0] = mma16h(va[tb_][0], uq[0][1], acc[tb_][0]);
+#define OSM_W16_B(tb_) acc[tb_][1] = mma16h(va[tb_][0], uq[1][1], acc[tb_][1]);
+#define OSM_W16_C(tb_) acc[tb_][0] = mma16h(va[tb_][1], uq[0][0], acc[tb_][0]);
+#define OSM_W16_D(tb_) acc[tb_][0] = mma16h(va[tb_][0], uq[0][0], acc[tb_][0]);
+#define OSM_W16_E(tb_) acc[tb_][1] = mma16h(va[tb_][1], uq[1][0], acc[tb_][1]);
+#define OSM_W16_F(tb_) acc[tb_][1] = mma16h(va[tb_][0], uq[1][0], acc[tb_][1]);
+#ifndef W16_FENCE_MODE
+#define W16_FENCE_MODE 0
+#endif
+#define OSM_W16_FENCE() if (W16_FENCE_MODE != 2) asm volatile("" ::: "memory"); if (W16_FENCE_MODE == 0) __builtin_amdgcn_sched_barrier(0);
+
+#ifndef W16_STAGGER
+#define W16_STAGGER 1      // 1: odd xi rows run "build, then MFMAs", even rows interleave them (0: every wave the same order)
+#endif
+  auto slab_loop = [&](auto cc, auto oc) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+    constexpr int ORDER = decltype(oc)::value;
+    constexpr int CA = C == 0 ? 0 : (C == 2 ? 2 : 1), CB = C == 2 ? 1 : (C == 3 ? 3 : 2);
+    constexpr float SB = C == 1 ? 1.f : -1.f;
+    const int k1 = min(kc0 + 1, kc1 - 1);
+    OSM_W16_LOAD_U1(0, 1, kc0) OSM_W16_LOAD_U1(1, 1, kc0) OSM_W16_LOAD_U1(0, 0, kc0) OSM_W16_LOAD_U1(1, 0, kc0)
+    OSM_W16_STORE_RAW(0)
+    OSM_W16_LOAD_RAW(k1)
+    __syncthreads();
+    OSM_W16_READS(0, 0, 0) OSM_W16_MATH(0, 0)
+    OSM_W16_READS(1, 0, 0) OSM_W16_MATH(1, 0)
+    OSM_W16_FENCE()
+    auto slab = [&](auto pc, const int c) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value, Q = 1 - P;
+      const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
+      OSM_W16_STORE_RAW(Q)
+      OSM_W16_LOAD_RAW(c2)
+      if constexpr (ORDER == 0) {
+        // unit 0: MFMAs of tile block 0 interleaved with the build of tile block 1 (this slab)
+        OSM_W16_READS(0, 1, P)
+        OSM_W16_A(0) OSM_W16_B(0) OSM_W16_C(0)
+        OSM_W16_MATH(0, 1)
+        OSM_W16_FENCE()
+        OSM_W16_READS(1, 1, P)
+        OSM_W16_D(0) OSM_W16_E(0) OSM_W16_F(0)
+        OSM_W16_MATH(1, 1)
+        OSM_W16_FENCE()
+        __syncthreads();          // raw(c + 1) is complete in buffer Q; nobody reads buffer P any more
+        // unit 1: MFMAs of tile block 1 | build of tile block 0 of slab c + 1 | every U fragment re-requested after its last use
+        OSM_W16_READS(0, 0, Q)
+        OSM_W16_A(1) OSM_W16_B(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 1, c1) OSM_W16_LOAD_U1(1, 1, c1)
+        OSM_W16_C(1)
+        OSM_W16_MATH(0, 0)
+        OSM_W16_FENCE()
+        OSM_W16_READS(1, 0, Q)
+        OSM_W16_D(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 0, c1)
+        OSM_W16_E(1) OSM_W16_F(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(1, 0, c1)
+        OSM_W16_MATH(1, 0)
+        OSM_W16_FENCE()
+      } else {
+        // the OTHER phase order (odd xi rows: the waves that share a SIMD are xi rows 0..3 of one column): the whole build first,
+        // then the six MFMAs -- while the even rows' waves issue MFMAs these issue VALU / LDS work and vice versa
+        OSM_W16_READS(0, 1, P)
+        OSM_W16_MATH(0, 1)
+        OSM_W16_READS(1, 1, P)
+        OSM_W16_MATH(1, 1)
+        OSM_W16_FENCE()
+        OSM_W16_A(0) OSM_W16_B(0) OSM_W16_C(0) OSM_W16_D(0) OSM_W16_E(0) OSM_W16_F(0)
+        OSM_W16_FENCE()
+        __syncthreads();
+        OSM_W16_READS(0, 0, Q)
+        OSM_W16_MATH(0, 0)
+        OSM_W16_READS(1, 0, Q)
+        OSM_W16_MATH(1, 0)
+        OSM_W16_FENCE()
+        OSM_W16_A(1) OSM_W16_B(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 1, c1) OSM_W16_LOAD_U1(1, 1, c1)
+        OSM_W16_C(1) OSM_W16_D(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 0, c1)
+        OSM_W16_E(1) OSM_W16_F(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(1, 0, c1)
+        OSM_W16_FENCE()
+      }
+    };
+    for (int c = kc0; c < kc1; c += 2) {
+      slab(std::integral_constant<int, 0>{}, c);
+      if (c + 1 >= kc1) break;
+      slab(std::integral_constant<int, 1>{}, c + 1);
+    }
+  };
+  using O0 = std::integral_constant<int, 0>; using O1 = std::integral_constant<int, 1>;
+  if (W16_STAGGER && (wr & 1)) {
+    if (wc == 0) slab_loop(std::integral_constant<int, 0>{}, O1{});
+    else if (wc == 1) slab_loop(std::integral_constant<int, 1>{}, O1{});
+    else if (wc == 2) slab_loop(std::integral_constant<int, 2>{}, O1{});
+    else slab_loop(std::integral_constant<int, 3>{}, O1{});
+  } else {
+    if (wc == 0) slab_loop(std::integral_constant<int, 0>{}, O0{});
+    else if (wc == 1) slab_loop(std::integral_constant<int, 1>{}, O0{});
+    else if (wc == 2) slab_loop(std::integral_constant<int, 2>{}, O0{});
+    else slab_loop(std::integral_constant<int, 3>{}, O0{});
+  }
+#undef OSM_W16_LOAD_RAW
+#undef OSM_W16_STORE_RAW
+#undef OSM_W16_LOAD_U1
+#undef OSM_W16_READS
+#undef OSM_W16_MATH
+#undef OSM_W16_A
+#undef OSM_W16_B
+#undef OSM_W16_C
+#undef OSM_W16_D
+#undef OSM_W16_E
+#undef OSM_W16_F
+#undef OSM_W16_FENCE
+
+#ifdef W16_NOEPI      // measurement build: the K loop alone (one value per lane keeps the accumulators alive)
+  if (p.alpha != 12345.f) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[a][b][e];
+    if (s == 1.2345e-30f) p.C[0] = (act_t)s;
+    return;
+  }
+#endif
+  // ---- Y = A^T M A.  red: [xi = 4 r + c][column tile][e][lane]; finishing wave = (oy, ox, column tile fb, row half ih)
+  const int oy = wave >> 3, ox = (wave >> 2) & 1, fb = (wave >> 1) & 1, ih = wave & 1;
+  const long long pix0 = (long long)img * p.H * p.W + (long long)(y0 + oy) * p.W + (x0 + ox);
+  act_t* __restrict__ obase = p.C + pix0 * p.ldc;
+  const act_t* __restrict__ rbase = p.res ? p.res + pix0 * p.ldr : nullptr;
+  const int c4 = 4 * (lane & 7), lk2 = (lane >> 3) & 1, e_lo = lane >> 4;
+  const int dx = 2 * (e_lo + 4 * lk2);
+  const bool xok = x0 + ox + dx < p.W;
+  const int n = (jn0 + fb) * 32 + c4;
+  const bool nok = n < p.N && (fb == 0 || u_nt != 0u);
+  const bool ok = nok && xok;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+  // signs of A^T (rows) and A (columns): output 0 = + + + of xi 0..2, output 1 = + - - of xi 1..3
+  float sgn[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      sgn[k][m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+          ((oy == 0 || k == 0) == (ox == 0 || m == 0)) ? 0x3f800000 : (int)0xbf800000));
+  const float* red_rd = red + (fb * 16 + e_lo) * 64 + lk2 * 32 + c4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    float4 pre_r[2], pre_a[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int dy = 8 * a + 2 * (2 * ih + i2);
+      const int po = dy * p.W + dx;
+      const bool live = ok && y0 + oy + dy < p.H;
+      pre_r[i2] = pre_a[i2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rbase && live) pre_r[i2] = osm::ld4(rbase + po * (int)p.ldr + n);
+      if (p.accumulate && live) pre_a[i2] = osm::ld4(obase + po * (int)p.ldc + n);
+    }
+    __syncthreads();       // a = 0: the slab loop's reads of raw are over;  a = 1: the previous round's reads of red
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[((wave * 2 + b) * 16 + e) * 64 + lane] = acc[a][b][e];
+    __syncthreads();
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int i = 2 * ih + i2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const float4 s = *reinterpret_cast<const float4*>(red_rd + (((4 * (oy + k) + ox + m) * 2) * 16 + 4 * i) * 64);
+          v.x = fmaf(sgn[k][m], s.x, v.x); v.y = fmaf(sgn[k][m], s.y, v.y);
+          v.z = fmaf(sgn[k][m], s.z, v.z); v.w = fmaf(sgn[k][m], s.w, v.w);
+        }
+      v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale;
+      const int dy = 8 * a + 2 * i;
+      if (y0 + oy + dy >= p.H) continue;
+      const int po = dy * p.W + dx;
+      v = make_float4(v.x * p.alpha + bv.x, v.y * p.alpha + bv.y, v.z * p.alpha + bv.z, v.w * p.alpha + bv.w);
+      v.x += pre_r[i2].x; v.y += pre_r[i2].y; v.z += pre_r[i2].z; v.w += pre_r[i2].w;
+      v.x += pre_a[i2].x; v.y += pre_a[i2].y; v.z += pre_a[i2].z; v.w += pre_a[i2].w;
+      if (ok) osm::st4(obase + po * (int)p.ldc + n, v);
+    }
+  }
+}
