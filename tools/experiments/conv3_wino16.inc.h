@@ -9,8 +9,8 @@
 //   out    every wave writes its M_xi (2 column tiles x 16 registers) to LDS, wave (oy, ox, column tile, row half) sums
 //          3 x 3 xi with the signs of A^T . A and stores two tile rows.
 // Serves the plain case only (splitk 1, no column sums): enough to measure whether four waves per SIMD hide the latencies
-// the SQ counters show at two.  RESULT (profiles/NOTES_r05.md section 1): correct; +33 % per launch against the 8-wave kernel
-// (232 vs 170 us at 256^2 256 -> 256); its MFMA-only loop runs in 69 us (0.68 matrix-pipe busy) but build, staging and U loads
+// the SQ counters show at two.  RESULT (profiles/NOTES_r05.md section 1): correct; +28 % per launch against the 8-wave kernel
+// (212 vs 165 us at 256^2 256 -> 256 in its best form, -DW16_COARSE=1); its MFMA-only loop runs in 69 us (0.68 matrix-pipe busy) but build, staging and U loads
 // add their full time back: nothing overlaps.  NOT compiled into the library: a measurement build includes it with
 //     -DOSM_WITH_WINO16 [-DW16_FORCE | OSM_WINO16=1] [-DW16_NOEPI] [-DW16_ABL=..] [-DW16_STAGGER=0] [-DW16_FENCE_MODE=..]
 // through tools/build_variants.sh (igemm.hip includes this file from tools/experiments/).
@@ -163,6 +163,9 @@ __global__ __launch_bounds__(1024, 1) void conv3_wino16_kernel(const act_t* __re
 #endif
 #define OSM_W16_FENCE() if (W16_FENCE_MODE != 2) asm volatile("" ::: "memory"); if (W16_FENCE_MODE == 0) __builtin_amdgcn_sched_barrier(0);
 
+#ifndef W16_COARSE
+#define W16_COARSE 0       // 1: a unit is two coarse blocks (six MFMAs | the whole build), their order opposite on odd / even xi rows
+#endif
 #ifndef W16_STAGGER
 #define W16_STAGGER 1      // 1: odd xi rows run "build, then MFMAs", even rows interleave them (0: every wave the same order)
 #endif
@@ -184,6 +187,42 @@ __global__ __launch_bounds__(1024, 1) void conv3_wino16_kernel(const act_t* __re
       const int c1 = min(c + 1, kc1 - 1), c2 = min(c + 2, kc1 - 1);
       OSM_W16_STORE_RAW(Q)
       OSM_W16_LOAD_RAW(c2)
+#if W16_COARSE     // both phase orders as two coarse blocks per unit: [six MFMAs] and [the whole build], in opposite order on odd / even xi rows
+#define OSM_W16_BLOCK_B(tb_, buf_) OSM_W16_READS(0, tb_, buf_) OSM_W16_MATH(0, tb_) OSM_W16_READS(1, tb_, buf_) OSM_W16_MATH(1, tb_) OSM_W16_FENCE()
+      if constexpr (ORDER == 0) {
+        OSM_W16_A(0) OSM_W16_B(0) OSM_W16_C(0) OSM_W16_D(0) OSM_W16_E(0) OSM_W16_F(0)
+        OSM_W16_FENCE()
+        OSM_W16_BLOCK_B(1, P)
+        __syncthreads();
+        OSM_W16_A(1) OSM_W16_B(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 1, c1) OSM_W16_LOAD_U1(1, 1, c1)
+        OSM_W16_C(1) OSM_W16_D(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 0, c1)
+        OSM_W16_E(1) OSM_W16_F(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(1, 0, c1)
+        OSM_W16_BLOCK_B(0, Q)
+      } else {
+        OSM_W16_BLOCK_B(1, P)
+        OSM_W16_A(0) OSM_W16_B(0) OSM_W16_C(0) OSM_W16_D(0) OSM_W16_E(0) OSM_W16_F(0)
+        OSM_W16_FENCE()
+        __syncthreads();
+        OSM_W16_BLOCK_B(0, Q)
+        OSM_W16_A(1) OSM_W16_B(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 1, c1) OSM_W16_LOAD_U1(1, 1, c1)
+        OSM_W16_C(1) OSM_W16_D(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(0, 0, c1)
+        OSM_W16_E(1) OSM_W16_F(1)
+        OSM_W16_FENCE()
+        OSM_W16_LOAD_U1(1, 0, c1)
+        OSM_W16_FENCE()
+      }
+#undef OSM_W16_BLOCK_B
+#else
       if constexpr (ORDER == 0) {
         // unit 0: MFMAs of tile block 0 interleaved with the build of tile block 1 (this slab)
         OSM_W16_READS(0, 1, P)
@@ -239,6 +278,7 @@ __global__ __launch_bounds__(1024, 1) void conv3_wino16_kernel(const act_t* __re
         OSM_W16_LOAD_U1(1, 0, c1)
         OSM_W16_FENCE()
       }
+#endif
     };
     for (int c = kc0; c < kc1; c += 2) {
       slab(std::integral_constant<int, 0>{}, c);
