@@ -450,12 +450,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino8_kernel(const act_t* __rest
   }
 #define OSM_W8P_LOAD_RAW(cc_, j_)                                                          \
   ra[j_] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)aoff[j_], (cc_) * (16 * ACT_B), 0));
-#ifndef W8_SKIP_DUMMY
-#define W8_SKIP_DUMMY 1   // 1: the 240 threads whose third piece lies past the 324 halo pixels (tid >= 272) do not store it; 0: they all
-                          // store to one dummy slot per channel quad (round 3-4 form: no predicate) -- 48 lanes of one address per quad
-#endif
 #define OSM_W8P_STORE_RAW(buf_, j_)                                                        \
-  if (!(W8_SKIP_DUMMY && (j_) == 2) || tid < 272)                                          \
   raw[(buf_) * (4 * WN_QP) + woff[j_]] = make_float4(ra[j_].x * xscale, ra[j_].y * xscale, ra[j_].z * xscale, ra[j_].w * xscale);
   auto slab_loop_p = [&](auto hc) __attribute__((always_inline)) {
     constexpr int H = decltype(hc)::value;
