@@ -9,7 +9,7 @@ out=$repo/gpurun_out/prof
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- \
-    python "$repo/bench.py" --steps 4 --warmup 1 --cpu-steps 0 --secondary-steps 0 --pmc off > "$out/kt.log" 2>&1
+    python "$repo/bench.py" --steps 8 --warmup 1 --cpu-steps 0 --secondary-steps 0 --pmc off > "$out/kt.log" 2>&1
 f=$(find "$out/kt" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/${tag}_rocprofv3_kernel_stats.csv"
 find "$out/kt" -name '*kernel_trace.csv' -delete
