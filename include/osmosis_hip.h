@@ -240,6 +240,15 @@ int osm_pool2x2(const float* x, long long ldx, float* y, long long ldy, int B, i
                 float scale, void* stream);
 int osm_upsample2x(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C,
                    float scale, void* stream);
+/* Round 5 -- pieces of the UNet variants no shipped Osmosis config uses (reference unet.py:160-219 Upsample / Downsample WITH a
+ * convolution, i.e. resblock_updown=False; :329-332 additive conditioning, i.e. use_scale_shift_norm=False; :729-731 class embedding):
+ *   osm_stride2_pick    y[b][i][j][:] = x[b][2i][2j][:]   (x: H x W -> y: H/2 x W/2): a stride-2 3x3 convolution = osm_conv2d_nhwc at
+ *                       stride 1, every other pixel kept;
+ *   osm_stride2_place   y[b][2i][2j][:] = x[b][i][j][:], 0 elsewhere  (x: H/2 x W/2 -> y: H x W; H, W = the OUTPUT's): its adjoint;
+ *   osm_add_rowvec      y[b][p][c] += v[b][c]  (y: [B * HW][ldy] activations, v: [B][ldv] fp32): h + emb_out, emb + label_emb[y]. */
+int osm_stride2_pick(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C, void* stream);
+int osm_stride2_place(const float* x, long long ldx, float* y, long long ldy, int B, int H, int W, int C, void* stream);
+int osm_add_rowvec(float* y, long long ldy, const float* v, long long ldv, int B, long long HW, int C, void* stream);
 /* two tensors of one shape through ONE launch (up != 0: osm_upsample2x, else osm_pool2x2; 4-element vectors only): an up / down
  * ResBlock resamples both its input and its normalised input (unet.py:263-270), its backward both gradients */
 int osm_resample_pair(int up, const float* x1, long long ldx1, float* y1, long long ldy1, const float* x2, long long ldx2,
@@ -392,6 +401,9 @@ int osm_pool2x2_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long l
                   float scale, void* stream);
 int osm_upsample2x_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C,
                      float scale, void* stream);
+int osm_stride2_pick_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C, void* stream);
+int osm_stride2_place_h(const osm_half_t* x, long long ldx, osm_half_t* y, long long ldy, int B, int H, int W, int C, void* stream);
+int osm_add_rowvec_h(osm_half_t* y, long long ldy, const float* v, long long ldv, int B, long long HW, int C, void* stream);
 int osm_resample_pair_h(int up, const osm_half_t* x1, long long ldx1, osm_half_t* y1, long long ldy1, const osm_half_t* x2,
                         long long ldx2, osm_half_t* y2, long long ldy2, int B, int H, int W, int C, float scale, void* stream);
 int osm_nchw_to_nhwc_h(const float* x, osm_half_t* y, long long ldy, int B, int C, int HW, void* stream);   /* fp32 NCHW -> half NHWC */

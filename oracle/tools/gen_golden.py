@@ -19,6 +19,7 @@ Sections (SURVEY.md section 8c recipe):
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
+  unet_variants.npz   (round 5) tiny UNets with conv up / down-sampling layers, additive conditioning, class conditioning
   outputs.npz         (round 5) the five per-image output files of osmosis_sampling.py:319-353 as uint8 arrays
   configs.json        (round 5) configs/*.yaml as parsed by the reference's load_yaml
   full_unet.npz       (round 4) the full 552.8 M-parameter architecture through the real reference at 256 x 256 (every 4th pixel of y and
@@ -547,6 +548,46 @@ def gen_postprocess():
     np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
 
 
+VARIANTS = {
+    # (a) the guided-diffusion defaults the Osmosis configs switch off: Upsample / Downsample layers with convolutions instead of
+    #     up / down ResBlocks, additive instead of scale-shift conditioning
+    "conv_updown_additive": dict(TINY_KW, resblock_updown=False, use_scale_shift_norm=False),
+    # (b) conv resampling with scale-shift conditioning, class-conditional, a non-zero dropout rate (inference: identity)
+    "conv_updown_classcond": dict(TINY_KW, resblock_updown=False, class_cond=True, dropout=0.1),
+    # (c) additive conditioning with up / down ResBlocks
+    "resblock_updown_additive": dict(TINY_KW, use_scale_shift_norm=False),
+}
+
+
+def gen_unet_variants():
+    """UNet variants NO shipped Osmosis config uses (VERDICT r04 "missing" 5): the real reference's create_model with
+    resblock_updown=False (Upsample / Downsample with 3x3 convolutions, unet.py:160-219), use_scale_shift_norm=False (:329-332),
+    class_cond=True (label_emb, :556-557, 729-731) and dropout > 0 in eval mode, tiny sizes, oracle.unet_ref.seeded_state_dict weights
+    (loaded strictly: the oracle's key / shape list is checked against the reference module on the way): y and d(sum(y w))/dx."""
+    out = {}
+    for tag, kw in VARIANTS.items():
+        cfg = UNetConfig.from_create_model_kwargs(**kw)
+        sd = seeded_state_dict(cfg, seed=4321)
+        m = R_unet.create_model(**kw)
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        m.eval()
+        g = torch.Generator().manual_seed(5)
+        x = (0.8 * torch.randn(2, 4, 32, 32, generator=g)).requires_grad_(True)
+        t = torch.tensor([3.0, 640.0])
+        w = torch.randn(2, 8, 32, 32, generator=g)
+        ykw = {}
+        if kw.get("class_cond"):
+            ykw["y"] = torch.tensor([7, 993])
+            out[f"{tag}.labels"] = npy(ykw["y"])
+        y = m(x, t, **ykw)
+        (dx,) = torch.autograd.grad((y * w).sum(), x)
+        out.update({f"{tag}.x": npy(x), f"{tag}.t": npy(t), f"{tag}.w": npy(w), f"{tag}.y": npy(y), f"{tag}.dx": npy(dx),
+                    f"{tag}.n_params": np.array(sum(p.numel() for p in m.parameters()))})
+        print(tag, "params", int(out[f"{tag}.n_params"]), "y max", float(y.abs().max()), "dx max", float(dx.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "unet_variants.npz"), **out)
+
+
 def gen_outputs():
     """The five per-image files of osmosis_sampling.py:319-353 as uint8 arrays, for a seeded final pred_xstart / phi / input of
     a revised-underwater run: the tensors are formed with the reference's OWN helpers (osmosis_utils/utils.py) in the order the
@@ -625,6 +666,7 @@ if __name__ == "__main__":
     gen_schedules()
     gen_blocks()
     gen_tiny_unet()
+    gen_unet_variants()
     gen_loops()
     gen_prior()
     gen_postprocess()

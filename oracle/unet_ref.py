@@ -12,6 +12,9 @@ Follows (reference file:line):
   * QKVAttention.forward              guided_diffusion/unet.py:449-468
   * GroupNorm32 / timestep_embedding  guided_diffusion/nn.py:17-19, 103-121
   * Upsample / Downsample (conv-less) guided_diffusion/unet.py:179-189, 217-219
+  * round 5, the variants no shipped config uses: Upsample / Downsample WITH convolution as layers of their own
+    (`resblock_updown=False`, unet.py:160-219, 600-612, 667-679), `use_scale_shift_norm=False` (:329-332), the class
+    embedding (`num_classes`, :556-557, 729-731)
 """
 import math
 from dataclasses import dataclass, field
@@ -35,13 +38,15 @@ class UNetConfig:
     use_scale_shift_norm: bool = True
     resblock_updown: bool = True
     use_new_attention_order: bool = False
+    conv_resample: bool = True          # UNetModel's default; create_model never changes it
+    num_classes: int = 0                # > 0: class-conditional (label_emb)
 
     @staticmethod
     def from_create_model_kwargs(image_size, num_channels, num_res_blocks, channel_mult="",
                                  attention_resolutions="16", num_heads=1, num_head_channels=-1,
                                  use_scale_shift_norm=False, resblock_updown=False,
                                  use_new_attention_order=False, learn_sigma=False,
-                                 pretrain_model="", **_unused):
+                                 pretrain_model="", class_cond=False, **_unused):
         """Mirror of create_model's argument digestion (unet.py:47-68, 91-92)."""
         if channel_mult == "":
             table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4),
@@ -63,7 +68,8 @@ class UNetConfig:
                           num_head_channels=num_head_channels,
                           use_scale_shift_norm=use_scale_shift_norm,
                           resblock_updown=resblock_updown,
-                          use_new_attention_order=use_new_attention_order)
+                          use_new_attention_order=use_new_attention_order,
+                          num_classes=1000 if class_cond else 0)      # NUM_CLASSES, unet.py:23
 
 
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
@@ -161,9 +167,7 @@ def build_layout(cfg: UNetConfig) -> _Layout:
             lay.input_blocks.append(layers)
             chans.append(ch)
         if level != len(cfg.channel_mult) - 1:
-            if not cfg.resblock_updown:
-                raise NotImplementedError("oracle covers resblock_updown=True (all shipped configs)")
-            lay.input_blocks.append([("res", {"down": True})])
+            lay.input_blocks.append([("res", {"down": True})] if cfg.resblock_updown else [("down", {})])
             chans.append(ch)
             ds *= 2
     lay.middle = [("res", {}), ("attn", {"heads": _heads(cfg, ch)}), ("res", {})]
@@ -175,7 +179,7 @@ def build_layout(cfg: UNetConfig) -> _Layout:
             if ds in cfg.attention_ds:
                 layers.append(("attn", {"heads": _heads(cfg, ch)}))
             if level and i == cfg.num_res_blocks:
-                layers.append(("res", {"up": True}))
+                layers.append(("res", {"up": True}) if cfg.resblock_updown else ("up", {}))
                 ds //= 2
             lay.output_blocks.append(layers)
     return lay
@@ -188,18 +192,28 @@ def _run_seq(sd, cfg, prefix, layers, h, emb):
             h = F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif kind == "res":
             h = res_block(sd, p, h, emb, scale_shift=cfg.use_scale_shift_norm, **kw)
+        elif kind == "down":        # Downsample, unet.py:192-219: 3x3 conv with stride 2, or 2x2 average pooling
+            h = F.conv2d(h, sd[p + "op.weight"], sd[p + "op.bias"], stride=2, padding=1) if cfg.conv_resample \
+                else F.avg_pool2d(h, 2, 2)
+        elif kind == "up":          # Upsample, unet.py:160-189: nearest 2x, then an optional 3x3 conv
+            h = F.interpolate(h, scale_factor=2, mode="nearest")
+            if cfg.conv_resample:
+                h = F.conv2d(h, sd[p + "conv.weight"], sd[p + "conv.bias"], padding=1)
         else:
             h = attention_block(sd, p, h, kw["heads"], cfg.use_new_attention_order)
     return h
 
 
 def unet_forward(sd: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor,
-                 timesteps: torch.Tensor) -> torch.Tensor:
-    """unet.py:713-742.  x [B,Cin,H,W] fp32 NCHW, timesteps [B] -> [B,Cout,H,W]."""
+                 timesteps: torch.Tensor, y: torch.Tensor = None) -> torch.Tensor:
+    """unet.py:713-742.  x [B,Cin,H,W] fp32 NCHW, timesteps [B] -> [B,Cout,H,W]; y [B] class labels iff num_classes > 0."""
+    assert (y is not None) == (cfg.num_classes > 0), "must specify y if and only if the model is class-conditional"
     lay = build_layout(cfg)
     emb = timestep_embedding(timesteps, cfg.model_channels)
     emb = F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    if cfg.num_classes > 0:
+        emb = emb + sd["label_emb.weight"][y]
     hs = []
     h = x
     for i, layers in enumerate(lay.input_blocks):
@@ -222,6 +236,8 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
     shapes["time_embed.0.bias"] = (ted,)
     shapes["time_embed.2.weight"] = (ted, ted)
     shapes["time_embed.2.bias"] = (ted,)
+    if cfg.num_classes > 0:
+        shapes["label_emb.weight"] = (cfg.num_classes, ted)
 
     def res(p, cin, cout):
         shapes[p + "in_layers.0.weight"] = (cin,)
@@ -263,7 +279,11 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
             chans.append(ch)
             idx += 1
         if level != len(cfg.channel_mult) - 1:
-            res(f"input_blocks.{idx}.0.", ch, ch)
+            if cfg.resblock_updown:
+                res(f"input_blocks.{idx}.0.", ch, ch)
+            elif cfg.conv_resample:
+                shapes[f"input_blocks.{idx}.0.op.weight"] = (ch, ch, 3, 3)
+                shapes[f"input_blocks.{idx}.0.op.bias"] = (ch,)
             chans.append(ch)
             idx += 1
     res("middle_block.0.", ch, ch)
@@ -279,8 +299,11 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
             for j, (kind, _kw) in enumerate(lay.output_blocks[idx][1:], start=1):
                 if kind == "attn":
                     attn(f"output_blocks.{idx}.{j}.", ch)
-                else:
+                elif kind == "res":
                     res(f"output_blocks.{idx}.{j}.", ch, ch)
+                elif cfg.conv_resample:
+                    shapes[f"output_blocks.{idx}.{j}.conv.weight"] = (ch, ch, 3, 3)
+                    shapes[f"output_blocks.{idx}.{j}.conv.bias"] = (ch,)
             idx += 1
     shapes["out.0.weight"] = (ch,)
     shapes["out.0.bias"] = (ch,)

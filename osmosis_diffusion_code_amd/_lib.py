@@ -104,6 +104,9 @@ _SIGS = {
     "osm_maxabs": [_P, _LL, _I, _LL, _I, _P, _P],
     "osm_maxabs_parts": [],
     "osm_conv_kernel_kind": [_I, _I, _I, _I, _I, _I, _I],
+    "osm_stride2_pick": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P],
+    "osm_stride2_place": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P],
+    "osm_add_rowvec": [_P, _LL, _P, _LL, _I, _LL, _I, _P],
     "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "osm_phys_nblk": [_I],
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
@@ -118,7 +121,7 @@ _SIGS = {
 }
 # fp16-storage family (activations as IEEE half, `_h` suffix): same argument lists
 for _n in ("osm_conv2d_nhwc", "osm_gn_stats", "osm_gn_apply", "osm_gn_fwd", "osm_gn_prep", "osm_gn_bwd", "osm_gn_bwd_apply", "osm_pool2x2",
-           "osm_resample_pair", "osm_upsample2x", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
+           "osm_resample_pair", "osm_upsample2x", "osm_stride2_pick", "osm_stride2_place", "osm_add_rowvec", "osm_nchw_to_nhwc", "osm_nhwc_to_nchw", "osm_copy2d"):
     _SIGS[_n + "_h"] = _SIGS[_n]
 _SIGS["osm_half_to_f32"] = [_P, _LL, _P, _LL, _LL, _I, _P]
 _SIGS["osm_f32_to_half"] = [_P, _LL, _P, _LL, _LL, _I, _P]

@@ -75,6 +75,44 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const act_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------- stride-2 pick / place, per-image row vector (round 5)
+// The UNet variants no shipped Osmosis config uses (unet.py:160-219 with use_conv, :329-332 without scale-shift norm):
+//   pick:  y[b][i][j] = x[b][2 i][2 j]            a stride-2 3x3 convolution = the stride-1 convolution, every other pixel kept
+//   place: y[b][2 i][2 j] = x[b][i][j], 0 elsewhere  its adjoint (the gradient of the kept pixels, before the stride-1 data gradient)
+//   rowvec: y[b][p][c] += v[b][c]                  h + emb_out (additive conditioning), emb + label_emb[y]
+template <int MODE>      // 0 pick (x: H x W -> y: H/2 x W/2), 1 place (x: H/2 x W/2 -> y: H x W)
+__global__ __launch_bounds__(256) void stride2_kernel(const act_t* __restrict__ x, long long ldx, act_t* __restrict__ y, long long ldy,
+                                                       int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int oh = MODE == 0 ? Ho : H, ow = MODE == 0 ? Wo : W;
+  const long long total = (long long)B * oh * ow * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int w = (int)(r % ow);
+    r /= ow;
+    const int h = (int)(r % oh);
+    const int b = (int)(r / oh);
+    if (MODE == 0) {
+      osm::st1(y + ((long long)(b * Ho + h) * Wo + w) * ldy + c, osm::ld1(x + ((long long)(b * H + 2 * h) * W + 2 * w) * ldx + c));
+    } else {
+      const bool kept = !(h & 1) && !(w & 1);
+      const float v = kept ? osm::ld1(x + ((long long)(b * Ho + h / 2) * Wo + w / 2) * ldx + c) : 0.f;
+      osm::st1(y + ((long long)(b * H + h) * W + w) * ldy + c, v);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void add_rowvec_kernel(act_t* __restrict__ y, long long ldy, const float* __restrict__ v, long long ldv,
+                                                          int B, long long HW, int C) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    act_t* d = y + row * ldy + c;
+    osm::st1(d, osm::ld1(d) + v[(row / HW) * ldv + c]);
+  }
+}
+
 // ---------------------------------------------------------------- layout
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, act_t* __restrict__ y,
                                                             long long ldy, int B, int C, int HW) {
@@ -349,6 +387,31 @@ extern "C" int OSM_FN(osm_upsample2x)(const abi_act_t* x_, long long ldx, abi_ac
   else
     hipLaunchKernelGGL((upsample2x_kernel<1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, scale);
   return osm::check_launch("upsample2x_kernel");
+}
+
+extern "C" int OSM_FN(osm_stride2_pick)(const abi_act_t* x_, long long ldx, abi_act_t* y_, long long ldy, int B, int H, int W, int C,
+                                        void* stream) {
+  OSM_REQUIRE(x_ && y_, "osm_stride2_pick: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "osm_stride2_pick: H, W must be even");
+  hipLaunchKernelGGL((stride2_kernel<0>), dim3(grid_for((long long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream,
+                     OSM_CACT(x_), ldx, OSM_ACT(y_), ldy, B, H, W, C);
+  return osm::check_launch("stride2_kernel<0>");
+}
+extern "C" int OSM_FN(osm_stride2_place)(const abi_act_t* x_, long long ldx, abi_act_t* y_, long long ldy, int B, int H, int W, int C,
+                                         void* stream) {
+  OSM_REQUIRE(x_ && y_, "osm_stride2_place: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "osm_stride2_place: H, W (of the OUTPUT) must be even");
+  hipLaunchKernelGGL((stride2_kernel<1>), dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                     OSM_CACT(x_), ldx, OSM_ACT(y_), ldy, B, H, W, C);
+  return osm::check_launch("stride2_kernel<1>");
+}
+extern "C" int OSM_FN(osm_add_rowvec)(abi_act_t* y_, long long ldy, const float* v, long long ldv, int B, long long HW, int C,
+                                      void* stream) {
+  OSM_REQUIRE(y_ && v, "osm_add_rowvec: null pointer");
+  OSM_REQUIRE(B > 0 && C > 0 && HW > 0 && ldv >= C, "osm_add_rowvec: bad shape");
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, OSM_ACT(y_), ldy, v,
+                     ldv, B, HW, C);
+  return osm::check_launch("add_rowvec_kernel");
 }
 
 // Two tensors of the same shape resampled by ONE launch (an up / down ResBlock resamples its input and its normalised input,

@@ -74,6 +74,7 @@ class _Norm:
 class _Res:
     def __init__(self, p, dev, wfmt=0):
         self.cin, self.cout, self.up, self.down = p.cin, p.cout, p.up, p.down
+        self.scale_shift = bool(getattr(p, "scale_shift", True))     # False: h + emb_out before the second GroupNorm (unet.py:331-332)
         self.n1 = _Norm(p.in_layers.at(0), dev)
         self.c1 = _Conv(p.in_layers.at(2), dev, wfmt)
         e = p.emb_layers.at(1)
@@ -82,6 +83,22 @@ class _Res:
         self.n2 = _Norm(p.out_layers.at(0), dev)
         self.c2 = _Conv(p.out_layers.at(3), dev, wfmt)
         self.skip = _Conv(p.skip_connection, dev, wfmt) if p.skip_connection is not None else None
+
+
+class _Down:
+    """Downsample as a layer of its own (resblock_updown=False; unet.py:192-219): 3x3 conv at stride 2, or 2x2 average pooling."""
+
+    def __init__(self, p, dev, wfmt=0):
+        self.ch = p.ch
+        self.conv = _Conv(p.op, dev, wfmt) if p.use_conv else None
+
+
+class _Up:
+    """Upsample as a layer of its own (unet.py:160-189): nearest 2x, then an optional 3x3 conv."""
+
+    def __init__(self, p, dev, wfmt=0):
+        self.ch = p.ch
+        self.conv = _Conv(p.conv, dev, wfmt) if p.use_conv else None
 
 
 class _Attn:
@@ -109,11 +126,15 @@ class UNetWeights:
         self.arch = describe_architecture(model)
 
         def wrap(m):
-            from .guided_diffusion.unet import AttentionParams, ResBlockParams
+            from .guided_diffusion.unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams
             if isinstance(m, ResBlockParams):
                 return _Res(m, dev, wfmt)
             if isinstance(m, AttentionParams):
                 return _Attn(m, dev, wfmt)
+            if isinstance(m, DownsampleParams):
+                return _Down(m, dev, wfmt)
+            if isinstance(m, UpsampleParams):
+                return _Up(m, dev, wfmt)
             return _Conv(m, dev, wfmt)
 
         def seq(s):
@@ -122,6 +143,7 @@ class UNetWeights:
         te = model.time_embed
         self.te0 = (te.at(0).weight.detach().to(dev).contiguous(), te.at(0).bias.detach().to(dev).contiguous())
         self.te2 = (te.at(2).weight.detach().to(dev).contiguous(), te.at(2).bias.detach().to(dev).contiguous())
+        self.num_classes = getattr(model, "num_classes", None)      # class-conditional: the engine adds label_emb rows to emb
         self.inp = [seq(s) for s in model.input_blocks]
         self.mid = seq(model.middle_block)
         self.outb = [seq(s) for s in model.output_blocks]
@@ -135,7 +157,8 @@ class UNetWeights:
         off = 0
         for m in res_blocks:
             m.film_off = off
-            off += 2 * m.cout
+            m.film_cols = (2 if m.scale_shift else 1) * m.cout     # (scale | shift), or the additive emb_out alone
+            off += m.film_cols
         self.film_cols = off
         self.ew_all = torch.cat([m.ew for m in res_blocks], 0).contiguous()
         self.eb_all = torch.cat([m.eb for m in res_blocks], 0).contiguous()
@@ -146,13 +169,15 @@ class UNetWeights:
 def describe_architecture(model) -> dict:
     """Shapes-only description of a UNetModel (no device work): per block sequence, ('res', cin, cout, up, down) /
     ('attn', ch, heads) entries; what `activation_bytes_per_image` walks."""
-    from .guided_diffusion.unet import AttentionParams, ResBlockParams
+    from .guided_diffusion.unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams
 
     def seq(s):
         out = []
         for _, m in sorted(((int(k), v) for k, v in s._modules.items()), key=lambda kv: kv[0]):
             if isinstance(m, ResBlockParams):
                 out.append(("res", m.cin, m.cout, m.up, m.down))
+            elif isinstance(m, (DownsampleParams, UpsampleParams)):      # costed like an up / down ResBlock (an upper bound)
+                out.append(("res", m.ch, m.ch, isinstance(m, UpsampleParams), isinstance(m, DownsampleParams)))
             elif isinstance(m, AttentionParams):
                 out.append(("attn", m.ch, m.heads))
             else:
@@ -288,6 +313,8 @@ class UNetEngine:
         self.d_out = torch.zeros(B, self.cout, H, W, **f32)
         self.dx = torch.zeros(B, self.cin, H, W, **f32)
         self.gn_part = torch.empty(B * ops.gn_nchunk(H * W) * G * 2, **f32)
+        self.num_classes = getattr(weights, "num_classes", None)
+        self.label_rows = torch.zeros(B, self.ted, **f32) if self.num_classes is not None else None   # label_emb[y], set per call
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, rows, cols, dtype=None) -> Mat:
@@ -519,8 +546,8 @@ class UNetEngine:
             h1 = self._buf(Mo, blk.cout)
             fuse2 = self._gn_fusable(blk.c2, (ho, wo))
             tab1 = None
-            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo), stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None,
-                             xmax=xm1)
+            cs1 = self._conv(a1r, blk.c1, h1, (ho, wo),
+                             stat=("fwd",) if (blk.scale_shift and self._gn_stats_from_conv(blk.c2, (ho, wo))) else None, xmax=xm1)
         else:
             ho, wo = H, W
             xs = x
@@ -537,10 +564,14 @@ class UNetEngine:
                     not self._gn_fusable(blk.c1, hw) and ops.gn_nchunk(HW) <= ops.MAXABS_PARTS:
                 xin = self._xmax_slot("skip")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
-                                stat=("fwd",) if self._gn_stats_from_conv(blk.c2, (ho, wo)) else None, xin_max=xin)
+                                stat=("fwd",) if (blk.scale_shift and self._gn_stats_from_conv(blk.c2, (ho, wo))) else None,
+                                xin_max=xin)
             if blk.skip is not None:
                 self._conv(xs, blk.skip, dst, (ho, wo), ws_slot="splitk2", xmax=xin)
-        film = self.film_all[:, blk.film_off:blk.film_off + 2 * blk.cout]
+        film = self.film_all[:, blk.film_off:blk.film_off + blk.film_cols]
+        if not blk.scale_shift:     # additive conditioning (unet.py:331-332): h = h + emb_out, then GroupNorm / SiLU / conv without FiLM
+            ops.add_rowvec(h1, film, self.film_all.stride(0), B, ho * wo)
+            film, cs1 = None, None
         st2 = self._small(B * G * 2)
         if blk.skip is not None:
             res = dst
@@ -747,6 +778,56 @@ class UNetEngine:
         self._gn_bwd(s["x"], dxn, dx_dst, T, s["st"], blk.norm, gst, silu=False, addend=dy,
                      addend2=dx_dst if accumulate else None)
 
+    # ------------------------------------------------------------------ Upsample / Downsample as layers (resblock_updown=False)
+    def _resample_fwd(self, l, x: Mat, dst: Mat, hw):
+        """Downsample: 3x3 conv at stride 2 = the stride-1 convolution (any of the 3x3 kernels) with every other pixel kept, or
+        2x2 average pooling; Upsample: nearest 2x, then the 3x3 conv (unet.py:160-219).  These variants are not on any shipped
+        config: the stride-2 form spends 4x the multiplies of a dedicated kernel on five layers."""
+        B = self.B
+        H, W = hw
+        self._xmax_invalidate(dst)
+        if isinstance(l, _Down):
+            ho = (H // 2, W // 2)
+            if l.conv is not None:
+                full = self._scr("a", B * H * W, l.ch)
+                self._conv(x, l.conv, full, hw)
+                ops.stride2_pick(full, dst, B, H, W)
+            else:
+                ops.pool2x2(x, dst, B, H, W, 0.25)
+        else:
+            ho = (2 * H, 2 * W)
+            if l.conv is not None:
+                u = self._scr("a", B * ho[0] * ho[1], l.ch)
+                ops.upsample2x(x, u, B, H, W, 1.0)
+                self._conv(u, l.conv, dst, ho)
+            else:
+                ops.upsample2x(x, dst, B, H, W, 1.0)
+        self._saved[id(l)] = dict(x=x, hw=hw, hwo=ho)
+        return ho
+
+    def _resample_bwd(self, l, dy: Mat, dx_dst: Mat, accumulate: bool):
+        s = self._saved[id(l)]
+        B = self.B
+        H, W = s["hw"]
+        ho, wo = s["hwo"]
+        self._xmax_invalidate(dx_dst)
+        if l.conv is not None and isinstance(l, _Down):       # adjoint of "keep every other pixel", then the stride-1 data gradient
+            df = self._scr("a", B * H * W, l.ch)
+            ops.stride2_place(dy, df, B, H, W)
+            self._conv(df, l.conv, dx_dst, (H, W), dgrad=True, accumulate=accumulate)
+            return
+        tgt = dx_dst if not accumulate else self._scr("b", B * H * W, l.ch)
+        if isinstance(l, _Down):                                # average pooling: replicate / 4
+            ops.upsample2x(dy, tgt, B, ho, wo, 0.25)
+        else:
+            src = dy
+            if l.conv is not None:
+                src = self._scr("a", B * ho * wo, l.ch)
+                self._conv(dy, l.conv, src, (ho, wo), dgrad=True)
+            ops.pool2x2(src, tgt, B, ho, wo, 1.0)               # nearest 2x: the gradient is the 2x2 sum
+        if accumulate:
+            ops.copy2d(tgt, dx_dst, accumulate=True)
+
     # ------------------------------------------------------------------ whole network
     @staticmethod
     def _out_ch(layers, cin):
@@ -766,6 +847,10 @@ class UNetEngine:
             elif isinstance(l, _Attn):
                 d = dst if last else self._buf(h.rows, l.ch)
                 hw = self._attn_fwd(l, h, d, hw)
+            elif isinstance(l, (_Down, _Up)):
+                ho = (hw[0] // 2, hw[1] // 2) if isinstance(l, _Down) else (hw[0] * 2, hw[1] * 2)
+                d = dst if last else self._buf(self.B * ho[0] * ho[1], l.ch)
+                hw = self._resample_fwd(l, h, d, hw)
             else:
                 raise AssertionError
             h = d
@@ -780,8 +865,10 @@ class UNetEngine:
             acc = accumulate if first else False
             if isinstance(l, _Res):
                 self._res_bwd(l, dy, d, acc)
-            else:
+            elif isinstance(l, _Attn):
                 self._attn_bwd(l, dy, d, acc)
+            else:
+                self._resample_bwd(l, dy, d, acc)
             dy = d
 
     def _forward_impl(self):
@@ -794,6 +881,8 @@ class UNetEngine:
         ops.linear(temb, self.te0[0], self.te0[1], e1, B, self.mc, self.ted, silu_out=True)
         self.emb = torch.empty(B, self.ted, **f32)
         ops.linear(e1, self.te2[0], self.te2[1], self.emb, B, self.ted, self.ted)
+        if self.label_rows is not None:          # class-conditional: emb = emb + label_emb(y) (unet.py:729-731)
+            ops.add_rowvec(Mat.of(self.emb), self.label_rows, self.ted, B, 1)
         self.film_all = torch.empty(B, self.film_cols, **f32)
         ops.linear(self.emb, self.ew_all, self.eb_all, self.film_all, B, self.ted, self.film_cols, silu_in=True)
 
@@ -811,7 +900,7 @@ class UNetEngine:
         hw = (H, W)
         for layers in self.inp:
             for l in layers:
-                if isinstance(l, _Res) and l.down:
+                if (isinstance(l, _Res) and l.down) or isinstance(l, _Down):
                     hw = (hw[0] // 2, hw[1] // 2)
             hws.append(hw)
         c_h = c_mid

@@ -330,6 +330,21 @@ def resample_pair(up: bool, x1: Mat, y1: Mat, x2: Mat, y2: Mat, B, H, W, scale):
          B, H, W, x1.cols, scale, _s(), keep=(x1.t, y1.t, x2.t, y2.t))
 
 
+def stride2_pick(x: Mat, y: Mat, B, H, W):
+    """y[b][i][j] = x[b][2i][2j]  (x: [B*H*W][C] -> y: [B*(H/2)*(W/2)][C]): a stride-2 convolution from its stride-1 result."""
+    call("osm_stride2_pick" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, H, W, x.cols, _s(), keep=(x.t, y.t))
+
+
+def stride2_place(x: Mat, y: Mat, B, H, W):
+    """y[b][2i][2j] = x[b][i][j], zero elsewhere (H, W: the output's): the adjoint of stride2_pick."""
+    call("osm_stride2_place" + _same_family(x.t, y.t), x.p, x.ld, y.p, y.ld, B, H, W, x.cols, _s(), keep=(x.t, y.t))
+
+
+def add_rowvec(y: Mat, v: torch.Tensor, ldv: int, B, HW):
+    """y[b][p][c] += v[b][c] (v fp32 [B][ldv])."""
+    call("osm_add_rowvec" + _fam(y.t), y.p, y.ld, ptr(v), ldv, B, HW, y.cols, _s(), keep=(y.t, v))
+
+
 def nchw_to_nhwc(x, y: Mat, B, Cc, HW):
     call("osm_nchw_to_nhwc" + _fam(y.t), ptr(x), y.p, y.ld, B, Cc, HW, _s(), keep=(x, y.t))
 

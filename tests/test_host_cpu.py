@@ -375,3 +375,26 @@ def test_xmax_registry_forgets_a_bound_when_someone_else_writes_the_buffer():
     eng._xmax_register(full, slot)
     eng._xmax_register(right, slot2)                   # registering a slice replaces whatever covered that memory
     assert eng._xmax_lookup(full) is None and eng._xmax_lookup(right) is slot2
+
+
+def test_unet_variants_have_the_reference_keys_and_a_memory_estimate():
+    """Round 5: every UNetModel option create_model can reach builds (Upsample / Downsample layers with or without a convolution,
+    additive conditioning, class conditioning, dropout accepted and inert); state_dict keys / shapes equal the oracle's list (which
+    gen_golden.py loads strictly into the REAL reference module); the dry-run activation estimate covers the new layer kinds."""
+    from osmosis_diffusion_code_amd.engine import activation_bytes_per_image, describe_architecture
+    from osmosis_diffusion_code_amd.guided_diffusion.unet import UNetModel
+    base = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+                num_head_channels=16, num_heads=4, learn_sigma=True, pretrain_model="osmosis")
+    for extra in (dict(resblock_updown=False, use_scale_shift_norm=False), dict(resblock_updown=False, use_scale_shift_norm=True,
+                  class_cond=True, dropout=0.1), dict(resblock_updown=True, use_scale_shift_norm=False), dict()):
+        kw = dict(base, **extra)
+        m = unet.create_model(**kw)
+        want = U.param_shapes(U.UNetConfig.from_create_model_kwargs(**kw))
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == want, (extra, set(got) ^ set(want))
+        assert activation_bytes_per_image(describe_architecture(m), 64, 64) > 0
+    m = UNetModel(image_size=64, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+                  channel_mult=(1, 2), conv_resample=False, num_head_channels=16)       # conv-less resampling layers: no parameters
+    assert not any(".op." in k or k.endswith(".conv.weight") for k in m.state_dict())
+    with pytest.raises(NotImplementedError):
+        UNetModel(image_size=64, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), dims=3)

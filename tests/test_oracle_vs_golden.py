@@ -241,3 +241,25 @@ def test_full_size_guided_steps_oracle_vs_reference_golden(fname, cfg_name):
     assert np.allclose(np.asarray(loss).ravel(), g["final_loss"].ravel(), rtol=1e-4)
     for k, v in variables.items():
         assert np.allclose(v.detach().numpy().ravel(), g["final." + k].ravel(), atol=5e-6), k
+
+
+VARIANT_KW = {
+    "conv_updown_additive": dict(TINY_KW, resblock_updown=False, use_scale_shift_norm=False),
+    "conv_updown_classcond": dict(TINY_KW, resblock_updown=False, class_cond=True, dropout=0.1),
+    "resblock_updown_additive": dict(TINY_KW, use_scale_shift_norm=False),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANT_KW))
+def test_unet_variants_no_shipped_config_uses(tag):
+    """Round 5: Upsample / Downsample layers with convolutions (resblock_updown=False), additive conditioning
+    (use_scale_shift_norm=False), class conditioning -- the oracle vs the real reference (unet_variants.npz)."""
+    g = load("unet_variants.npz")
+    cfg = U.UNetConfig.from_create_model_kwargs(**VARIANT_KW[tag])
+    sd = U.seeded_state_dict(cfg, 4321)
+    assert sum(v.numel() for v in sd.values()) == int(g[f"{tag}.n_params"])
+    x = T(g[f"{tag}.x"]).requires_grad_(True)
+    y = U.unet_forward(sd, cfg, x, T(g[f"{tag}.t"]), y=T(g[f"{tag}.labels"]) if f"{tag}.labels" in g else None)
+    (dx,) = torch.autograd.grad((y * T(g[f"{tag}.w"])).sum(), x)
+    assert torch.allclose(y, T(g[f"{tag}.y"]), atol=5e-6), float((y - T(g[f"{tag}.y"])).abs().max())
+    assert torch.allclose(dx, T(g[f"{tag}.dx"]), atol=2e-5), float((dx - T(g[f"{tag}.dx"])).abs().max())
