@@ -292,9 +292,12 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_kernel(FlashArgs a) {
 // dk, dv: grid (T / 32, heads, B): workgroup = 32 keys, waves split the queries.
 //   S = (scale Q) K^T (queries x keys: column = this lane's key), P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q]);
 //   dv^T[d][key] = sum_q dO^T[d][q] P[q][key];   dk^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
-template <int NP, int WV>
+// KVL: the K / V fragments of the workgroup's 32 keys (2 x 4 k16-steps x NP planes, 24 KB for bf16x6) live in LDS -- aliased with the
+// combine buffer, which is only written after the loop -- instead of 96 registers per lane: the bf16x6 instance then fits two waves
+// per SIMD (WV = 8: 250 registers; with the fragments resident it needs 368 and runs one wave per SIMD with nothing to hide its loads).
+template <int NP, int WV, bool KVL = false>
 __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
-  __shared__ float os[WV][2 * DH][33];
+  __shared__ __attribute__((aligned(16))) float os[WV][2 * DH][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int k0r = blockIdx.x * 32, hd = blockIdx.y;
   const long long rb = (long long)blockIdx.z * a.T;
@@ -306,11 +309,23 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
   const float* __restrict__ lsep = a.lse + ((long long)blockIdx.z * a.heads + hd) * a.T;
   const float* __restrict__ dlp = a.delta + ((long long)blockIdx.z * a.heads + hd) * a.T;
 
-  uint4 kf[4][NP], vf[4][NP];   // B operands (k = d, column = key)
+  uint4 kf[KVL ? 1 : 4][NP], vf[KVL ? 1 : 4][NP];   // B operands (k = d, column = key); KVL: one k16-step at a time, from LDS
+  uint4* kvs = reinterpret_cast<uint4*>(&os[0][0][0]);      // KVL: [K | V][k16-step][plane][lane]
+  if constexpr (KVL) {
+    static_assert(sizeof(os) >= 2 * 4 * NP * 64 * sizeof(uint4), "the fragments alias the combine buffer");
+    for (int f = wave; f < 8; f += WV) {           // fragment f = (K | V, k16-step): split once per workgroup, by one wave each
+      uint4 t[NP];
+      frag_row(f < 4 ? K : V, ld, rb + k0r + lr, 0, f & 3, h, 1.f, t);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    frag_row(K, ld, rb + k0r + lr, 0, s, h, 1.f, kf[s]);
-    frag_row(V, ld, rb + k0r + lr, 0, s, h, 1.f, vf[s]);
+      for (int q = 0; q < NP; ++q) kvs[(f * NP + q) * 64 + lane] = t[q];
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      frag_row(K, ld, rb + k0r + lr, 0, s, h, 1.f, kf[s]);
+      frag_row(V, ld, rb + k0r + lr, 0, s, h, 1.f, vf[s]);
+    }
   }
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
   const int qw = a.T / a.nw;
@@ -322,12 +337,20 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
       uint4 qf[NP], gf[NP];
       frag_row(Q, ld, rb + qb + lr, 0, s, h, a.scale, qf);
       frag_row(dO, a.lddout, rb + qb + lr, 0, s, h, 1.f, gf);
+      if constexpr (KVL) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          kf[0][q] = kvs[(s * NP + q) * 64 + lane];
+          vf[0][q] = kvs[((4 + s) * NP + q) * 64 + lane];
+        }
+      }
+      const int si = KVL ? 0 : s;
 #pragma unroll
       for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
         for (int pb = NP - 1 - pa; pb >= 0; --pb) {
-          sc = mma16<NP>(qf[pa], kf[s][pb], sc);
-          dp = mma16<NP>(gf[pa], vf[s][pb], dp);
+          sc = mma16<NP>(qf[pa], kf[si][pb], sc);
+          dp = mma16<NP>(gf[pa], vf[si][pb], dp);
         }
     }
     // rows of the C layout are queries: q = qb + (e&3) + 8 (e>>2) + 4 h
@@ -345,24 +368,37 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      uint4 pf[NP], sf[NP], g0[NP], g1[NP], q0f[NP], q1f[NP];
-      frag_acc(sc, t, pf);
-      frag_acc(dp, t, sf);
-      frag_gather(dO, a.lddout, rb + qb, lr, t, h, g0);
-      frag_gather(dO, a.lddout, rb + qb, 32 + lr, t, h, g1);
-      frag_gather(Q, ld, rb + qb, lr, t, h, q0f);
-      frag_gather(Q, ld, rb + qb, 32 + lr, t, h, q1f);
+      {   // dv^T += dO^T P        (the two halves of a step kept apart: fewer fragments live at once -- no spill at 256 registers)
+        uint4 pf[NP], g0[NP], g1[NP];
+        frag_acc(sc, t, pf);
+        frag_gather(dO, a.lddout, rb + qb, lr, t, h, g0);
+        frag_gather(dO, a.lddout, rb + qb, 32 + lr, t, h, g1);
 #pragma unroll
-      for (int pa = NP - 1; pa >= 0; --pa)
+        for (int pa = NP - 1; pa >= 0; --pa)
 #pragma unroll
-        for (int pb = NP - 1 - pa; pb >= 0; --pb) {
-          dv0 = mma16<NP>(g0[pa], pf[pb], dv0);
-          dv1 = mma16<NP>(g1[pa], pf[pb], dv1);
-          dk0 = mma16<NP>(q0f[pa], sf[pb], dk0);
-          dk1 = mma16<NP>(q1f[pa], sf[pb], dk1);
-        }
+          for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+            dv0 = mma16<NP>(g0[pa], pf[pb], dv0);
+            dv1 = mma16<NP>(g1[pa], pf[pb], dv1);
+          }
+      }
+      if constexpr (KVL) __builtin_amdgcn_sched_barrier(0);
+      {   // dk^T += Q^T dS
+        uint4 sf[NP], q0f[NP], q1f[NP];
+        frag_acc(dp, t, sf);
+        frag_gather(Q, ld, rb + qb, lr, t, h, q0f);
+        frag_gather(Q, ld, rb + qb, 32 + lr, t, h, q1f);
+#pragma unroll
+        for (int pa = NP - 1; pa >= 0; --pa)
+#pragma unroll
+          for (int pb = NP - 1 - pa; pb >= 0; --pb) {
+            dk0 = mma16<NP>(q0f[pa], sf[pb], dk0);
+            dk1 = mma16<NP>(q1f[pa], sf[pb], dk1);
+          }
+      }
+      if constexpr (KVL) __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if constexpr (KVL) __syncthreads();     // every wave's last fragment read is over before the combine buffer overwrites them
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -460,10 +496,16 @@ extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long
     constexpr int P = decltype(np)::value;
     if (a.nw == 8) hipLaunchKernelGGL((flash_bwd_q_kernel<P, 8>), g, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((flash_bwd_q_kernel<P, 4>), g, dim3(256), 0, st, a);
-    // (the bf16x6 dk / dv kernel holds K, V fragments and four accumulators: 368 registers -- it stays at one wave per SIMD)
+    // the dk / dv kernel: with K, V fragments resident it needs 368 registers (bf16x6) = one wave per SIMD; with the fragments in
+    // LDS (KVL) eight waves = two per SIMD split the queries (round 5: attention class 0.99 -> 0.95 ms; OSM_FLASH_KV_LDS=0: the old form)
+    static const bool kv_lds = [] { const char* e = std::getenv("OSM_FLASH_KV_LDS"); return !(e && atoi(e) == 0); }();
     FlashArgs b = a;
-    if (b.nw > 4) b.nw = 4;
-    hipLaunchKernelGGL((flash_bwd_kv_kernel<P, 4>), g, dim3(256), 0, st, b);
+    if (kv_lds && b.nw == 8) {
+      hipLaunchKernelGGL((flash_bwd_kv_kernel<P, 8, true>), g, dim3(512), 0, st, b);
+    } else {
+      if (b.nw > 4) b.nw = 4;
+      hipLaunchKernelGGL((flash_bwd_kv_kernel<P, 4>), g, dim3(256), 0, st, b);
+    }
   };
   if (d->arith == 1) launch(std::integral_constant<int, 1>{});
   else launch(std::integral_constant<int, 3>{});
