@@ -59,6 +59,28 @@ def main():
         after[(p[:50], n[:50])] += g
     for (p, n), v in after.most_common(15):
         print(f"  {v / 1e6:7.2f} ms idle between  {p}  ->  {n}")
+    # ---- split-K combines (VERDICT r04 item 4 iii): is a combine hidden behind its producer?  For every splitk_reduce* launch: its
+    # duration, the idle gap in front of it (producer end -> combine start) and how much of it ran while the producer was still running
+    tot = {"n": 0, "dur": 0, "gap": 0, "overlap": 0, "after": 0}
+    by = Counter()
+    for k in range(1, len(win) - 1):
+        s0, e0, n = win[k]
+        if "splitk_reduce" not in n:
+            continue
+        ps, pe, pn = win[k - 1]
+        ns = win[k + 1][0]
+        tot["n"] += 1
+        tot["dur"] += e0 - s0
+        tot["gap"] += max(0, s0 - pe)
+        tot["overlap"] += max(0, min(e0, pe) - s0)
+        tot["after"] += max(0, ns - e0)
+        short = pn.replace("void ", "").replace("(anonymous namespace)::", "")
+        by[short[:short.index("(")] if "(" in short else short] += 1
+    if tot["n"]:
+        print(f"split-K combines per step: {tot['n'] / steps:.1f} launches, kernel time {tot['dur'] / 1e6 / steps:.3f} ms, idle gap producer -> "
+              f"combine {tot['gap'] / 1e6 / steps:.3f} ms, time overlapped with the producer {tot['overlap'] / 1e6 / steps:.3f} ms, idle gap combine -> "
+              f"next kernel {tot['after'] / 1e6 / steps:.3f} ms")
+        print("  producers:", dict(by.most_common(6)))
 
 
 if __name__ == "__main__":
