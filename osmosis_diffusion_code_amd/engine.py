@@ -1076,9 +1076,10 @@ class BlockEngine(UNetEngine):
         ted = blk.ew.shape[1] if is_res else 1
         if is_res:
             blk.film_off = 0
+            blk.film_cols = (2 if blk.scale_shift else 1) * blk.cout
         w = types.SimpleNamespace(dev=dev, conv_mode=conv_mode, mc=cin, ted=ted, cin=cin, cout=cout, nlev=1, te0=None, te2=None,
                                   inp=[], mid=[blk], outb=[], out_norm=None, out_conv=None,
-                                  film_cols=2 * cout if is_res else 0,
+                                  film_cols=blk.film_cols if is_res else 0,
                                   ew_all=blk.ew if is_res else None, eb_all=blk.eb if is_res else None, arch=None)
         super().__init__(w, B, H, W)
         self.block, self.is_res = blk, is_res

@@ -308,7 +308,13 @@ class RankSync:
         if self.world == 1:
             return
         import os
-        for path in self._mine:         # (peers have read a round's files before they could enter the next one)
+        # Files of every round but the LAST are removed: a peer has read round k's files before it could enter round k + 1, but a
+        # slower peer may still be polling for this rank's file of the last round (removing it made that peer wait for its timeout:
+        # seen once in the GPU suite).  The last round's few bytes stay until the next job's rank 0 empties the directory.
+        keep = ("b%d_r" % self._round, "g%d_r" % self._round)
+        for path in self._mine:
+            if os.path.basename(path).startswith(keep):
+                continue
             try:
                 os.remove(path)
             except OSError:
