@@ -46,7 +46,8 @@ def main():
         k = k[:k.index("(")] if "(" in k else k
         per[k] += e0 - s0
         cnt[k] += 1
-    steps = max(1, round(nfin / 21))
+    npost = sum(1 for r in win if "posterior_kernel" in r[2])      # one per guided step
+    steps = npost if npost else max(1, round(nfin / 21))
     print(f"per step (~{steps} steps in the window): kernel time by kernel")
     for k, v in per.most_common(40):
         print(f"  {v / 1e6 / steps:7.3f} ms  {cnt[k] / steps:7.1f} launches  {v / cnt[k] / 1e3:7.1f} us  {k}")
