@@ -13,6 +13,11 @@ import sys
 from collections import Counter
 
 
+def short_name(n):
+    n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n[:n.index("(")] if "(" in n else n
+
+
 def main():
     files = [f for a in sys.argv[1:] for f in glob.glob(a, recursive=True)]
     rows = []
@@ -82,6 +87,14 @@ def main():
               f"combine {tot['gap'] / 1e6 / steps:.3f} ms, time overlapped with the producer {tot['overlap'] / 1e6 / steps:.3f} ms, idle gap combine -> "
               f"next kernel {tot['after'] / 1e6 / steps:.3f} ms")
         print("  producers:", dict(by.most_common(6)))
+        # what consumes a combined tensor next (a GroupNorm that follows could do the combine in its own load stage)
+        nxt = Counter()
+        for k in range(1, len(win) - 1):
+            if "splitk_reduce" in win[k][2]:
+                nn = win[k + 1][2].replace("void ", "").replace("(anonymous namespace)::", "")
+                nxt[(short_name(win[k][2]), nn[:nn.index("(")] if "(" in nn else nn)] += 1
+        for (a, b), v in nxt.most_common(30):
+            print(f"  {v / steps:6.1f} per step  {a}  ->  {b}")
 
 
 if __name__ == "__main__":
