@@ -47,7 +47,8 @@ const char* osm_last_error(void);
  *                             LDS, weight fragments straight from L2; 8 x 8 images by its PH = 8 instance), 1x1 layers and
  *                             ragged shapes by igemm_bf16s_kernel;
  *   wfmt 4                    "f16x3": both operands as two IEEE-half planes after power-of-two scaling (~22-bit operands), three
- *                             v_mfma_f32_32x32x16_f16 per product: 1x1 layers with H * W >= 4096 by igemm_bf16s_kernel<1,2,true>;
+ *                             v_mfma_f32_32x32x16_f16 per product: 1x1 layers (H * W a multiple of 128) by igemm_bf16s_kernel<1,2,true>,
+ *                             3x3 layers with H, W >= 8 by conv3_halo_bf16s_kernel<2,...,HP> (the 8 x 8 layers of the sampler);
  *   wfmt | OSM_WFMT_WINOGRAD  3x3 layers with H, W >= 16 by conv3_wino8_kernel: Winograd F(2x2, 3x3), 16 x 16 pixels x 64
  *                             output channels per workgroup, input transform in the registers that feed the MFMA, 16/36 of the
  *                             direct kernel's multiplies -- with wfmt 4 the default of the sampler (the dominant kernel of a step);
@@ -73,8 +74,8 @@ typedef struct osm_conv_desc {
                           1 = one fp16 plane (fp16 x fp16 -> fp32 MFMA): the fp16 family only, see the end of this file;
                           4 = "f16x3": two IEEE-half planes per operand, both operands scaled into the fp16 range by powers of
                           two (~22-bit operands, three fp16 MFMAs per product); needs x_maxabs, refuses gn_table.  3x3 layers:
-                          4 | OSM_WFMT_WINOGRAD (osm_pack_conv_weight_winograd); 1x1 layers: plain 4 (osm_pack_conv_weight_bf16s),
-                          H * W a multiple of 128 */
+                          4 | OSM_WFMT_WINOGRAD (osm_pack_conv_weight_winograd; H, W >= 16) or plain 4 (osm_pack_conv_weight_bf16s:
+                          the direct halo-tile kernel, H, W >= 8); 1x1 layers: plain 4, H * W a multiple of 128 */
   const float* gn_table; /* optional fused input transform (3x3, split-bf16 formats, W >= 8, H >= 8 only):
                           x' = act(((x - mean_c) * rstd_c) * g_c + b_c) applied while staging, zero padding AFTER it
                           (= conv(SiLU(GroupNorm+FiLM(x)))).  [B][4][Cin] = mean | rstd | g | b rows from

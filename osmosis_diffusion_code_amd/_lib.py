@@ -174,6 +174,19 @@ class Recorder:
         _state.recorders.pop()
         return False
 
+    @staticmethod
+    def suspended():
+        """Context manager: calls made inside run now and are NOT recorded (one-off work a recording pass triggers, e.g. a weight
+        image packed on first use -- it must not be replayed with every step)."""
+        class _Suspend:
+            def __enter__(self_):
+                self_.saved, _state.recorders = _state.recorders, []
+
+            def __exit__(self_, *exc):
+                _state.recorders = self_.saved
+                return False
+        return _Suspend()
+
     def replay(self):
         """Launch by launch on the stream the calls were recorded on."""
         for c in self.calls:

@@ -43,7 +43,11 @@ template <int PW, int PH = 8> struct HaloGeom {
 // LDS feeds a single MFMA per column tile -- 1 KB of LDS reads per MFMA, i.e. the CU's whole LDS bandwidth at the matrix rate.  Two
 // column tiles per wave (workgroup = 128 rows x 256 columns, 8 accumulators per wave) halve that; the weight-fragment traffic per
 // MFMA stays what it was (a fragment still feeds the 4 row blocks).
-template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8, bool NARROW = false, int NT = 1>
+// HP ("f16x3", NP = 2; round 5: the 8 x 8 layers, where the Winograd kernel does not apply): the two planes are IEEE halves of
+// x * 2^ex (2^ex from the per-image max |x|, IGemmParams::xmax) against a weight image of halves of w * 2^ew behind its scale word
+// -- three fp16 MFMAs per product instead of six bf16 ones and 4 instead of 6 bytes of weight stream per weight; the accumulators
+// are rescaled (exactly, by a power of two) before the epilogue.  A patch belongs to one image, so one scale per workgroup.
+template <int NP, bool GNF, int PW = 16, int BR = 3, int PH = 8, bool NARROW = false, int NT = 1, bool HP = false>
 __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel(const act_t* __restrict__ Aglob,
                                                                    const unsigned short* __restrict__ Bglob,
                                                                    IGemmParams p) {
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   static_assert(PH == 8, "patches are 8 x 8 or 8 x 16 (the 16 x 16 variant of round 2 lost everywhere but one layer and was removed)");
   static_assert(!NARROW || (PW == 16 && PH == 8), "the narrow variant works on 8 x 16 patches");
   static_assert(NT == 1 || (NT == 2 && PW == 16 && !NARROW), "two column tiles per wave: 8 x 16 patches only");
+  static_assert(!HP || (NP == 2 && !GNF && !OSM_ACT_IS_F16), "f16x3: two half planes, fp32 activations, no fused GroupNorm (x_maxabs is the range of x)");
   using GEO = HaloGeom<PW, PH>;
   constexpr int HALO_W = GEO::HW, HALO_P = GEO::HP, HALO_PIX = GEO::PIX, H_PLANE = GEO::PLANE, NJ = GEO::NJ,
                 RB = GEO::RB;
@@ -75,6 +80,25 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   const int per = (nslab + p.splitk - 1) / p.splitk;
   const int kc0 = ks * per;
   const int kc1 = min(nslab, kc0 + per);
+
+  float xscale = 1.f, oscale = 1.f;
+  if constexpr (HP) {      // as igemm_bf16s_kernel<1, 2, true>: fold the image's partial maxima, x * 2^ex into [2^13, 2^14)
+    static_assert(OSM_MAXABS_PARTS == 1024, "four partial maxima per thread");
+    const unsigned* xm = reinterpret_cast<const unsigned*>(p.xmax) + (long long)img * OSM_MAXABS_PARTS;
+    unsigned mb = max(max(xm[tid], xm[tid + 256]), max(xm[tid + 512], xm[tid + 768]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    unsigned* red_u = reinterpret_cast<unsigned*>(As);
+    if (lane == 0) red_u[wave] = mb;
+    __syncthreads();
+    mb = max(max(red_u[0], red_u[1]), max(red_u[2], red_u[3]));
+    __syncthreads();              // the staging stores that follow reuse the LDS
+    const float mx = __uint_as_float(mb);
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = min(14 - ex, 100); }
+    xscale = mx == mx ? ldexpf(1.f, ex) : mx;       // a NaN in the input poisons the output
+    oscale = ldexpf(1.f, -ex) / p.wscale[0];
+  }
 
   // ---- halo staging coordinates: slot s = tid + 256 j -> halo pixel (tid >> 3) + 32 j, float4 group tid & 7
   const int cg = tid & 7;
@@ -168,8 +192,10 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
   _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                                   \
     _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb)                            \
       _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2) {                                  \
-        acc[RB * t2 + 2 * (h_)] = mma16<NP>(f_[0][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_)]);         \
-        acc[RB * t2 + 2 * (h_) + 1] = mma16<NP>(f_[1][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_) + 1]); \
+        acc[RB * t2 + 2 * (h_)] = HP ? mma16h(f_[0][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_)])          \
+                                     : mma16<NP>(f_[0][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_)]);      \
+        acc[RB * t2 + 2 * (h_) + 1] = HP ? mma16h(f_[1][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_) + 1])  \
+                                         : mma16<NP>(f_[1][pa], bq[slot_][t2][pb], acc[RB * t2 + 2 * (h_) + 1]); \
       }
 
   if (kc1 > kc0) {
@@ -191,7 +217,14 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
             v.x = osm::silu_f(v.x); v.y = osm::silu_f(v.y); v.z = osm::silu_f(v.z); v.w = osm::silu_f(v.w);
           }
         }
-        split_planes<NP>(sel4((okm >> j) & 1u, v), pl);
+        if constexpr (HP) {
+          const float4 z = sel4((okm >> j) & 1u, v);
+          uint2 ph[2];
+          split_f16x2(make_float4(z.x * xscale, z.y * xscale, z.z * xscale, z.w * xscale), ph);
+          pl[0] = ph[0]; pl[NP - 1] = ph[1];
+        } else {
+          split_planes<NP>(sel4((okm >> j) & 1u, v), pl);
+        }
 #pragma unroll
         for (int q2 = 0; q2 < NP; ++q2)
           *reinterpret_cast<uint2*>(As + q2 * H_PLANE + woff[j]) = pl[q2];
@@ -218,7 +251,8 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
           int cnt = 0;                                                                     \
           _Pragma("unroll") for (int pa = NP - 1; pa >= 0; --pa)                           \
             _Pragma("unroll") for (int pb = NP - 1 - pa; pb >= 0; --pb, ++cnt)             \
-              acc[cnt & 1] = mma16<NP>(fx[(s_) & 1][pa], bq[(s_) % B_RING][0][pb], acc[cnt & 1]); \
+              acc[cnt & 1] = HP ? mma16h(fx[(s_) & 1][pa], bq[(s_) % B_RING][0][pb], acc[cnt & 1]) \
+                                : mma16<NP>(fx[(s_) & 1][pa], bq[(s_) % B_RING][0][pb], acc[cnt & 1]); \
           __builtin_amdgcn_sched_barrier(0);                                               \
         }
         OSM_H_NREAD(0)
@@ -264,6 +298,12 @@ __global__ __launch_bounds__(256, PH == 16 ? 1 : 2) void conv3_halo_bf16s_kernel
 #undef OSM_H_LOAD_B
 #undef OSM_H_READ
 #undef OSM_H_MMA
+  if constexpr (HP) {      // undo both power-of-two scales (exact)
+#pragma unroll
+    for (int i = 0; i < RB * NT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] *= oscale;
+  }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   // Vector form (see igemm_bf16s.inc.h: stores are issue-bound): each wave transposes its (RB x 32) x 32 tile through its

@@ -598,7 +598,7 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     if (p.splitk > p.nchunks) p.splitk = p.nchunks;
     p.stat_chunks = p.mtiles / nimg;
     const dim3 g2(p.mtiles * p.ntiles, p.splitk, 1);
-    if (wfmt < 1 || wfmt > 3) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
+    if (wfmt < 1 || wfmt > 4) return osm::fail(OSM_ERR_UNSUPPORTED, "unknown weight format %d", wfmt);
     // <= 32 output columns (head / stem data-gradient): the waves split the row blocks instead of the column tiles
     static const bool narrow_on = [] { const char* e = std::getenv("OSM_NARROW"); return !(e && e[0] == '0'); }();
     const bool narrow = narrow_on && wide && p.N <= 32 && !p.colsum;
@@ -632,7 +632,15 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
     OSM_HALO_PICK(1)
     }
 #else
-    if (wfmt == 3) { OSM_HALO_PICK(3) } else { OSM_HALO_PICK(2) }
+    if (wfmt == 4) {      // direct f16x3 (conv3_halo.inc.h, HP): two half planes behind a scale word, the input's range from the caller
+      if (!(p.xmax && osm::aligned16(p.xmax)))
+        return osm::fail(OSM_ERR_INVALID, "the f16x3 image (wfmt 4) needs x_maxabs (osm_maxabs of the input), 16-byte aligned");
+      if (p.gn_table) return osm::fail(OSM_ERR_UNSUPPORTED, "the f16x3 image does not take a fused GroupNorm input (gn_table)");
+      p.wscale = reinterpret_cast<const float*>(Bp + 2LL * 9 * p.ksteps * p.nt32 * 512);
+      if (narrow) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, false, 16, 3, 8, true, 1, true>), g2, dim3(256), 0, st, p.A, Bp, p);
+      else if (wide) hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, false, 16, 3, 8, false, 1, true>), g2, dim3(256), 0, st, p.A, Bp, p);
+      else hipLaunchKernelGGL((conv3_halo_bf16s_kernel<2, false, 8, 3, 8, false, 1, true>), g2, dim3(256), 0, st, p.A, Bp, p);
+    } else if (wfmt == 3) { OSM_HALO_PICK(3) } else { OSM_HALO_PICK(2) }
 #endif
 #undef OSM_HALO_PICK
 #undef OSM_HALO_LAUNCH
@@ -646,7 +654,7 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
       hipLaunchKernelGGL((igemm_bf16s_kernel<1, 1>), g2, dim3(256), 0, st, p.A, Bp, p);
 #else
     if (wfmt == 4) {     // f16x3 image of a 1x1 layer: two half planes behind a scale word, the input's range from the caller
-      if (taps != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 image (wfmt 4 without OSM_WFMT_WINOGRAD) is for 1x1 layers");
+      if (taps != 1) return osm::fail(OSM_ERR_UNSUPPORTED, "the direct f16x3 image (wfmt 4 without OSM_WFMT_WINOGRAD): 3x3 layers need H, W >= 8 (the halo-tile kernel)");
       if (!(p.xmax && osm::aligned16(p.xmax)))
         return osm::fail(OSM_ERR_INVALID, "the f16x3 image (wfmt 4) needs x_maxabs (osm_maxabs of the input), 16-byte aligned");
       if ((p.H * p.W) % BM != 0)
@@ -850,8 +858,7 @@ extern "C" int osm_conv2d_nhwc(const osm_conv_desc* d, void* stream) {
               "osm_conv2d_nhwc: OSM_WFMT_WINOGRAD goes with ksize 3 and wfmt 1 / 2 / 3 / 4");
   p.xmax = d->x_maxabs;
   if (wfmt != 0) {   // split-bf16 fragment image [plane][tap][k16-step][Cout/32][lane][8]
-    OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && (wino || d->ksize == 1)),
-                "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3), 3 (bf16x6), or 4 (f16x3: Winograd images and 1x1 layers)");
+    OSM_REQUIRE(wfmt >= 1 && wfmt <= 4, "osm_conv2d_nhwc: wfmt must be 0 (f32), 1 (fp16), 2 (bf16x3), 3 (bf16x6), or 4 (f16x3)");
     p.nt32 = (d->Cout + 31) / 32;
     p.ksteps = 2 * ((d->Cin + 31) / 32);
   }
@@ -903,8 +910,7 @@ extern "C" int osm_pack_conv_weight_bf16s(const float* w, void* w_fwd, void* w_d
                                           int wfmt, void* stream) {
   OSM_REQUIRE(w && (w_fwd || w_dgrad), "osm_pack_conv_weight_bf16s: null pointer");
   OSM_REQUIRE(k == 1 || k == 3, "osm_pack_conv_weight_bf16s: ksize must be 1 or 3");
-  OSM_REQUIRE((wfmt >= 1 && wfmt <= 3) || (wfmt == 4 && k == 1),
-              "osm_pack_conv_weight_bf16s: wfmt must be 1 (fp16), 2 or 3 (bf16 planes), or 4 (f16x3: 1x1 layers only)");
+  OSM_REQUIRE(wfmt >= 1 && wfmt <= 4, "osm_pack_conv_weight_bf16s: wfmt must be 1 (fp16), 2 or 3 (bf16 planes), or 4 (f16x3)");
   for (int dg = 0; dg < 2; ++dg) {
     unsigned short* out = reinterpret_cast<unsigned short*>(dg ? w_dgrad : w_fwd);
     if (!out) continue;

@@ -62,7 +62,22 @@ class _Conv:
         self.wf16 = self.wd16 = None
         if self.k == 1 and self.wwfmt == 4 and os.environ.get("OSM_F16X3_1X1", "1") != "0":
             self.wf16, self.wd16 = ops.pack_conv_weight(w, wfmt=4)
+        # 3x3 layers of an f16x3 model on images SMALLER than the Winograd tile (the 8 x 8 level): the direct halo-tile kernel with
+        # two-half-plane images (3 instead of 6 MFMAs per product, 4 instead of 6 bytes of weight stream per weight).  Which layers
+        # meet such an image depends on the input size, so the image is packed on first use (direct_f16x3)
+        self._slot = slot if (self.k == 3 and self.wwfmt == 4 and os.environ.get("OSM_F16X3_DIRECT", "1") != "0") else None
+        self.wf3 = self.wd3 = None
         self.b = slot.bias.detach().to(dev, torch.float32).contiguous()
+
+    def direct_f16x3(self, dgrad: bool):
+        """The direct (non-Winograd) f16x3 image of a 3x3 layer, or None when the layer has none (other arithmetic / switched off)."""
+        if self._slot is None:
+            return None
+        if self.wf3 is None:
+            w = self._slot.weight.detach().to(self.b.device, torch.float32)
+            with Recorder.suspended():               # one-off: not part of the launch plan being recorded
+                self.wf3, self.wd3 = ops.pack_conv_weight(w, wfmt=4)
+        return self.wd3 if dgrad else self.wf3
 
 
 class _Norm:
@@ -367,6 +382,11 @@ class UNetEngine:
                     ops.maxabs(x, self.B, xm)
         elif cv.wf16 is not None and xmax is not None and H * W >= 4096 and (H * W) % 128 == 0:
             wfmt, wimg, xm = 4, (cv.wd16 if dgrad else cv.wf16), xmax     # 1x1 f16x3: only where the range is already known
+        elif gn_table is None and self._is_direct_f16(cv, hw):
+            wfmt, wimg, xm = 4, cv.direct_f16x3(dgrad), xmax
+            if xm is None:
+                xm = self._xmax_slot(ws_slot)
+                ops.maxabs(x, self.B, xm)
         if xm is not None and xmax is not None and self._check_xmax:
             self._xmax_debug_check(x, xm, f"conv {cin}->{cout} k{cv.k} at {H}x{W}{' dgrad' if dgrad else ''}")
         self._xmax_invalidate(y)            # a convolution leaves no max |y| behind
@@ -392,6 +412,11 @@ class UNetEngine:
         cin, cout = (cv.cout, cv.cin) if dgrad else (cv.cin, cv.cout)
         return cv.wwf is not None and H >= self.winograd_min_hw and W >= self.winograd_min_hw and \
             bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
+
+    def _is_direct_f16(self, cv: _Conv, hw) -> bool:
+        """3x3 layer of an f16x3 model on an image smaller than the Winograd tile (8 <= H, W and one of them < 16): direct f16x3."""
+        H, W = hw
+        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < 16 or W < 16)
 
     # ---- registry of "max |.| of this gradient buffer was left behind by its last writer" (f16x3 range hand-over)
     @staticmethod
@@ -435,7 +460,7 @@ class UNetEngine:
     def _xmax_from_gn(self, cv: _Conv, hw_conv, hw_gn, key: str, dgrad=False):
         """The slot a GroupNorm pass should fill with max |output| because the f16x3 convolution `cv` (at resolution hw_conv)
         reads that output next; None when the layer is not f16x3 or the GroupNorm grid does not fit the slots."""
-        if cv.wwfmt != 4 or not self._is_wino(cv, hw_conv, dgrad=dgrad):
+        if cv.wwfmt != 4 or not (self._is_wino(cv, hw_conv, dgrad=dgrad) or self._is_direct_f16(cv, hw_conv)):
             return None
         if ops.gn_nchunk(hw_gn[0] * hw_gn[1]) > ops.MAXABS_PARTS:
             return None
@@ -774,9 +799,16 @@ class UNetEngine:
         dxn = self._scr("a", M, C)
         self._conv(dqkv, blk.qkv, dxn, hw, dgrad=True)
         gst = self._small(B * G * 2)
-        self._xmax_invalidate(dx_dst)       # this pass leaves no max |dx_dst| behind
+        # this pass writes dx_dst: it leaves max |dx_dst| behind for the f16x3 data-gradient convolution of the ResBlock that reads
+        # the buffer as its dy (as the ResBlock backward's last pass does)
+        xmo = None
+        if self.conv_mode == "f16x3" and ops.gn_nchunk(T) <= ops.MAXABS_PARTS and dx_dst.t.dtype == torch.float32:
+            xmo = self._small(B * ops.MAXABS_PARTS)
+            self._xmax_register(dx_dst, xmo)
+        else:
+            self._xmax_invalidate(dx_dst)
         self._gn_bwd(s["x"], dxn, dx_dst, T, s["st"], blk.norm, gst, silu=False, addend=dy,
-                     addend2=dx_dst if accumulate else None)
+                     addend2=dx_dst if accumulate else None, maxabs=xmo)
 
     # ------------------------------------------------------------------ Upsample / Downsample as layers (resblock_updown=False)
     def _resample_fwd(self, l, x: Mat, dst: Mat, hw):
