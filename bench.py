@@ -311,6 +311,47 @@ def roofline(model, args, reps=3):
             else:
                 tag = {"winograd": "conv3x3_winograd", "direct": "conv3x3_direct", "direct8": "conv3x3_8x8",
                        "igemm": "conv3x3_tapchunked", "f32": "conv3x3_f32"}[kind]
+            # what THIS launch has to move, given its tiling and its fused epilogue (the PMC traffic is compared with it):
+            # x once, its halo overlap (patches of 16 x 16 / 8 x 16 / 8 x 8 pixels stage a one-pixel border), x again for every group
+            # of column tiles beyond the first (Winograd: groups of <= 4 tiles of 64 columns share a patch in time), the weight
+            # image once, the result (split-K: fp32 partials), the residual / previous output, the GroupNorm input of the fused
+            # backward reductions
+            esz_ = 2.0 if d.wfmt & 0xf == 1 else 4.0
+            Mx = float(d.B * d.H * d.W)
+            wf_ = d.wfmt & 0xf
+            wbytes_per = {0: 4.0, 1: 2.0, 2: 4.0, 3: 6.0, 4: 4.0}[wf_]
+            if kind == "winograd":
+                ph, pw, taps_img = min(d.H, 16), min(d.W, 16), 16
+                ntile = (d.Cout + 63) // 64
+                nb1_ = max(g for g in (1, 2, 3, 4) if ntile % g == 0)
+                groups = ntile // nb1_
+                # the eight XCDs have private L2s: an XCD fetches the weight fragments of every column tile one of ITS workgroups
+                # works on (ids are dealt to the XCDs in contiguous ranges; id -> (group, M-tile, column tile in the group) as in
+                # conv3_wino8_kernel).  Beyond the first fetch these come from the Infinity Cache, and FETCH_SIZE counts them
+                mt_ = d.B * ((d.H + 15) // 16) * ((d.W + 15) // 16)
+                nt_, gsz_ = mt_ * ntile, nb1_ * mt_
+                q_, r_ = divmod(nt_, 8)
+                fetched_tiles, lo_ = 0, 0
+                for xcd_ in range(8):
+                    n_ = q_ + (1 if xcd_ < r_ else 0)
+                    fetched_tiles += len({(i_ // gsz_) * nb1_ + i_ % nb1_ for i_ in range(lo_, lo_ + n_)})
+                    lo_ += n_
+                wino_xcd_refetch = max(0, fetched_tiles - ntile) / float(ntile)
+            elif kind in ("direct", "direct8"):
+                ph, pw, taps_img, groups = 8, (16 if d.W >= 16 else 8), d.ksize * d.ksize, 1   # column tiles of a patch: adjacent ids, one XCD
+            else:
+                ph, pw, taps_img, groups = 0, 0, d.ksize * d.ksize, 1
+            halo = ((ph + 2) * (pw + 2) / float(ph * pw) - 1.0) if (ph and d.ksize == 3) else 0.0
+            comp = {"x": esz_ * Mx * d.Cin, "x_halo_overlap": esz_ * Mx * d.Cin * halo,
+                    "x_again_per_column_tile_group": esz_ * Mx * d.Cin * (1.0 + halo) * (groups - 1),
+                    "weights": wbytes_per * taps_img * d.Cin * d.Cout,
+                    "weights_again_per_xcd": wbytes_per * taps_img * d.Cin * d.Cout * (wino_xcd_refetch if kind == "winograd" else 0.0),
+                    "result": (4.0 * d.splitk if d.splitk > 1 else esz_) * Mx * d.Cout,
+                    "residual_or_previous_output": esz_ * Mx * d.Cout * ((1 if d.res else 0) + (1 if d.accumulate else 0)) * (d.splitk <= 1),
+                    "groupnorm_input_of_fused_backward_sums": esz_ * Mx * d.Cout * (1 if (d.colsum and d.stat_mode == 2 and d.splitk <= 1) else 0)}
+            ob = opbytes.setdefault(tag, {})
+            for k_, v_ in comp.items():
+                ob[k_] = ob.get(k_, 0.0) + v_
             return (tag, fl, shape)
         if name == "osm_maxabs":
             return ("maxabs", 0.0, None)
@@ -349,6 +390,7 @@ def roofline(model, args, reps=3):
     agg = {}
     per_shape = {}
     shape_tag = {}
+    opbytes = {}
     for _ in range(reps):
         for plan in (eng._fwd_plan, eng._bwd_plan):
             for (tag, fl, shape), ms in plan.replay_timed(select):
@@ -486,6 +528,13 @@ def roofline(model, args, reps=3):
             "hbm_gbps": None if traffic is None else round(traffic / lt / 1e6, 1),
             "algorithmic_gbps": round(alg_bytes / lt / 1e6, 1),
             "algorithmic_bytes_per_launch_avg": round(alg_bytes),
+            # the bytes the launches of this class have to move given their tiling and fused epilogues, by component (average per
+            # launch), and the counter traffic over their sum (FETCH_SIZE counts L2 misses that the Infinity Cache serves as well:
+            # the per-XCD weight fetches and the column-group re-reads of x are of that kind, not HBM reads)
+            "operand_bytes_per_launch_avg": {k_: round(v_ / reps / c["launches_per_step"]) for k_, v_ in opbytes.get(dom, {}).items()},
+            "operand_bytes_per_launch_total": round(sum(opbytes.get(dom, {}).values()) / reps / c["launches_per_step"]),
+            "traffic_over_operand_bytes": None if traffic is None else round(
+                traffic / max(1.0, sum(opbytes.get(dom, {}).values()) / reps / c["launches_per_step"]), 3),
             "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
             "avg_launch_ms": lt, "avg_launch_ms_is": "HIP events around one osm_conv2d_nhwc call (kernel + split-K combine where there is one)",
             "launches_per_step": c["launches_per_step"]}, out
