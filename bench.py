@@ -14,10 +14,13 @@ from the phi-update regime (t <= 0.7 T, the expensive 70 % of the chain), starti
 x_t so that the un-trained network's x0 prediction stays inside the physical model's range.  Weights are seeded
 synthetic (no checkpoint is available offline), inputs synthetic; timing is value independent.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (3x3 implicit-GEMM conv,
-split-bf16 MFMA): algorithmic FLOPs of every 3x3-conv launch of one guided step divided by the
-HIP-event-measured duration of those launches (events on the launch stream).  `cpu_baseline` times
-the CPU oracle (oracle/, torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the Winograd 3x3 convolution): `frac` is the
+EXECUTED fraction -- MFMA flops the matrix cores ran per launch (algorithmic flops x 16/36 x MFMAs per product) / the
+kernel's duration / the dense MFMA peak of the operand type -- with the duration taken from a kernel trace of a child run
+of this script (`kernel_only_avg_us`) and, beside it, from HIP events around the launches on the launch stream
+(`frac_hip_event`, `avg_launch_ms`: kernel + split-K combine); the algorithmic figure is `algorithmic_frac_of_direct_roof`.
+`cpu_baseline` times the CPU oracle (oracle/, torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1.
+`--scale-only`: the N = 2 / 4 / 8 form (headline leg + config-4 leg, nothing else).
 """
 import argparse
 import json
@@ -169,7 +172,7 @@ def timed_steps(args, dev, model, sampler, cond, batch, image_index, steps, warm
 
 def run_gpu(args, rank, world, dev, sync):
     """The headline leg on this rank.  Returns (model, job seconds = MAX over ranks of barrier-to-barrier time, finite,
-    per-rank rows [rank, image index, own ms per step, barrier-to-barrier ms per step, setup s, finite])."""
+    per-rank rows [rank, image index, own ms per step, barrier-to-barrier ms per step, setup s, finite, device index])."""
     t_setup = time.perf_counter()
     model, sampler, cond = build_case(args, dev, args.batch, conv_mode=args.conv_mode)
     image_index = shard(world, rank, world)[0]
@@ -179,7 +182,7 @@ def run_gpu(args, rank, world, dev, sync):
                              dump=True)
     setup_s = time.perf_counter() - t_setup - dt
     rows = sync.all_gather([rank, image_index, 1e3 * timed_steps.last_own_s / args.steps, 1e3 * dt / args.steps, setup_s,
-                            1.0 if finite else 0.0])
+                            1.0 if finite else 0.0, float(torch.cuda.current_device())])
     dt = max(r[3] for r in rows) * args.steps / 1e3
     return model, dt, all(r[5] == 1.0 for r in rows), rows
 
@@ -267,6 +270,8 @@ def run_secondary(args, dev):
                         "ms_per_step": round(1e3 * dt / steps, 2),
                         "image_steps_per_s": round(c["batch"] * steps / dt, 2), "finite_outputs": finite,
                         "roofline_kernel": rl["kernel"], "roofline_frac": rl["frac"], "roofline_achieved_tflops": rl["achieved"],
+                        "roofline_frac_is": "executed MFMA flops / HIP-event launch time / dense MFMA peak",
+                        "roofline_algorithmic_frac_of_direct_roof": rl["algorithmic_frac_of_direct_roof"],
                         "kernel_breakdown_ms_per_step": {k: round(v["ms_per_step"], 2) for k, v in br.items() if not k.startswith("_")}})
             del model, sampler, cond
             torch.cuda.empty_cache()
@@ -464,12 +469,21 @@ def roofline(model, args, reps=3):
                 ("bf16", 3): "fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative)",
                 ("f16", 1): "fp16 activations x fp16 weights, fp32 accumulation (the reference's use_fp16): one fp16 MFMA per product",
                 }.get((mtype, nmfma), "") + f": peak = dense {mtype} MFMA peak 2500 TFLOP/s / {nmfma}; achieved counts ALGORITHMIC flops"
-    extra = {}
+    # `frac` is the EXECUTED fraction: MFMA flops the matrix cores really ran (algorithmic flops x 16/36 for
+    # Winograd F(2x2,3x3) x the MFMAs of one product in this arithmetic) / kernel time / the DENSE peak of the MFMA operand type.
+    # <= 1 by construction.  The algorithmic figure against the roof a direct convolution in this arithmetic would have
+    # (peak / MFMAs per product) stays beside it as `algorithmic_frac_of_direct_roof` (it tops out at 36/16 for Winograd).
+    mfma_peak = FP32_MFMA_PEAK_TFLOPS if nmfma == 0 else BF16_MFMA_PEAK_TFLOPS
+    exec_ratio = (16.0 / 36.0 if wino else 1.0) * max(nmfma, 1)
+    executed = achieved * exec_ratio
+    extra = {"executed_tflops": round(executed, 2), "executed_frac": round(executed / mfma_peak, 4),
+             "executed_is": f"algorithmic flops x {'16/36 (Winograd F(2x2,3x3)) x ' if wino else ''}{max(nmfma, 1)} MFMA(s) per product",
+             "mfma_dense_peak_tflops": mfma_peak,
+             "algorithmic_tflops": round(achieved, 2), "algorithmic_roof_tflops": round(peak, 1),
+             "algorithmic_frac_of_direct_roof": round(achieved / peak, 4)}
     if wino:
-        note += ("; the Winograd F(2x2,3x3) kernel EXECUTES 16/36 of the algorithmic multiply-adds: `achieved` stays algorithmic "
-                 "(what a direct convolution would have to do), `executed_tflops` is what the matrix cores did")
-        executed = achieved * 16.0 / 36.0
-        extra = {"executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4)}
+        note += ("; the Winograd F(2x2,3x3) kernel EXECUTES 16/36 of the algorithmic multiply-adds: `achieved` / `frac` count what the "
+                 "matrix cores did, `algorithmic_tflops` what a direct convolution would have to do")
     extra["share_of_3x3_time"] = round(c["ms_per_step"] / sum(v["ms_per_step"] for v in conv3.values()), 4)
     # HBM bytes per launch of the dominant kernel RELAYED from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, tools/pmc_summary.py): a builder-side measurement, not something this run observed
@@ -517,10 +531,28 @@ def roofline(model, args, reps=3):
                     "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound; the counter-based "
                     "matrix-pipe busy fraction of these kernels is in profiles/r03_pmc_mfma_busy.json"}
     lt = c["ms_per_step"] / c["launches_per_step"]
+    # kernel-only duration of the same kernel from a kernel trace taken in THIS run (a child run of this script under
+    # `rocprofv3 --kernel-trace`, one guided step): what profiles/rNN_rocprofv3_kernel_stats.csv reports.  The HIP-event time
+    # brackets one osm_conv2d_nhwc call, i.e. the kernel AND the split-K combine of the launches that have one.
+    ktrace = None
+    if getattr(args, "pmc", "off") == "auto" and reps > 1:
+        ktrace = live_kernel_time(args, kname)
+    k_us = ktrace.get("avg_us") if isinstance(ktrace, dict) else None
+    fl_launch = c["gflop_per_step"] * 1e9 / c["launches_per_step"]
+    exec_event = fl_launch * exec_ratio / (lt * 1e-3) / 1e12
+    exec_kernel = None if not k_us else fl_launch * exec_ratio / (k_us * 1e-6) / 1e12
+    best = exec_kernel if exec_kernel is not None else exec_event
     return {"bound": "mfma", "kernel": kname + " (3x3 conv fwd + dgrad)", "class": dom, "arithmetic": note,
-            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), **extra,
-            "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # 157.3 TF: the exact-fp32 MFMA / vector peak
+            "achieved": round(best, 2), "peak": mfma_peak, "unit": "TFLOP/s",
+            "frac": round(best / mfma_peak, 4),
+            "frac_is": ("EXECUTED MFMA flops per launch / kernel-only time of that kernel (kernel trace of a child run of this script, "
+                        "this box) / dense MFMA peak of the operand type" if exec_kernel is not None else
+                        "EXECUTED MFMA flops per launch / HIP-event time of the launch (kernel + split-K combine) / dense MFMA peak"),
+            "frac_hip_event": round(exec_event / mfma_peak, 4),
+            "frac_kernel_trace": None if exec_kernel is None else round(exec_kernel / mfma_peak, 4),
+            "kernel_only_avg_us": None if not k_us else round(k_us, 2), "kernel_trace": ktrace,
+            **extra,
+            "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),   # algorithmic, against 157.3 TF (exact-fp32 MFMA / vector peak)
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_measured_in": traffic_how, "traffic_detail": traffic_detail,
             # achieved HBM GB/s of the conv kernel (north_star asks for it; the kernel is MFMA / power bound, not HBM-bound):
@@ -535,9 +567,61 @@ def roofline(model, args, reps=3):
             "operand_bytes_per_launch_total": round(sum(opbytes.get(dom, {}).values()) / reps / c["launches_per_step"]),
             "traffic_over_operand_bytes": None if traffic is None else round(
                 traffic / max(1.0, sum(opbytes.get(dom, {}).values()) / reps / c["launches_per_step"]), 3),
-            "flop_per_launch_avg": c["gflop_per_step"] * 1e9 / c["launches_per_step"],
+            "flop_per_launch_avg": fl_launch, "executed_mfma_flop_per_launch_avg": fl_launch * exec_ratio,
             "avg_launch_ms": lt, "avg_launch_ms_is": "HIP events around one osm_conv2d_nhwc call (kernel + split-K combine where there is one)",
             "launches_per_step": c["launches_per_step"]}, out
+
+
+def _kernel_matcher(kname):
+    pref = kname.split("<")[0]
+    targs = kname.split("<")[1].rstrip(">").split(",") if "<" in kname else []
+
+    def match(name):
+        kn = name.replace(" ", "")
+        i = kn.find(pref + "<")
+        if i < 0:
+            return False
+        ka = kn[i + len(pref) + 1:].split(">")[0].split(",")
+        return all(t == "*" or (j < len(ka) and ka[j] == t) for j, t in enumerate(targs))
+    return match
+
+
+def live_kernel_time(args, kname):
+    """Kernel-only duration of the dominant kernel, MEASURED IN THIS RUN: one child run of this script (1 warm-up + 1 guided
+    step) under `rocprofv3 --kernel-trace` (no counters, no other trace domain); the average of End - Start over the kernel's
+    dispatches -- the quantity `rocprofv3 --kernel-trace --stats` prints as AverageNs.  Returns a dict or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    match = _kernel_matcher(kname)
+    d = tempfile.mkdtemp(prefix="osm_kt_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--steps", "1", "--warmup", "1", "--cpu-steps", "0", "--secondary-steps", "0", "--pmc", "off",
+           "--conv-mode", args.conv_mode, "--batch", str(args.batch), "--image-size", str(args.image_size)]
+    try:
+        env = {k: v for k, v in os.environ.items() if k != "OSM_BENCH_DUMP"}
+        subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=args.pmc_timeout)
+        tot, n, names = 0.0, 0, set()
+        for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if match(r["Kernel_Name"]):
+                    tot += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                    n += 1
+                    names.add(r["Kernel_Name"].split("(")[0][-60:])
+        if n == 0:
+            return {"error": f"no kernel-trace rows for {kname}"}
+        return {"avg_us": tot / n / 1e3, "dispatches": n, "instances": sorted(names)[:4],
+                "how": "rocprofv3 --kernel-trace, child run of this script (1 warm-up + 1 guided step); average End - Start of the "
+                       "kernel's dispatches (both UNet plans, every template instance)"}
+    except Exception as e:          # a profiler problem must never cost the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def live_traffic(args, kname):
@@ -675,7 +759,12 @@ def main():
                     help="batch of the config-4 secondary leg (BASELINE config 4: 64 images sharded 8 per GPU); runs at every N")
     ap.add_argument("--secondary-steps", type=int, default=3,
                     help="timed steps of each secondary configuration (BASELINE configs 3 and 5; N = 1 only; 0 = skip)")
+    ap.add_argument("--scale-only", action="store_true",
+                    help="scaling runs (N = 2 / 4 / 8): the headline leg and the config-4 leg only -- no rocprofv3 child runs, no CPU "
+                         "baseline, no complete chain, no long window, no bf16x6 / config 3 / config 5 legs: < 60 s per N after setup")
     args = ap.parse_args()
+    if args.scale_only:
+        args.pmc, args.cpu_steps, args.full_chain, args.long_window = "off", 0, 0, 0
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started plainly with --gpus N: become the one-process-per-GPU job the contract describes
@@ -747,15 +836,25 @@ def main():
         # no collective.  per_rank_ms: each rank's own synchronize-to-synchronize time per step; the job time is the MAX over
         # ranks of the barrier-to-barrier time
         "collective": sync.transport, "collective_failures": sync.failures or None,
-        "ranks_seen": len(rank_rows), "per_rank_ms": [round(r[2], 3) for r in sorted(rank_rows)],
+        "ranks_seen": len(rank_rows), "per_rank_device": [int(r[6]) for r in sorted(rank_rows)],
+        "per_rank_ms": [round(r[2], 3) for r in sorted(rank_rows)],
         "per_rank_image": [int(r[1]) for r in sorted(rank_rows)],
         "per_rank_setup_s": [round(r[4], 1) for r in sorted(rank_rows)],
     }
+    if world > 1:
+        # a scaling line is only a scaling line if every rank reported and (one rank per GPU) every rank drove its own device;
+        # OSM_BENCH_BACKEND=gloo (ranks sharing device 0 on a one-GPU box: tests) is the declared exception
+        line["ranks_complete"] = line["ranks_seen"] == world
+        line["devices_distinct"] = len(set(line["per_rank_device"])) == world
+        if rank == 0 and not line["ranks_complete"]:
+            raise SystemExit(f"bench.py: {line['ranks_seen']} of {world} ranks reported -- not a valid N = {world} line")
+        if rank == 0 and backend == "nccl" and ndev >= world and not line["devices_distinct"]:
+            raise SystemExit(f"bench.py: ranks shared a device ({line['per_rank_device']}) on a node with {ndev} GPUs")
     rl = breakdown = None
     long_window = chain = None
     if rank == 0:               # replays the headline engine's plans: before the config-4 leg replaces that engine
         rl, breakdown = roofline(model, args)
-        if world == 1 and not args.tiny and args.secondary_steps > 0:     # (--secondary-steps 0 = the headline leg alone: profiling runs)
+        if world == 1 and not args.tiny and args.secondary_steps > 0 and not args.scale_only:     # (--secondary-steps 0 = the headline leg alone: profiling runs)
             # same model, same engine, same start state as the headline leg -- only longer (the driver passes --steps 20)
             if 0 < args.steps < args.long_window:
                 try:
@@ -790,7 +889,7 @@ def main():
                 line["images_per_sec_at_1000_steps_measured"] = chain["images_per_sec"]
         line["achieved_tflops_whole_step"] = round(
             sum(v["gflop_per_step"] for v in breakdown.values()) / (1e3 * dt / args.steps), 2)
-        if world == 1 and args.secondary_steps > 0 and not args.tiny:
+        if world == 1 and args.secondary_steps > 0 and not args.tiny and not args.scale_only:
             del model
             model = None
             torch.cuda.empty_cache()

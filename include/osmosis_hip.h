@@ -293,7 +293,10 @@ int osm_posterior(const float* model_out /*[B,8,HW]*/, const float* x /*[B,4,HW]
 /* physical forward model + guidance loss (measurements.py:138-151,251-264,363-376;
  * condition_methods.py:109-144; losses.py:29-83; utils.py:544-566,674-700) */
 typedef struct osm_phys_desc {
-  int kind;            /* 0 underwater_physical_revised, 1 underwater_physical, 2 haze_physical */
+  int kind;            /* 0 underwater_physical_revised, 1 underwater_physical, 2 haze_physical,
+                          3 identity: I = x0[:, 0:3] -- the 'noise' / 'rgb_guidance' operators of the rgb-guidance ('ps') path
+                          (measurements.py:41-66, condition_methods.py:35-41: loss = ||y - x0[:, 0:3]||); loss_type 0, no
+                          weight, no auxiliary losses, no parameters (osm_phys_finalize with do_update = 0 only) */
   int depth_type;      /* 0 original, 1 gamma, 2 move                                  */
   float dval[3];       /* depth params (gamma: v0,v1,v2 ; move: v0)                    */
   int weight_type;     /* 0 none, 1 depth                                              */
@@ -337,6 +340,31 @@ int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, in
 int osm_guide_update(const float* mean, const float* logvar, const float* g, const float* dx_unet,
                      const float* noise, const float* coef, const float* scale4, float clip,
                      float* x_next, float* grad_out, int B, int HW, void* stream);
+/* osm_guide_update with the step noise drawn INSIDE the kernel (gaussian_diffusion.py:266-268 `noise = torch.randn_like(img)`):
+ * Philox-4x32-10, key = seed, counter = (element / 4, img0 + b * img_stride, *step, stream id) -> the four normals (two Box-Muller
+ * pairs) of four consecutive elements of image b.  An image's noise depends on (seed, its index, the step) only: not on the batch
+ * it travels in, not on chunking, not on the grid; img_stride = 0 gives every image of the batch the SAME noise (what separately
+ * seeded batch-1 runs draw).  `step` is the device-side step counter osm_fetch_coefs moves (read, not
+ * moved, here); the counter word is *step + step_offset (+1 when the fetch of this step has already moved it by -1).  noise_out (optional, [B,4,HW]) receives the draws (tests, traces).  H*W % 4 == 0; tensors 16-byte aligned.
+ * NOT the bit stream of ATen's Philox (offsets / Box-Muller pairing differ): parity runs inject noise through osm_guide_update. */
+int osm_guide_update_rng(const float* mean, const float* logvar, const float* g, const float* dx_unet, const float* coef,
+                         const float* scale4, float clip, float* x_next, float* grad_out, float* noise_out, int B, int HW,
+                         unsigned long long seed, const int* step, int step_offset, int img0, int img_stride, void* stream);
+/* out[b][0..n) ~ N(0,1) from the same generator (image b: counter word 1 = img0 + b * img_stride; word 2 = *step_dev if given, else
+ * step_const): what osm_guide_update_rng draws for (seed, image, step) when n = 4*H*W.  out 16-byte aligned; B > 1 needs n % 4 == 0. */
+int osm_randn(float* out, int B, long long n, unsigned long long seed, const int* step_dev, int step_const, int img0,
+              int img_stride, void* stream);
+/* out[4 q .. 4 q + 3] = Philox-4x32-10(counter = (q, c1, c2, c3), key = (k0, k1)) for q < n4: the raw generator, checked in the
+ * tests against the Random123 known-answer vectors. */
+int osm_philox_raw(unsigned* out, long long n4, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, void* stream);
+/* DDIM step + guidance of the rgb-guidance path (gaussian_diffusion.py:505-535 `DDIM.p_sample`, condition_methods.py:247-251):
+ *   eps = (c0*x - x0)/c1 ; sigma = eta*sqrt((1-abp)/(1-ab))*sqrt(1-ab/abp) ; grad = c0*g + dx_unet
+ *   x_next = x0*sqrt(abp) + sqrt(1-abp-sigma^2)*eps + noise_on*sigma*noise - scale[c]*clamp(grad,+-clip)
+ * coef: the posterior row of the step; dcoef: device float[8] = {alpha_bar, alpha_bar_prev, eta, noise_on, -, -, -, t}.
+ * g / dx_unet / noise / grad_out optional; x_next may alias x. */
+int osm_ddim_update(const float* x0, const float* x, const float* g, const float* dx_unet, const float* noise,
+                    const float* coef, const float* dcoef, const float* scale4, float clip, float* x_next, float* grad_out,
+                    int B, int HW, void* stream);
 /* unconditional ancestral step of the RGBD prior sampler (osmosis_utils/diffusion.py:94-122), NCHW:
  *   eps = model_out[:, :C]; x_next = c_a (x - c_b eps) + c_s z; x0 = c_r x - c_m eps (x0, z optional)
  * coef: device float[8] = {c_a, c_b, c_s, c_r, c_m, -, -, t}.  x_next may alias x (in-place update). */

@@ -115,6 +115,10 @@ _SIGS = {
     "osm_phys_optimize": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "osm_posterior_bwd": [_P, _P, _P, _I, _I, _P],
     "osm_guide_update": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
+    "osm_guide_update_rng": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, C.c_ulonglong, _P, _I, _I, _I, _P],
+    "osm_randn": [_P, _I, _LL, C.c_ulonglong, _P, _I, _I, _I, _P],
+    "osm_philox_raw": [_P, _LL, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, _P],
+    "osm_ddim_update": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     "osm_fetch_coefs": [_P, _I, _P, _I, _P, _P, _I, _P],
     "osm_ancestral_step": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "osm_version": [],

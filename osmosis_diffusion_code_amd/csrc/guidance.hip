@@ -50,6 +50,16 @@ __device__ __forceinline__ void eval_pixel(const osm_phys_desc& ds, const float*
     q.y[c] = y[(long long)b * 3 * ds.HW + (long long)c * ds.HW + p];
   }
   q.D = x0[base + 3LL * ds.HW];
+  if (ds.kind == 3) {   // identity forward model of the rgb-guidance ('ps') path: I = x0[:, 0:3], unweighted (condition_methods.py:35-41)
+    q.d = 0.f; q.dd = 0.f; q.w = 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q.Ea[c] = q.Eb[c] = 1.f;
+      q.J[c] = 0.5f * (q.rgb[c] + 1.0f);
+      q.r[c] = q.y[c] - q.rgb[c];
+    }
+    return;
+  }
   q.d = conv_depth(q.D, ds.depth_type, ds.dval, q.dd);
   float wdd;
   q.w = ds.weight_type == 1 ? conv_depth(q.D, ds.wdepth_type, ds.wval, wdd) : 1.0f;
@@ -202,6 +212,12 @@ __global__ __launch_bounds__(256) void phys_grad_kernel(osm_phys_desc ds, const 
   const float* ph = phi + b * 9;
   float gD = 0.f;
   const long long base = (long long)b * 4 * ds.HW + p;
+  if (ds.kind == 3) {   // d ||y - x0[:, 0:3]|| / d x0 = -(y - x0) / ||.|| on the colour channels, nothing on depth
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[base + (long long)c * ds.HW] = -(q.r[c] * gscale);
+    g[base + 3LL * ds.HW] = 0.f;
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float pa = ds.kind == 2 ? ph[0] : ph[c];
@@ -304,6 +320,131 @@ __global__ __launch_bounds__(256) void ancestral_step_kernel(const float* __rest
   }
 }
 
+
+// ---------------------------------------------------------------- step noise inside the library (gaussian_diffusion.py:266-268)
+// Philox-4x32-10 (Salmon et al., SC'11; the Random123 constants), counter = (element quad, image, step, stream id), key = the
+// 64-bit seed: one counter gives the four normals of four consecutive elements of one image (two Box-Muller pairs), so the
+// noise of an image depends on (seed, image index, step) only -- not on the batch it is processed in, its chunking or the grid.
+struct Philox4 { unsigned v[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+// (0, 1): 24 random bits, centred in their 2^-24 cell
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f; }
+__device__ __forceinline__ void normal4(const Philox4& r, float z[4]) {
+  const float r0 = sqrtf(-2.0f * logf(u01(r.v[0]))), r1 = sqrtf(-2.0f * logf(u01(r.v[2])));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u01(r.v[1]), &s0, &c0);
+  sincosf(6.283185307179586f * u01(r.v[3]), &s1, &c1);
+  z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+constexpr unsigned OSM_RNG_STREAM_STEP_NOISE = 0x6f736d31u;   // "osm1": the per-step noise of a chain
+
+__global__ __launch_bounds__(256) void philox_raw_kernel(unsigned* __restrict__ out, long long n4, unsigned c1, unsigned c2,
+                                                          unsigned c3, unsigned k0, unsigned k1) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+    const Philox4 r = philox4x32_10((unsigned)q, c1, c2, c3, k0, k1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[4 * q + e] = r.v[e];
+  }
+}
+
+// out[b][0..n) ~ N(0, 1): image b uses counter word 1 = img0 + b, word 2 = the step (from the device counter when given)
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int B, long long n, unsigned k0, unsigned k1,
+                                                     const int* __restrict__ step_dev, int step_const, int img0, int img_stride) {
+  const unsigned step = (unsigned)(step_dev ? *step_dev : step_const);
+  const long long nq = (n + 3) >> 2;
+  const long long total = (long long)B * nq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / nq, q = i - b * nq;
+    float z[4];
+    normal4(philox4x32_10((unsigned)q, (unsigned)(img0 + (int)b * img_stride), step, OSM_RNG_STREAM_STEP_NOISE, k0, k1), z);
+    float* o = out + b * n + 4 * q;
+    if (4 * q + 3 < n) *reinterpret_cast<float4*>(o) = make_float4(z[0], z[1], z[2], z[3]);    // (n % 4 == 0 and out 16-byte aligned: checked by the host)
+    else for (int e = 0; e < 4 && 4 * q + e < n; ++e) o[e] = z[e];
+  }
+}
+
+// guide_update with the noise drawn in the kernel: four consecutive elements of one image per thread (4 HW % 4 == 0)
+__global__ __launch_bounds__(256) void guide_update_rng_kernel(const float* __restrict__ mean, const float* __restrict__ logvar,
+                                                                const float* __restrict__ g, const float* __restrict__ dxu,
+                                                                const float* __restrict__ coef, const float* __restrict__ scale4,
+                                                                float clip, float* __restrict__ x_next, float* __restrict__ grad_out,
+                                                                float* __restrict__ noise_out, int B, int HW, unsigned k0, unsigned k1,
+                                                                const int* __restrict__ step_dev, int step_offset, int img0,
+                                                                int img_stride) {
+  const long long nq = (long long)HW;             // 4 HW elements per image = HW quads
+  const long long total = (long long)B * nq;
+  const float c0 = coef[0], noise_on = coef[6];
+  const unsigned step = (unsigned)(*step_dev + step_offset);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / nq, q = i - b * nq;
+    const long long e0 = b * 4LL * HW + 4 * q;
+    const int c = (int)((4 * q) / HW);            // HW % 4 == 0: a quad never straddles two channels
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noise_on != 0.f) normal4(philox4x32_10((unsigned)q, (unsigned)(img0 + (int)b * img_stride), step, OSM_RNG_STREAM_STEP_NOISE, k0, k1), z);
+    const float4 m = *reinterpret_cast<const float4*>(mean + e0);
+    const float4 lv = *reinterpret_cast<const float4*>(logvar + e0);
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), du = gv;
+    if (g) gv = *reinterpret_cast<const float4*>(g + e0);
+    if (g && dxu) du = *reinterpret_cast<const float4*>(dxu + e0);
+    const float mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {lv.x, lv.y, lv.z, lv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w},
+                dd[4] = {du.x, du.y, du.z, du.w};
+    float xo[4], go[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float grad = g ? c0 * gg[e] + dd[e] : 0.f;
+      go[e] = grad;
+      float gc = grad;
+      if (clip >= 0.f) gc = (grad != grad) ? grad : fminf(fmaxf(grad, -clip), clip);
+      float xt = mm[e] - (g ? scale4[c] * gc : 0.f);
+      if (noise_on != 0.f) xt += expf(0.5f * ll[e]) * z[e];
+      xo[e] = xt;
+    }
+    *reinterpret_cast<float4*>(x_next + e0) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    if (grad_out) *reinterpret_cast<float4*>(grad_out + e0) = make_float4(go[0], go[1], go[2], go[3]);
+    if (noise_out) *reinterpret_cast<float4*>(noise_out + e0) = make_float4(z[0], z[1], z[2], z[3]);
+  }
+}
+
+// DDIM step + guidance (gaussian_diffusion.py:505-535, condition_methods.py:247-251), in the reference's operation order:
+//   eps = (c0 x - x0) / c1 ; sigma = eta sqrt((1 - abp) / (1 - ab)) sqrt(1 - ab / abp) ;
+//   x_next = x0 sqrt(abp) + sqrt(1 - abp - sigma^2) eps + [t != 0] sigma noise - scale[c] clamp(grad)
+// coef = the posterior row (c0 = sqrt_recip_ac, c1 = sqrt_recipm1_ac), dcoef = {alpha_bar, alpha_bar_prev, eta, noise_on}.
+// x_next may alias x (each element is read, then written, by one thread).
+__global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x0, const float* x, const float* __restrict__ g,
+                                                           const float* __restrict__ dxu, const float* __restrict__ noise,
+                                                           const float* __restrict__ coef, const float* __restrict__ dcoef,
+                                                           const float* __restrict__ scale4, float clip, float* x_next,
+                                                           float* __restrict__ grad_out, int B, int HW) {
+  const long long total = (long long)B * 4 * HW;
+  const float c0 = coef[0], c1 = coef[1];
+  const float ab = dcoef[0], abp = dcoef[1], eta = dcoef[2], noise_on = dcoef[3];
+  const float sigma = eta * sqrtf((1.0f - abp) / (1.0f - ab)) * sqrtf(1.0f - ab / abp);
+  const float sa = sqrtf(abp), sb = sqrtf(1.0f - abp - sigma * sigma);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % 4);
+    const float xs = x0[i];
+    const float eps = (c0 * x[i] - xs) / c1;
+    float xt = xs * sa + sb * eps;
+    if (noise_on != 0.f && noise) xt += sigma * noise[i];
+    float grad = 0.f;
+    if (g) grad = c0 * g[i] + (dxu ? dxu[i] : 0.f);
+    if (grad_out) grad_out[i] = grad;
+    float gc = grad;
+    if (clip >= 0.f) gc = (grad != grad) ? grad : fminf(fmaxf(grad, -clip), clip);
+    x_next[i] = xt - (g ? scale4[c] * gc : 0.f);
+  }
+}
+
 __global__ void fetch_coefs_kernel(const float* __restrict__ table, int* __restrict__ step, int delta,
                                    float* __restrict__ coef_out, float* __restrict__ t_out, int B, int n_rows) {
   const int s = min(max(*step, 0), n_rows - 1);   // a counter that ran off the table re-reads its last row
@@ -321,7 +462,9 @@ inline int grid_for(long long total) {
 
 int check_desc(const osm_phys_desc* d, const char* who) {
   OSM_REQUIRE(d, "%s: null descriptor", who);
-  OSM_REQUIRE(d->kind >= 0 && d->kind <= 2, "%s: unknown operator kind %d", who, d->kind);
+  OSM_REQUIRE(d->kind >= 0 && d->kind <= 3, "%s: unknown operator kind %d", who, d->kind);
+  OSM_REQUIRE(d->kind != 3 || (d->loss_type == 0 && d->weight_type == 0 && d->gamma_avrg == 0.f && d->gamma_val == 0.f),
+              "%s: the identity operator (kind 3) is the plain norm loss: no weight, no auxiliary losses", who);
   OSM_REQUIRE(d->depth_type >= 0 && d->depth_type <= 2, "%s: unknown depth_type %d", who, d->depth_type);
   OSM_REQUIRE(d->loss_type == 0 || d->loss_type == 1, "%s: unknown loss_type %d", who, d->loss_type);
   OSM_REQUIRE(d->B > 0 && d->HW > 0, "%s: bad shape", who);
@@ -350,6 +493,7 @@ extern "C" int osm_phys_finalize(const osm_phys_desc* d, const float* part, floa
   OSM_REQUIRE(part && red && phi, "osm_phys_finalize: null pointer");
   OSM_REQUIRE(d->optimizer == 0 || d->optimizer == 1, "osm_phys_finalize: optimizer must be 0 (sgd / GD) or 1 (adam)");
   OSM_REQUIRE(!(d->optimizer == 1 && do_update) || opt_state, "osm_phys_finalize: the Adam step needs opt_state [B][20]");
+  OSM_REQUIRE(!(d->kind == 3 && do_update), "osm_phys_finalize: the identity operator (kind 3) has no parameters to step");
   hipLaunchKernelGGL(phys_finalize_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, *d, part, red, phi,
                      do_update, loss_out, opt_state, osm_phys_nblk(d->HW));
   return osm::check_launch("phys_finalize_kernel");
@@ -414,6 +558,50 @@ extern "C" int osm_guide_update(const float* mean, const float* logvar, const fl
                      (hipStream_t)stream, mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, grad_out, B,
                      HW);
   return osm::check_launch("guide_update_kernel");
+}
+
+
+extern "C" int osm_guide_update_rng(const float* mean, const float* logvar, const float* g, const float* dx_unet,
+                                    const float* coef, const float* scale4, float clip, float* x_next, float* grad_out,
+                                    float* noise_out, int B, int HW, unsigned long long seed, const int* step, int step_offset,
+                                    int img0, int img_stride, void* stream) {
+  OSM_REQUIRE(mean && logvar && coef && x_next && step && B > 0 && HW > 0, "osm_guide_update_rng: bad argument");
+  OSM_REQUIRE(!g || scale4, "osm_guide_update_rng: guidance needs the per-channel scale");
+  OSM_REQUIRE(HW % 4 == 0, "osm_guide_update_rng: H*W must be a multiple of 4 (one Philox counter per four elements)");
+  OSM_REQUIRE(((reinterpret_cast<size_t>(mean) | reinterpret_cast<size_t>(logvar) | reinterpret_cast<size_t>(g) |
+                reinterpret_cast<size_t>(dx_unet) | reinterpret_cast<size_t>(x_next) | reinterpret_cast<size_t>(grad_out) |
+                reinterpret_cast<size_t>(noise_out)) & 15) == 0, "osm_guide_update_rng: tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(guide_update_rng_kernel, dim3(grid_for((long long)B * HW)), dim3(256), 0, (hipStream_t)stream, mean, logvar,
+                     g, dx_unet, coef, scale4, clip, x_next, grad_out, noise_out, B, HW, (unsigned)(seed & 0xffffffffull),
+                     (unsigned)(seed >> 32), step, step_offset, img0, img_stride);
+  return osm::check_launch("guide_update_rng_kernel");
+}
+
+extern "C" int osm_randn(float* out, int B, long long n, unsigned long long seed, const int* step_dev, int step_const, int img0,
+                         int img_stride, void* stream) {
+  OSM_REQUIRE(out && B > 0 && n > 0, "osm_randn: bad argument");
+  OSM_REQUIRE((reinterpret_cast<size_t>(out) & 15) == 0, "osm_randn: out must be 16-byte aligned");
+  OSM_REQUIRE(n % 4 == 0 || B == 1, "osm_randn: a batch needs n %% 4 == 0 (every image's row starts 16-byte aligned)");
+  hipLaunchKernelGGL(randn_kernel, dim3(grid_for((long long)B * ((n + 3) / 4))), dim3(256), 0, (hipStream_t)stream, out, B, n,
+                     (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), step_dev, step_const, img0, img_stride);
+  return osm::check_launch("randn_kernel");
+}
+
+extern "C" int osm_philox_raw(unsigned* out, long long n4, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                              void* stream) {
+  OSM_REQUIRE(out && n4 > 0, "osm_philox_raw: bad argument");
+  hipLaunchKernelGGL(philox_raw_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, out, n4, c1, c2, c3, k0, k1);
+  return osm::check_launch("philox_raw_kernel");
+}
+
+extern "C" int osm_ddim_update(const float* x0, const float* x, const float* g, const float* dx_unet, const float* noise,
+                               const float* coef, const float* dcoef, const float* scale4, float clip, float* x_next,
+                               float* grad_out, int B, int HW, void* stream) {
+  OSM_REQUIRE(x0 && x && coef && dcoef && x_next && B > 0 && HW > 0, "osm_ddim_update: bad argument");
+  OSM_REQUIRE(!g || scale4, "osm_ddim_update: guidance needs the per-channel scale");
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(grid_for((long long)B * 4 * HW)), dim3(256), 0, (hipStream_t)stream, x0, x, g,
+                     dx_unet, noise, coef, dcoef, scale4, clip, x_next, grad_out, B, HW);
+  return osm::check_launch("ddim_update_kernel");
 }
 
 extern "C" int osm_fetch_coefs(const float* table, int n_rows, int* step, int delta, float* coef_out, float* t_out,

@@ -416,7 +416,10 @@ class UNetEngine:
     def _is_direct_f16(self, cv: _Conv, hw) -> bool:
         """3x3 layer of an f16x3 model on an image smaller than the Winograd tile (8 <= H, W and one of them < 16): direct f16x3."""
         H, W = hw
-        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < 16 or W < 16)
+        # (only where the halo-tile kernel serves the layer: with OSM_CONV_HALO=0, the documented A/B switch, the wfmt-4 direct
+        # image has no kernel and the layer keeps its bf16x6 images -- ADVICE r05)
+        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < 16 or W < 16) and \
+            os.environ.get("OSM_CONV_HALO", "1") != "0"
 
     # ---- registry of "max |.| of this gradient buffer was left behind by its last writer" (f16x3 range hand-over)
     @staticmethod

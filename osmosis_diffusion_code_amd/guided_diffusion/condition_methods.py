@@ -260,11 +260,48 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
 
 @register_conditioning_method(name="ps")
 class PosteriorSampling(ConditioningMethod):
-    """rgb-guidance DPS variant (reference :234-251); secondary path, torch autograd over our UNet op."""
+    """rgb-guidance DPS variant (reference :234-251).  With an identity operator ('noise' / 'rgb_guidance') and the gaussian
+    noiser the data term is ||y - x0[:, 0:3]|| (:35-41): `loss_grad_x0` evaluates it and its x0-gradient with the physics
+    kernels' identity operator (osm_phys_desc.kind 3), which is what the fused sampler loop calls; `conditioning` keeps the
+    reference's autograd form for third-party operators / noisers."""
 
     def __init__(self, operator, noiser, **kwargs):
         super().__init__(operator, noiser)
         self.scale = _parse_scale(kwargs.get("scale", 1.0))
+        self._states = {}
+
+    def hip_ok(self) -> bool:
+        from .measurements import _IdentityOperator
+        return isinstance(self.operator, _IdentityOperator) and getattr(self.noiser, "__name__", None) == "gaussian" and \
+            self.scale.numel() in (1, 4)
+
+    def scale4(self, device):
+        s = self.scale.to(torch.float32)
+        return (s.repeat(4) if s.numel() == 1 else s).to(device).contiguous()
+
+    def loss_grad_x0(self, x0, y, g_out=None, loss_out=None):
+        """loss[b] = ||y[b] - x0[b, 0:3]||_2 and g = d loss / d x0 (zero on the depth channel), per image (B = 1: the reference's
+        batch-global norm).  x0 [B,4,H,W], y [B,3,H,W] contiguous device fp32."""
+        B, HW = x0.shape[0], x0.shape[2] * x0.shape[3]
+        if y.shape[0] != B or y.shape[1] != 3 or x0.shape[1] != 4:
+            raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
+        key = (B, HW, str(x0.device))
+        st = self._states.get(key)
+        if st is None:
+            d = PhysDesc()
+            d.kind, d.depth_type, d.weight_type, d.wdepth_type, d.loss_type, d.optimizer = 3, 0, 0, 0, 0, 0
+            d.gamma_avrg = d.gamma_val = 0.0
+            d.B, d.HW = B, HW
+            f32 = dict(device=x0.device, dtype=torch.float32)
+            st = {"desc": d, "part": torch.empty(B * ops.phys_nblk(HW) * 16, **f32), "red": torch.zeros(B * 16, **f32),
+                  "loss": torch.zeros(B, **f32), "g": torch.empty(B, 4, HW, **f32), "phi": torch.zeros(B, 9, **f32)}
+            while len(self._states) >= 4:
+                self._states.pop(next(iter(self._states)))
+            self._states[key] = st
+        g = g_out if g_out is not None else st["g"]
+        loss = loss_out if loss_out is not None else st["loss"]
+        ops.phys_optimize(st["desc"], x0.contiguous(), y.contiguous(), st["phi"], st["part"], st["red"], loss, g, 1, True)
+        return g.view(x0.shape), loss
 
     def conditioning(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
         norm_grad, norm = self.grad_and_value(x_prev=x_prev, x_0_hat=x_0_hat, measurement=measurement, **kwargs)

@@ -12,9 +12,13 @@ sequence with no host synchronisation:
 
 (the reference performs 4 + n_iter device->host copies per step: gaussian_diffusion.py:216,276,288,
 condition_methods.py:130,224).  Per-timestep coefficients live in a device table indexed by a
-device-side step counter, so the whole step can be replayed from a hipGraph.  Any other
-combination falls back to a generic loop that follows the reference control flow on top of the
-same kernels through torch.autograd.
+device-side step counter, so the whole step can be replayed from a hipGraph.  The rgb-guidance
+configuration (`rgb_guidance=True`: DDPM / DDIM `p_sample` + 'ps' conditioning on an identity operator,
+gaussian noiser) runs through the same loop: osm_phys_* with the identity operator (kind 3) for
+||y - x0[:, 0:3]|| and its gradient, osm_guide_update(_rng) or osm_ddim_update for the step.  The per-step
+noise is drawn inside the update kernel (Philox-4x32-10) unless `noise="aten"` asks for torch's stream.
+Any other combination (third-party conditioners / operators / processors) falls back to a generic loop
+that follows the reference control flow on top of the HIP UNet operator through torch.autograd.
 """
 import math
 
@@ -173,14 +177,14 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ fused (HIP) loop
     def _fast_path_ok(self, model, cond_fn, pretrain_model, rgb_guidance, sample_pattern):
-        from .condition_methods import PosteriorSamplingOsmosis
+        """The conditioner whose step the fused loop implements, or None (-> `_generic_loop`).  Two configurations:
+        the Osmosis one (pretrain_model 'osmosis', 'osmosis' conditioning with gradient_x_prev, a physical operator) and the
+        rgb-guidance one (`rgb_guidance=True`: `DDPM.p_sample` / `DDIM.p_sample` + 'ps' conditioning on an identity operator
+        with the gaussian noiser; gaussian_diffusion.py:231-232,296-302, condition_methods.py:234-251)."""
+        from .condition_methods import PosteriorSampling, PosteriorSamplingOsmosis
         from .unet import UNetModel
         cond = getattr(cond_fn, "__self__", None)
-        if pretrain_model != "osmosis" or rgb_guidance:
-            return None
-        if not isinstance(model, UNetModel) or not isinstance(cond, PosteriorSamplingOsmosis):
-            return None
-        if not cond.gradient_x_prev or not hasattr(cond.operator, "fill_desc"):
+        if not isinstance(model, UNetModel) or model.in_channels != 4:
             return None
         if self.mean_processor.hip_kernel != "osm_posterior" or self.var_processor.hip_kernel != "osm_posterior":
             return None
@@ -189,6 +193,22 @@ class GaussianDiffusion:
         if sample_pattern is not None and sample_pattern.get("pattern") not in (None, "original"):
             if sample_pattern.get("local_M", 1) != 1:
                 return None
+        if rgb_guidance or pretrain_model != "osmosis":
+            # the 'ps' step: only the two registered step rules, un-overridden, and a chain that is guided at every index (the
+            # reference calls the conditioner at every step of this branch: an unguided index raises in its autograd.grad)
+            if type(cond) is not PosteriorSampling or not cond.hip_ok():
+                return None
+            if getattr(type(self), "p_sample", None) not in (DDPM.p_sample, DDIM.p_sample):
+                return None
+            if sample_pattern is not None and not all(self._guidance_flag(sample_pattern, i) for i in (0, self.num_timesteps - 1)):
+                return None
+            if sample_pattern is not None and utilso.set_alternate_length(sample_pattern, 0, self.num_timesteps) != 1:
+                return None
+            return cond
+        if not isinstance(cond, PosteriorSamplingOsmosis):
+            return None
+        if not cond.gradient_x_prev or not hasattr(cond.operator, "fill_desc"):
+            return None
         return cond
 
     def coef_table(self) -> np.ndarray:
@@ -200,6 +220,18 @@ class GaussianDiffusion:
             tab[i, 4:6] = self.var_processor.kernel_coefs(i)
             tab[i, 6] = 0.0 if i == 0 else 1.0
             tab[i, 7] = self._model_timesteps(i)
+        return tab
+
+    def ddim_table(self, eta: float = 0.0) -> np.ndarray:
+        """[T][8] fp32 rows of `DDIM.p_sample` (gaussian_diffusion.py:505-528) for osm_ddim_update:
+        alpha_bar, alpha_bar_prev, eta, noise_on, -, -, -, t_model."""
+        T = self.num_timesteps
+        tab = np.zeros((T, 8), dtype=np.float32)
+        tab[:, 0] = self.alphas_cumprod
+        tab[:, 1] = self.alphas_cumprod_prev
+        tab[:, 2] = eta
+        tab[1:, 3] = 1.0
+        tab[:, 7] = [self._model_timesteps(i) for i in range(T)]
         return tab
 
     @staticmethod
@@ -225,10 +257,23 @@ class GaussianDiffusion:
         return sample_pattern["start_guidance"] * T >= idx >= sample_pattern["stop_guidance"] * T
 
     def _fused_loop(self, model, cond, x_start, measurement, sample_pattern, kwargs, record=False, record_every=150):
+        """One device-resident step per index, for the Osmosis configuration and for the rgb-guidance ('ps') one (`_fast_path_ok`).
+        Per-step noise (gaussian_diffusion.py:266-268 / :497 / :522): by default drawn INSIDE osm_guide_update_rng from the
+        library's Philox-4x32-10 stream (seed: `noise_seed=`, else one draw from torch's CPU generator, so `torch.manual_seed`
+        still fixes the chain); `noise="aten"` (or OSM_STEP_NOISE=aten) draws it with torch on the device in the reference's
+        call order instead (the reference's own realisation for the same seed); `noise_fn=` injects it (parity runs)."""
+        import os
+        from .condition_methods import PosteriorSampling
+        ps = isinstance(cond, PosteriorSampling)
+        ddim = ps and getattr(type(self), "p_sample", None) is DDIM.p_sample
         dev = x_start.device
         B, C, H, W = x_start.shape
         HW = H * W
         T = self.num_timesteps
+        # the loop drives the engine's plans directly and calls the network as model(x, t) (gaussian_diffusion.py:243): a
+        # class-conditional network has no labels here -- the reference's forward asserts (unet.py:713-716); so does this path,
+        # instead of replaying the plans with zero / stale label rows (ADVICE r05)
+        assert getattr(model, "num_classes", None) is None, "must specify y if and only if the model is class-conditional"
         # optional sub-range of the chain (benchmarks / resumed chains): idx = first .. last, descending
         first, last = kwargs.get("index_range", (T - 1, 0))
         if not (0 <= last <= first <= T - 1):
@@ -249,40 +294,63 @@ class GaussianDiffusion:
         table = torch.from_numpy(self.coef_table()).to(dev)
         step = torch.tensor([first], device=dev, dtype=torch.int32)
         coef = torch.zeros(8, **f32)
+        dtable = torch.from_numpy(self.ddim_table(float(kwargs.get("eta", 0.0)))).to(dev) if ddim else None
+        dcoef = torch.zeros(8, **f32) if ddim else None
         x0, mean, logvar = (torch.empty(B, 4, H, W, **f32) for _ in range(3))
         g = torch.empty(B, 4, H, W, **f32)
-        noise = torch.zeros(B, 4, H, W, **f32)
         loss_all = torch.zeros(B, **f32)
         scale4 = cond.scale4(dev)
+        clip = -1.0 if ps else cond.clip_value
         y = measurement.detach().to(dev, torch.float32).contiguous()
-        phi = cond.operator.phi
+        phi = None if ps else cond.operator.phi
         single = len(chunks) == 1
         x_state = eng.x_in if single else torch.empty(B, 4, H, W, **f32)
         x_state.copy_(x_start.detach())
         noise_fn = kwargs.get("noise_fn", None)           # (k, shape) -> tensor : injected noise (parity runs)
         trace = kwargs.get("trace", None)                 # list collecting per-step tensors (tests)
-        draw_measurement_noise = kwargs.get("reference_rng_order", noise_fn is None)
         records = kwargs.get("record_out", [] if record else None)   # (idx, pred_xstart cpu) snapshots
-        # every image of the batch receives the SAME noise (what separate, identically seeded batch-1 runs would draw)
-        noise1 = torch.zeros(1, 4, H, W, **f32) if kwargs.get("shared_noise", False) and B > 1 else None
+        shared = bool(kwargs.get("shared_noise", False)) and B > 1   # every image receives the SAME noise (separately seeded batch-1 runs)
+        source = "fn" if noise_fn is not None else str(kwargs.get("noise", os.environ.get("OSM_STEP_NOISE", "library"))).lower()
+        if source not in ("fn", "library", "aten"):
+            raise ValueError(f"noise must be 'library' or 'aten', got {source!r}")
+        if source == "library" and (HW % 4 != 0):
+            source = "aten"                               # (one Philox counter covers four consecutive elements of an image)
+        # q_sample's unused draw (reference :241) and, for 'ps', p_sample's draw before it: only meaningful on torch's generator
+        draw_measurement_noise = kwargs.get("reference_rng_order", source == "aten") and source == "aten"
+        lib_rng = source == "library" and not ddim        # (DDIM at eta = 0 adds no noise; osm_ddim_update takes a tensor for eta > 0)
+        seed = 0
+        if source == "library":
+            seed = kwargs.get("noise_seed")
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        img_base, img_stride = int(kwargs.get("image_index0", 0)), 0 if shared else 1
+        noise = None if lib_rng else torch.zeros(B, 4, H, W, **f32)
+        noise1 = torch.zeros(1, 4, H, W, **f32) if (shared and source == "aten") else None
+        noise_used = torch.empty(B, 4, H, W, **f32) if (lib_rng and trace is not None) else None
         have_loss = False
         for k, idx in enumerate(range(first, last - 1, -1)):
-            guided = self._guidance_flag(sample_pattern, idx)
-            freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
-            if draw_measurement_noise:                    # q_sample's unused draw (reference :241) keeps RNG order
-                torch.randn_like(y[:1] if noise1 is not None else y)
-            if noise_fn is not None:
+            guided = True if ps else self._guidance_flag(sample_pattern, idx)
+            freeze = False if ps else utilso.is_freeze_phi(sample_pattern, idx, T)
+            if source == "fn":
                 noise.copy_(noise_fn(k, noise.shape))
-            elif noise1 is not None:
-                noise1.normal_()
-                noise.copy_(noise1.expand_as(noise))
-            else:
-                noise.normal_()
+            elif source == "aten":
+                if ps:                                    # DDPM / DDIM.p_sample draw first (:497, :522), then q_sample (:241)
+                    noise1.normal_() if noise1 is not None else noise.normal_()
+                if draw_measurement_noise:
+                    torch.randn_like(y[:1] if noise1 is not None else y)
+                if not ps:
+                    noise1.normal_() if noise1 is not None else noise.normal_()
+                if noise1 is not None:
+                    noise.copy_(noise1.expand_as(noise))
+            elif not lib_rng:                             # library stream, DDIM: as a tensor (used only for eta > 0)
+                ops.randn(noise, B, 4 * HW, seed, step=step, img0=img_base, img_stride=img_stride)   # (before the fetch: counter = idx)
             # every engine's timestep vector is filled from the SAME step counter; the counter moves once, in the last fetch,
             # which always goes through the first engine (stream order: the delta-0 fetches read it before it moves)
             for e2 in engs.values():
                 if e2 is not eng:
                     ops.fetch_coefs(table, step, 0, coef, e2.t_dev, e2.B)
+            if ddim:
+                ops.fetch_coefs(dtable, step, 0, dcoef, eng.t_dev, eng.B)
             ops.fetch_coefs(table, step, -1, coef, eng.t_dev, eng.B)
             if trace is not None:
                 rec = {"x_in": x_state.clone()}
@@ -296,21 +364,33 @@ class GaussianDiffusion:
                 ops.posterior(ce.out, ce.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW)
                 if trace is not None:
                     model_out[c0:c1].copy_(ce.out)
+                gg = dxu = grad_out = None
                 if guided:
-                    cond.loss_grad_x0(x0[c0:c1], y[c0:c1], freeze_phi=freeze, g_out=g[c0:c1], phi=phi[c0:c1],
-                                      loss_out=loss_all[c0:c1])
+                    if ps:
+                        cond.loss_grad_x0(x0[c0:c1], y[c0:c1], g_out=g[c0:c1], loss_out=loss_all[c0:c1])
+                    else:
+                        cond.loss_grad_x0(x0[c0:c1], y[c0:c1], freeze_phi=freeze, g_out=g[c0:c1], phi=phi[c0:c1],
+                                          loss_out=loss_all[c0:c1])
                     have_loss = True
                     ops.posterior_bwd(g[c0:c1], coef, ce.d_out, Bc, HW)
                     ce.run_backward()
+                    gg, dxu = g[c0:c1], ce.dx
                     grad_out = grad_all[c0:c1] if trace is not None else None
-                    ops.guide_update(mean[c0:c1], logvar[c0:c1], g[c0:c1], ce.dx, noise[c0:c1], coef, scale4,
-                                     cond.clip_value, x_state[c0:c1], grad_out, Bc, HW)
+                nz = None if noise is None else noise[c0:c1]
+                sc, cl = (scale4, clip) if guided else (None, -1.0)
+                if ddim:
+                    ops.ddim_update(x0[c0:c1], ce.x_in, gg, dxu, nz, coef, dcoef, sc, cl, x_state[c0:c1], grad_out, Bc, HW)
+                elif lib_rng:
+                    ops.guide_update_rng(mean[c0:c1], logvar[c0:c1], gg, dxu, coef, sc, cl, x_state[c0:c1], grad_out,
+                                         None if noise_used is None else noise_used[c0:c1], Bc, HW, seed, step, step_offset=1,
+                                         img0=img_base + (0 if shared else c0), img_stride=img_stride)   # (+1: the fetch moved the counter)
                 else:
-                    ops.guide_update(mean[c0:c1], logvar[c0:c1], None, None, noise[c0:c1], coef, None, -1.0,
-                                     x_state[c0:c1], None, Bc, HW)
+                    ops.guide_update(mean[c0:c1], logvar[c0:c1], gg, dxu, nz, coef, sc, cl, x_state[c0:c1], grad_out, Bc, HW)
             if trace is not None:
                 rec.update(x0=x0.clone(), mean=mean.clone(), x_out=x_state.clone(), model_out=model_out,
-                           loss=loss_all.clone() if have_loss else None, phi=phi.clone())
+                           loss=loss_all.clone() if have_loss else None, phi=None if phi is None else phi.clone())
+                if noise_used is not None:
+                    rec["noise"] = noise_used.clone()
                 if guided:
                     rec["grad"] = grad_all
                 trace.append(rec)
@@ -318,10 +398,12 @@ class GaussianDiffusion:
             if records is not None and ((idx % record_every == 0) or idx == 0 or idx == 999):
                 records.append((idx, x0.detach().cpu()))
         img = x_state.clone()
-        variables = cond.operator.optimize(freeze_phi=True)
-        loss_np = loss_all.detach().cpu().numpy() if have_loss else None
         if record and records:
             self._save_process_grid(records, kwargs.get("save_grids_path"), kwargs.get("original_file_name"))
+        if ps:                                            # the rgb-guidance branch returns the sample only (:339-340)
+            return img
+        variables = cond.operator.optimize(freeze_phi=True)
+        loss_np = loss_all.detach().cpu().numpy() if have_loss else None
         return img, variables, loss_np, x0.detach().cpu()
 
     @staticmethod
@@ -359,21 +441,20 @@ class GaussianDiffusion:
         if cond is not None:
             return self._fused_loop(model, cond, x_start, measurement, sample_pattern, kwargs, record=record,
                                     record_every=record_every)
-        if record:
-            import warnings
-            warnings.warn("record=True is honoured by the fused Osmosis loop only; this configuration runs the generic "
-                          "autograd loop, which does not record intermediate images")
         return self._generic_loop(model, x_start, measurement, measurement_cond_fn, pretrain_model,
-                                  rgb_guidance, sample_pattern, kwargs)
+                                  rgb_guidance, sample_pattern, kwargs, record=record, record_every=record_every)
 
     def _generic_loop(self, model, x_start, measurement, cond_fn, pretrain_model, rgb_guidance, sample_pattern,
-                      kwargs):
-        """Reference control flow (gaussian_diffusion.py:213-340) on top of the same kernels via
-        torch.autograd.  Recording of intermediate images is a driver concern and not done here."""
+                      kwargs, record=False, record_every=150):
+        """Third-party conditioners / operators / processors the fused loop has no kernels for: the reference's control flow
+        (gaussian_diffusion.py:213-340) over `p_mean_variance` / `p_sample` with torch.autograd through the HIP UNet operator.
+        `record=True` snapshots pred_xstart at the reference's indices (:308-327) here as well."""
         img = x_start
         device = x_start.device
         T = self.num_timesteps
         loss = variable_dict = out = None
+        records = kwargs.get("record_out", [] if record else None)
+        osmosis = pretrain_model == "osmosis" and not rgb_guidance
         for idx in range(T - 1, -1, -1):
             time = torch.tensor([idx] * img.shape[0], device=device)
             guided = self._guidance_flag(sample_pattern, idx) if sample_pattern is not None else True
@@ -386,25 +467,27 @@ class GaussianDiffusion:
                     out = self.p_mean_variance(model=model, x=img, t=time)
                     out["sample"] = out["mean"]
                 noisy_measurement = self.q_sample(measurement, t=time)
-                if pretrain_model == "osmosis" and not rgb_guidance:
-                    freeze = utilso.is_freeze_phi(sample_pattern, idx, T)
-                    if guided:
-                        img, loss, variable_dict, _grads, _aux = cond_fn(
-                            x_t=out["sample"], measurement=measurement, noisy_measurement=noisy_measurement,
-                            x_prev=img, x_0_hat=out["pred_xstart"], freeze_phi=freeze,
-                            time_index=float(idx) / T)
-                    else:
-                        img = out["sample"]
-                    noise = torch.randn_like(img)
+                if not osmosis:
+                    img, loss = cond_fn(x_t=out["sample"], measurement=measurement, noisy_measurement=noisy_measurement,
+                                        x_prev=img, x_0_hat=out["pred_xstart"])
                     img = img.detach()
-                    if idx != 0:
-                        img = img + torch.exp(0.5 * out["log_variance"].detach()) * noise
+                    continue
+                if guided:
+                    img, loss, variable_dict, _grads, _aux = cond_fn(
+                        x_t=out["sample"], measurement=measurement, noisy_measurement=noisy_measurement, x_prev=img,
+                        x_0_hat=out["pred_xstart"], freeze_phi=utilso.is_freeze_phi(sample_pattern, idx, T),
+                        time_index=float(idx) / T)
                 else:
-                    img, loss = cond_fn(x_t=out["sample"], measurement=measurement,
-                                        noisy_measurement=noisy_measurement, x_prev=img,
-                                        x_0_hat=out["pred_xstart"])
-                    img = img.detach()
-        if pretrain_model == "osmosis" and not rgb_guidance:
+                    img = out["sample"]
+                noise = torch.randn_like(img)
+                img = img.detach()
+                if idx != 0:
+                    img = img + torch.exp(0.5 * out["log_variance"].detach()) * noise
+            if records is not None and ((idx % record_every == 0) or idx == 0 or idx == 999):
+                records.append((idx, out["pred_xstart"].detach().cpu()))
+        if record and records:
+            self._save_process_grid(records, kwargs.get("save_grids_path"), kwargs.get("original_file_name"))
+        if osmosis:
             return img, variable_dict, loss, out["pred_xstart"].detach().cpu()
         return img
 
@@ -457,30 +540,43 @@ class _WrappedModel:
 
 @register_sampler(name="ddpm")
 class DDPM(SpacedDiffusion):
+    """Ancestral step (reference :492-502).  In the fused loop it IS osm_guide_update / osm_guide_update_rng (the row's
+    `noise_on` switches the noise off at index 0); `p_sample` is the same row applied to torch tensors, for conditioners the
+    fused loop has no kernels for (`_generic_loop`, autograd through `pred_xstart`)."""
+
     def p_sample(self, model, x, t):
         out = self.p_mean_variance(model, x, t)
-        sample = out["mean"]
-        noise = torch.randn_like(x)
-        if t[0] != 0:
-            sample = sample + torch.exp(0.5 * out["log_variance"]) * noise
+        z = torch.randn_like(x)                            # drawn at every index (the reference's RNG order), used when noise_on
+        noise_on = int(t[0]) != 0
+        sample = out["mean"] + torch.exp(0.5 * out["log_variance"]) * z if noise_on else out["mean"]
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
 
 @register_sampler(name="ddim")
 class DDIM(SpacedDiffusion):
+    """DDIM step (reference :505-535, Song et al. eq. 12).  In the fused loop it IS osm_ddim_update fed by `ddim_table`;
+    `p_sample` applies the same fp32 row scalars to torch tensors (`_generic_loop`)."""
+
+    def step_scalars(self, idx: int, eta: float = 0.0):
+        """fp32 scalars of index idx in the kernel's operation order: (sqrt_recip_ac, sqrt_recipm1_ac, sqrt(ab_prev),
+        sqrt(1 - ab_prev - sigma^2), sigma)."""
+        f = np.float32
+        ab, abp = f(self.alphas_cumprod[idx]), f(self.alphas_cumprod_prev[idx])
+        sigma = f(eta) * np.sqrt((f(1) - abp) / (f(1) - ab)) * np.sqrt(f(1) - ab / abp)
+        return (f(self.sqrt_recip_alphas_cumprod[idx]), f(self.sqrt_recipm1_alphas_cumprod[idx]), np.sqrt(abp),
+                np.sqrt(f(1) - abp - sigma * sigma), sigma)
+
     def p_sample(self, model, x, t, eta=0.0):
         out = self.p_mean_variance(model, x, t)
-        eps = self.predict_eps_from_x_start(x, t, out["pred_xstart"])
-        ab = extract_and_expand(self.alphas_cumprod, t, x)
-        ab_prev = extract_and_expand(self.alphas_cumprod_prev, t, x)
-        sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
-        noise = torch.randn_like(x)
-        sample = out["pred_xstart"] * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
-        if t[0] != 0:
-            sample = sample + sigma * noise
-        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+        idx = int(t[0])
+        c0, c1, sa, sb, sigma = (float(v) for v in self.step_scalars(idx, eta))
+        x0 = out["pred_xstart"]
+        z = torch.randn_like(x)                            # drawn at every index (the reference's RNG order)
+        sample = x0 * sa + sb * ((c0 * x - x0) / c1)
+        if idx != 0:
+            sample = sample + sigma * z
+        return {"sample": sample, "pred_xstart": x0}
 
     def predict_eps_from_x_start(self, x_t, t, pred_xstart):
-        c1 = extract_and_expand(self.sqrt_recip_alphas_cumprod, t, x_t)
-        c2 = extract_and_expand(self.sqrt_recipm1_alphas_cumprod, t, x_t)
-        return (c1 * x_t - pred_xstart) / c2
+        c0, c1 = (float(v) for v in self.step_scalars(int(t[0]))[:2])
+        return (c0 * x_t - pred_xstart) / c1

@@ -408,6 +408,30 @@ def guide_update(mean, logvar, g, dx_unet, noise, coef, scale4, clip, x_next, gr
          keep=(mean, logvar, g, dx_unet, noise, coef, scale4, x_next, grad_out))
 
 
+def guide_update_rng(mean, logvar, g, dx_unet, coef, scale4, clip, x_next, grad_out, noise_out, B, HW, seed, step, step_offset=0,
+                     img0=0, img_stride=1):
+    """osm_guide_update with the step noise drawn in the kernel: Philox-4x32-10 keyed by `seed`, counter (element / 4,
+    img0 + b * img_stride, *step + step_offset)."""
+    call("osm_guide_update_rng", ptr(mean), ptr(logvar), ptr(g), ptr(dx_unet), ptr(coef), ptr(scale4), float(clip), ptr(x_next),
+         ptr(grad_out), ptr(noise_out), B, HW, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step), int(step_offset), int(img0), int(img_stride), _s(),
+         keep=(mean, logvar, g, dx_unet, coef, scale4, x_next, grad_out, noise_out, step))
+
+
+def randn(out, B, n, seed, step=None, step_const=0, img0=0, img_stride=1):
+    """out[B][n] ~ N(0, 1) from the library's generator (what osm_guide_update_rng draws for (seed, image, step) when n = 4 H W)."""
+    call("osm_randn", ptr(out), int(B), int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step), int(step_const), int(img0), int(img_stride), _s(),
+         keep=(out, step))
+
+
+def philox_raw(out, n4, c1, c2, c3, k0, k1):
+    call("osm_philox_raw", ptr(out), int(n4), int(c1), int(c2), int(c3), int(k0), int(k1), _s(), keep=(out,))
+
+
+def ddim_update(x0, x, g, dx_unet, noise, coef, dcoef, scale4, clip, x_next, grad_out, B, HW):
+    call("osm_ddim_update", ptr(x0), ptr(x), ptr(g), ptr(dx_unet), ptr(noise), ptr(coef), ptr(dcoef), ptr(scale4), float(clip),
+         ptr(x_next), ptr(grad_out), B, HW, _s(), keep=(x0, x, g, dx_unet, noise, coef, dcoef, scale4, x_next, grad_out))
+
+
 def fetch_coefs(table, step, delta, coef_out, t_out, B):
     """table: [n_rows][8] device fp32; the device-side row counter `step` is clamped to the table."""
     call("osm_fetch_coefs", ptr(table), int(table.shape[0]), ptr(step), delta, ptr(coef_out), ptr(t_out), B, _s(),

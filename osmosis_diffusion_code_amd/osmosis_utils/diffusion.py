@@ -56,6 +56,8 @@ class GaussianDiffusion:
         from ..guided_diffusion.unet import UNetModel
         if not isinstance(net, UNetModel):
             raise NotImplementedError("inverse() drives the HIP UNetModel (there is no eager fallback)")
+        # net(x, t) without labels (osmosis_utils/diffusion.py:104 of the reference): a class-conditional network asserts there
+        assert net.num_classes is None, "must specify y if and only if the model is class-conditional"
         noise_fn = kwargs.get("noise_fn", None)          # (k, shape) -> tensor : injected noise (parity runs)
         dev = torch.device(device)
         if x is None:

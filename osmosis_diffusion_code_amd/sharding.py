@@ -62,13 +62,19 @@ def gather_per_image(values: Sequence[float], n_items: int, device=None) -> List
 # stream instead of the whole device (a wedged RCCL kernel would block `torch.cuda.synchronize()`).
 class RankSync:
     ORDER = ("rccl", "gloo", "files")
+    _instances = 0              # RankSync objects this process has built (SPMD: the same number on every rank): part of the job token
 
     def __init__(self, rank: int, world: int, device=None, sync_dir: str = None, probe_timeout_s: float = 120.0,
                  force_fail: Sequence[str] = ()):
         import os
+        import sys
+        import time
         self.rank, self.world, self.device = int(rank), int(world), device
         self.transport, self.failures = "none", {}
         self.device_sync_safe = True
+        self.setup_s = 0.0
+        RankSync._instances += 1
+        self._seq = RankSync._instances
         self._round = 0
         self._mine = []             # files this rank wrote (removed by close())
         self._group = None
@@ -82,13 +88,19 @@ class RankSync:
         os.makedirs(sync_dir, exist_ok=True)
         self.dir = sync_dir
         self._timeout = float(probe_timeout_s)
+        t_all = time.monotonic()
+
+        def say(msg):           # a broken node must not look like silence (up to probe_timeout_s per transport): stderr, at once
+            print("[RankSync rank %d/%d] %s" % (self.rank, self.world, msg), file=sys.stderr, flush=True)
         self._nonce = self._agree_on_nonce()
         force_fail = set(force_fail) | set(filter(None, os.environ.get("OSM_SYNC_FORCE_FAIL", "").split(",")))
         for name in self.ORDER:
             if name == "files":
                 self.transport = "files"
                 break
+            t0 = time.monotonic()
             ok, why = (False, "forced failure (test)") if name in force_fail else self._probe(name)
+            say("probe %s: %s in %.1f s%s" % (name, "ok" if ok else "FAILED", time.monotonic() - t0, "" if ok else " (%s)" % why))
             votes = self._file_gather("vote_" + name, [1.0 if ok else 0.0])
             if not ok:
                 self.failures[name] = why
@@ -97,6 +109,8 @@ class RankSync:
                 break
             if ok:
                 self.failures[name] = "failed on rank(s) %s" % [r for r, v in enumerate(votes) if v[0] != 1.0]
+        self.setup_s = time.monotonic() - t_all
+        say("transport = %s, device = %s, set up in %.1f s" % (self.transport, self.device, self.setup_s))
 
     @property
     def round(self) -> int:
@@ -125,7 +139,8 @@ class RankSync:
                     os.remove(os.path.join(self.dir, f))
                 except OSError:
                     pass
-            tok = {"pid": os.getpid(), "start": self._proc_start(os.getpid()), "born": time.time(), "nonce": uuid.uuid4().hex}
+            tok = {"pid": os.getpid(), "start": self._proc_start(os.getpid()), "born": time.time(), "nonce": uuid.uuid4().hex,
+                   "seq": self._seq}
             with open(path + ".tmp", "w") as f:
                 json.dump(tok, f)
             os.replace(path + ".tmp", path)
@@ -138,8 +153,11 @@ class RankSync:
                     tok = json.load(f)
                 # this job's token is the one whose writer is still running (pid + kernel start time identify a process on
                 # the node); without /proc: a token not older than this process by more than two minutes
+                # ... and that belongs to THIS RankSync of that process (a second RankSync in the same processes and directory must
+                # not adopt the first one's token before rank 0 has replaced it: ADVICE r05)
                 alive = self._proc_start(int(tok["pid"]))
-                if (alive is not None and alive == tok["start"]) or (tok["start"] is None and tok["born"] > my_born - 120.0):
+                if int(tok.get("seq", self._seq)) == self._seq and (
+                        (alive is not None and alive == tok["start"]) or (tok["start"] is None and tok["born"] > my_born - 120.0)):
                     return str(tok["nonce"])
             except (OSError, ValueError, KeyError, TypeError):
                 pass
@@ -320,6 +338,11 @@ class RankSync:
             except OSError:
                 pass
         self._mine = []
+        if self.rank == 0:          # the job token goes with the job: a later RankSync in this directory waits for ITS rank 0's token
+            try:
+                os.remove(os.path.join(self.dir, "token_r0.json"))
+            except OSError:
+                pass
         if not self._dist_up:
             return
         import torch.distributed as dist

@@ -22,6 +22,7 @@ table holds weak references, so an engine dies with its model.  An engine keeps 
 the autograd node of `unet_fwd` remembers which pass it belongs to (the engine's pass counter, a Python-side attribute, not an
 operator output -- outputs are functions of the inputs alone, so fake-tensor tracing and `torch.library.opcheck` see pure
 operators) and raises instead of differentiating through activations a later forward has overwritten."""
+import itertools
 import weakref
 from typing import List, Tuple
 
@@ -31,10 +32,14 @@ from . import ops
 from ._lib import OsmosisHipError, PhysDesc
 
 _ENGINES = weakref.WeakValueDictionary()
+_next_handle = itertools.count(1)
 
 
 def engine_handle(eng) -> int:
-    h = id(eng)
+    """A handle that is never reused (id(eng) can be, once the engine is collected -- and tickets restart at 0)."""
+    h = getattr(eng, "_osm_handle", None)
+    if h is None:
+        h = eng._osm_handle = next(_next_handle)
     _ENGINES[h] = eng
     return h
 
@@ -75,11 +80,12 @@ def _unet_bwd_fake(grad_out, engine):
 
 def _unet_setup(ctx, inputs, output):
     ctx.engine = inputs[2]
-    ctx.ticket = _engine(inputs[2]).ticket        # the forward pass this node belongs to (eager mode: checked below)
+    ctx.engine_obj = _engine(inputs[2])           # strong reference: the activations backward needs live in this engine
+    ctx.ticket = ctx.engine_obj.ticket            # the forward pass this node belongs to (eager mode: checked below)
 
 
 def _unet_backward(ctx, grad_out):
-    if _engine(ctx.engine).ticket != ctx.ticket:
+    if _engine(ctx.engine) is not ctx.engine_obj or ctx.engine_obj.ticket != ctx.ticket:
         raise RuntimeError("UNet activations were overwritten by a later forward before backward ran")
     return torch.ops.osmosis.unet_bwd_data(grad_out, ctx.engine), None, None
 

@@ -238,6 +238,153 @@ def test_rgb_guidance_ps_chain_matches_reference(pkg, name, monkeypatch):
     assert err < 1e-3
 
 
+def _ps_setup(pkg, name):
+    unet, gd, M, CM = pkg
+    g = np.load(os.path.join(GOLD, "loop_ps.npz"))
+    model = make_model(unet)
+    operator = M.get_operator("rgb_guidance", device=DEV, batch_size=1)
+    cond = CM.get_conditioning_method("ps", operator, M.get_noise("gaussian", sigma=0.05), scale="0.6,0.5,0.4,0.0")
+    sampler = gd.get_sampler(name)(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                   model_mean_type="epsilon", model_var_type="learned_range", dynamic_threshold=False,
+                                   clip_denoised=False, rescale_timesteps=False)
+    return g, model, cond, sampler
+
+
+@pytest.mark.parametrize("name", ["ddpm", "ddim"])
+def test_rgb_guidance_ps_chain_fused_matches_reference(pkg, name, monkeypatch):
+    """SURVEY a22 on the FUSED kernels (round 6): the same reference chain as above through `_fused_loop` -- osm_phys_* with
+    the identity operator (kind 3) for ||y - x0[:, 0:3]|| and its gradient, osm_guide_update (DDPM) / osm_ddim_update (DDIM)
+    for the step; the generic autograd loop must not be entered.  Noise: the reference's x-shaped draws, injected."""
+    unet, gd, M, CM = pkg
+    g, model, cond, sampler = _ps_setup(pkg, name)
+
+    def no_generic(*a, **k):
+        raise AssertionError("the rgb-guidance chain fell back to the generic loop")
+    monkeypatch.setattr(type(sampler), "_generic_loop", no_generic)
+    draws = torch.from_numpy(g[f"{name}.draws_x"]).to(DEV)
+    trace = []
+    img = sampler.p_sample_loop(model=model, x_start=torch.from_numpy(g[f"{name}.x_T"]).to(DEV),
+                                measurement=torch.from_numpy(g[f"{name}.y"]).to(DEV), measurement_cond_fn=cond.conditioning,
+                                record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=True,
+                                sample_pattern=PATTERN, noise_fn=lambda k, shape: draws[k], trace=trace)
+    assert isinstance(img, torch.Tensor) and len(trace) == 10
+    losses = [float(r["loss"][0]) for r in trace]
+    assert np.allclose(losses, g[f"{name}.loss"], rtol=1e-4), (losses, g[f"{name}.loss"])
+    err = float((img.detach().cpu() - torch.from_numpy(g[f"{name}.final_img"])).abs().max())
+    print(name, "fused rgb-guidance chain max-abs error", err)
+    assert err < 2e-5
+
+
+def test_generic_loop_honours_record(pkg, tmp_path):
+    """VERDICT r05 missing 4: `record=True` is honoured by every loop (reference gaussian_diffusion.py:308-333), also by the
+    generic autograd loop a third-party conditioner runs through."""
+    unet, gd, M, CM = pkg
+    g, model, cond, sampler = _ps_setup(pkg, "ddpm")
+    calls = []
+
+    def third_party(**kw):                      # a plain function: no `__self__`, so the fused loop does not recognise it
+        calls.append(1)
+        return cond.conditioning(**kw)
+    recs = []
+    torch.manual_seed(0)
+    img = sampler.p_sample_loop(model=model, x_start=torch.from_numpy(g["ddpm.x_T"]).to(DEV).requires_grad_(),
+                                measurement=torch.from_numpy(g["ddpm.y"]).to(DEV), measurement_cond_fn=third_party,
+                                record=True, save_root=None, pretrain_model="osmosis", rgb_guidance=True,
+                                sample_pattern=PATTERN, record_every=3, record_out=recs,
+                                save_grids_path=str(tmp_path), original_file_name="img7")
+    assert len(calls) == 10 and torch.isfinite(img).all()
+    assert [i for i, _ in recs] == [9, 6, 3, 0]
+    assert os.path.exists(os.path.join(str(tmp_path), "img7_process.png"))
+
+
+def test_library_step_noise(pkg):
+    """Round 6: the per-step noise is drawn inside osm_guide_update_rng (Philox-4x32-10, counter = (element / 4, image, step)).
+    (i) the raw generator reproduces the Random123 known-answer vectors; (ii) osm_randn has the moments of N(0, 1) and
+    independent per-image / per-step streams; (iii) the fused loop's chain is reproducible from its seed, differs between
+    seeds, does not depend on how a batch is chunked, and `shared_noise` gives every image of a batch the batch-1 chain."""
+    from osmosis_diffusion_code_amd import ops
+    unet, gd, M, CM = pkg
+    # (i) Random123 kat_vectors: philox4x32-10, counter / key all zero, all ones, and the pi digits
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        n4 = (ctr[0] & 0xffffffff) + 1                       # word 0 of the counter is the element-quad index
+        out = torch.zeros(4 * n4 if n4 <= 4096 else 4, device=DEV, dtype=torch.int32)
+        if n4 > 4096:
+            continue                                        # (quad index 0xffffffff / 0x243f6a88: checked through numpy below)
+        ops.philox_raw(out, n4, ctr[1], ctr[2], ctr[3], key[0], key[1])
+        got = tuple(int(v) & 0xffffffff for v in out[-4:].cpu())
+        assert got == want, (hex(got[0]), hex(want[0]))
+
+    def philox_np(c, k):                                    # the published algorithm, for the vectors a launch cannot reach
+        c, k = [int(v) for v in c], [int(v) for v in k]
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return tuple(c)
+    for ctr, key, want in kat:
+        assert philox_np(ctr, key) == want
+    out = torch.zeros(4 * 1000, device=DEV, dtype=torch.int32)
+    ops.philox_raw(out, 1000, 7, 8, 9, 10, 11)
+    ref = np.array([philox_np((q, 7, 8, 9), (10, 11)) for q in (0, 1, 999)], dtype=np.uint32)
+    got = out.view(1000, 4)[[0, 1, 999]].cpu().numpy().astype(np.uint32)
+    assert (got == ref).all()
+    # (ii) moments, independence
+    n = 4 * 256 * 256
+    z = torch.empty(3, n, device=DEV)
+    ops.randn(z, 3, n, seed=1234, step_const=5, img0=0)
+    z64 = z.double()
+    assert abs(float(z64.mean())) < 4e-3 and abs(float(z64.var()) - 1.0) < 6e-3
+    assert abs(float((z64 ** 3).mean())) < 2e-2 and abs(float((z64 ** 4).mean()) - 3.0) < 5e-2
+    assert torch.isfinite(z).all() and float(z.abs().max()) < 6.5
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        assert abs(float((z64[a] * z64[b]).mean())) < 6e-3       # distinct images: uncorrelated
+    z2 = torch.empty(1, n, device=DEV)
+    ops.randn(z2, 1, n, seed=1234, step_const=5, img0=2)
+    assert torch.equal(z2[0], z[2])                              # an image's stream does not depend on the batch it is drawn in
+    ops.randn(z2, 1, n, seed=1234, step_const=6, img0=2)
+    assert abs(float((z2[0].double() * z64[2]).mean())) < 6e-3   # another step: another stream
+    ops.randn(z2, 1, n, seed=1235, step_const=5, img0=2)
+    assert abs(float((z2[0].double() * z64[2]).mean())) < 6e-3   # another seed: another stream
+    # (iii) through the fused loop
+    g = dict(np.load(os.path.join(GOLD, "loop_underwater_physical_revised.npz")))
+    spec = OPERATORS["underwater_physical_revised"]
+    model = make_model(unet)
+    x_T = torch.from_numpy(g["x_T"]).to(DEV)
+    y = torch.from_numpy(g["y"]).to(DEV)
+
+    def chain(B, seed, monkey_cap=None, **kw):
+        operator = M.get_operator("underwater_physical_revised", device=DEV, batch_size=B, **spec["operator"])
+        cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+        trace = []
+        if monkey_cap is not None:
+            os.environ["OSM_MAX_BATCH"] = str(monkey_cap)
+        try:
+            img = make_sampler(gd).p_sample_loop(model=model, x_start=x_T.repeat(B, 1, 1, 1), measurement=y.repeat(B, 1, 1, 1),
+                                                 measurement_cond_fn=cond.conditioning, record=False, save_root=None,
+                                                 pretrain_model="osmosis", sample_pattern=PATTERN, noise_seed=seed, trace=trace, **kw)[0]
+        finally:
+            os.environ.pop("OSM_MAX_BATCH", None)
+        return img, trace
+    a, tr = chain(1, 77)
+    assert "noise" in tr[0] and abs(float(tr[0]["noise"].double().var()) - 1.0) < 0.1
+    assert float(tr[-1]["noise"].abs().max()) == 0.0            # index 0: no noise (gaussian_diffusion.py:267)
+    b, _ = chain(1, 77)
+    assert torch.equal(a, b)                                    # reproducible from the seed
+    c, _ = chain(1, 78)
+    assert float((a - c).abs().max()) > 1e-3                    # another seed: another chain
+    d3, tr3 = chain(3, 77)
+    assert torch.allclose(d3[0:1], a, atol=2e-5)                # image 0 of a batch = the batch-1 chain (same index, same stream)
+    assert float((d3[1] - d3[0]).abs().max()) > 1e-3            # images of a batch get different noise
+    e3, _ = chain(3, 77, monkey_cap=2)                          # the batch walked in chunks of two sizes
+    assert torch.allclose(e3, d3, atol=2e-5)
+    s3, _ = chain(3, 77, shared_noise=True)
+    assert torch.allclose(s3[1:2], a, atol=2e-5) and torch.allclose(s3[2:3], a, atol=2e-5)
+
+
 def test_full_size_batch_equals_independent_images(pkg):
     """BASELINE-size property (no oracle needed): a B = 2 batch through the fused guided loop at 256x256 on the
     552.8 M-parameter network equals two B = 1 chains (images are independent Markov chains: per-image reductions,
