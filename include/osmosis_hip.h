@@ -178,7 +178,10 @@ typedef struct osm_attn_desc {
   float* ws;
   int arith;            /* osm_attn_flash_*: 0 = bf16x6 (fp32-class: three bf16 planes per operand, six MFMAs per product); 1 = ONE
                            IEEE-half plane per operand, one fp16 MFMA per product, fp32 accumulation and softmax -- the arithmetic of
-                           the reference's use_fp16 attention (unet.py:426-433 on half tensors).  Other entry points ignore it */
+                           the reference's use_fp16 attention (unet.py:426-433 on half tensors); 2 = "f16x3": every fp32 operand
+                           tile scaled by a power of two (its max |.| is found in the kernel) and split into two IEEE-half terms,
+                           three fp16 MFMAs per product, fp32 accumulation and softmax (fp32-class, ~22-bit operands: the
+                           convolutions' default arithmetic).  Other entry points ignore it */
 } osm_attn_desc;
 /* Flash-style core on the matrix cores for 64-wide heads and T = 64 or a multiple of 128 (the 8x8 / 16x16 / 32x32 blocks):
  * logits / probabilities stay in registers, fp32 operands are split into 3 bf16 planes (6 MFMAs per product, fp32-class),

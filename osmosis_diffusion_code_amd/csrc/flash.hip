@@ -424,6 +424,485 @@ __global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_kernel(FlashArgs a) {
   }
 }
 
+// ================================================================================================ f16x3 ("HP") instances
+// The same three kernels in the convolutions' default arithmetic (mfma_split.h, round 3): every fp32 operand is scaled by a power
+// of two into the fp16 range and split into TWO IEEE-half terms (~22 bits), a product is three fp16 MFMAs (h0 g0 + h0 g1 + h1 g0)
+// instead of six bf16 ones, and a split costs 6 VALU per 4 values instead of 22.  osm_attn_desc.arith = 2.
+// Operand ranges are found IN the kernels (no side channel from the producers): a 32 x 64 operand tile is spread over exactly
+// one wave, so its max |.| is the lane's max over its 32 values and one 6-step butterfly; the power-of-two scale is undone
+// exactly on the accumulator.  Products that ACCUMULATE over tiles whose scales differ (O += P V, dq += dS K, dv += P^T dO,
+// dk += dS^T Q) keep a running scale exponent -- the smallest seen, i.e. the largest operand -- and rescale the accumulator by an
+// exact power of two when it falls, as the online softmax does with its running max (forward: folded into its alpha).  P is in
+// [0, 1] and needs no scale; dS = P (dP - delta) is scaled per COLUMN of the C layout (one query / key = one lane and its
+// partner lane ^ 32: a column scale of a B operand factors out of the product per accumulator column, lane-locally).
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return v;
+}
+// e with max * 2^e in [2^11, 2^12); 0 for zero / denormal / non-finite maxima (a NaN or Inf operand then poisons the result)
+__device__ __forceinline__ int scale_exp_of(unsigned maxbits) {
+  const int ex = (int)(maxbits >> 23);
+  if (ex == 0 || ex == 255) return 0;
+  return min(max(11 - (ex - 127), -100), 100);
+}
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + min(max(e, -126), 127)) << 23); }
+__device__ __forceinline__ unsigned max8_bits(const float4& a, const float4& b, unsigned m) {
+  m = max(m, max(max(abs_bits(a.x), abs_bits(a.y)), max(abs_bits(a.z), abs_bits(a.w))));
+  return max(m, max(max(abs_bits(b.x), abs_bits(b.y)), max(abs_bits(b.z), abs_bits(b.w))));
+}
+struct Raw8 { float4 a, b; };
+__device__ __forceinline__ Raw8 raw_row(const float* __restrict__ X, long long ld, long long row, int col, int s, int h) {
+  const float* p = X + row * ld + col + 16 * s + 8 * h;
+  return Raw8{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+}
+__device__ __forceinline__ Raw8 raw_gather(const float* __restrict__ X, long long ld, long long row0, int col, int s, int h) {
+  const float* p = X + (row0 + 16 * s + 4 * h) * ld + col;
+  return Raw8{make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]), make_float4(p[8 * ld], p[9 * ld], p[10 * ld], p[11 * ld])};
+}
+// 8 fp32 x sc -> the two half planes of one fragment
+__device__ __forceinline__ void split_hp(const Raw8& r, float sc, uint4 (&f)[2]) {
+  uint2 lo[2], hi[2];
+  split_f16x2(make_float4(r.a.x * sc, r.a.y * sc, r.a.z * sc, r.a.w * sc), lo);
+  split_f16x2(make_float4(r.b.x * sc, r.b.y * sc, r.b.z * sc, r.b.w * sc), hi);
+  f[0] = make_uint4(lo[0].x, lo[0].y, hi[0].x, hi[0].y);
+  f[1] = make_uint4(lo[1].x, lo[1].y, hi[1].x, hi[1].y);
+}
+// accumulator registers [8 s .. 8 s + 7] x sc -> fragment of step s
+__device__ __forceinline__ void split_acc_hp(const f32x16& c, int s, float sc, uint4 (&f)[2]) {
+  const Raw8 r = s == 0 ? Raw8{make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7])}
+                        : Raw8{make_float4(c[8], c[9], c[10], c[11]), make_float4(c[12], c[13], c[14], c[15])};
+  split_hp(r, sc, f);
+}
+// c += (a0 + a1)(b0 + b1) without a1 b1: smallest terms first
+__device__ __forceinline__ f32x16 mma_hp(const uint4 (&a)[2], const uint4 (&b)[2], f32x16 c) {
+  c = mma16h(a[1], b[0], c);
+  c = mma16h(a[0], b[1], c);
+  return mma16h(a[0], b[0], c);
+}
+
+template <int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_fwd_hp_kernel(FlashArgs a) {
+  __shared__ float os[WV][DH][33];
+  __shared__ float ms[WV][32];
+  __shared__ float ls[WV][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const long long ld = a.ldqkv;
+
+  uint4 qf[4][2];   // B operand of S^T = K (scale Q)^T: k = d, column = this lane's query; x 2^eq
+  int eq;
+  {
+    Raw8 r[4];
+    unsigned m = 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { r[s] = raw_row(Q, ld, rb + q0 + lr, 0, s, h); m = max8_bits(r[s].a, r[s].b, m); }
+    eq = scale_exp_of(abs_bits(__uint_as_float(wave_max_bits(m)) * a.scale));
+    const float sc = a.scale * pow2i(eq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_hp(r[s], sc, qf[s]);
+  }
+  f32x16 o0 = zero16(), o1 = zero16();   // O^T x 2^ev: rows d (0..31 | 32..63), column = query
+  int ev = 100;                          // running scale exponent of the V operand (falls as larger |V| tiles arrive)
+  float m = -INFINITY, l = 0.f;
+  const int kw = a.T / a.nw;
+  const int kend = wave < a.nw ? (wave + 1) * kw : 0;
+  for (int kb = wave * kw; kb < kend; kb += 32) {
+    f32x16 sa = zero16();   // S^T of keys kb .. kb + 31, x 2^(ek + eq)
+    float cs;               // 2^-(ek + eq)
+    {
+      Raw8 r[4];
+      unsigned mk = 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { r[s] = raw_row(K, ld, rb + kb + lr, 0, s, h); mk = max8_bits(r[s].a, r[s].b, mk); }
+      const int ek = scale_exp_of(wave_max_bits(mk));
+      const float sc = pow2i(ek);
+      cs = pow2i(-(ek + eq));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint4 kf[2];
+        split_hp(r[s], sc, kf);
+        sa = mma_hp(kf, qf[s], sa);
+      }
+    }
+    // the V tile (both k16-steps, both halves of d) goes out before the softmax: its latency runs under it
+    Raw8 rv[2][2];
+    unsigned mv = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      rv[t][0] = raw_gather(V, ld, rb + kb, lr, t, h);
+      rv[t][1] = raw_gather(V, ld, rb + kb, 32 + lr, t, h);
+    }
+    // online softmax of this lane's query over its 16 keys (the other 16 sit in lane ^ 32)
+    float mx = sa[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sa[e]);
+    mx *= cs;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    float alpha = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      sa[e] = __expf(fmaf(sa[e], cs, -mn));
+      ps += sa[e];
+    }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) mv = max8_bits(rv[t][1].a, rv[t][1].b, max8_bits(rv[t][0].a, rv[t][0].b, mv));
+    const int evn = min(ev, scale_exp_of(wave_max_bits(mv)));
+    alpha *= pow2i(evn - ev);          // the accumulator moves to the new (smaller) scale with the softmax's own rescale
+    ev = evn;
+    const float sv = pow2i(ev);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      o0[e] *= alpha;
+      o1[e] *= alpha;
+    }
+    // O^T += V^T P^T : A = V^T (rows d, key slots) x 2^ev, B = P^T straight from the S^T registers (in [0, 1]: no scale)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 pf[2], v0[2], v1[2];
+      split_acc_hp(sa, t, 1.f, pf);
+      split_hp(rv[t][0], sv, v0);
+      split_hp(rv[t][1], sv, v1);
+      o0 = mma_hp(v0, pf, o0);
+      o1 = mma_hp(v1, pf, o1);
+    }
+  }
+  const float un = pow2i(-ev);           // (an idle wave: 0 x 2^-100)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = o0[e] * un;
+    os[wave][32 + d][lr] = o1[e] * un;
+  }
+  if (h == 0) ms[wave][lr] = m;
+  ls[wave][lane] = l;
+  __syncthreads();
+  const int d = tid & 63, qg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int q = qg * (32 / WV) + i;
+    float M = ms[0][q];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) M = fmaxf(M, ms[w][q]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) {
+      const float sc = __expf(ms[w][q] - M);     // idle waves: exp(-inf) = 0
+      L += (ls[w][q] + ls[w][q + 32]) * sc;
+      o += os[w][d][q] * sc;
+    }
+    a.out[(rb + q0 + q) * a.ldout + hd * DH + d] = o / L;
+    if (d == 0) a.lse[((long long)blockIdx.z * a.heads + hd) * a.T + q0 + q] = M + logf(L);
+  }
+}
+
+template <int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_bwd_q_hp_kernel(FlashArgs a) {
+  __shared__ float os[WV][DH][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const float* __restrict__ dO = a.dout + hd * DH;
+  const long long ld = a.ldqkv;
+  const long long stat = ((long long)blockIdx.z * a.heads + hd) * a.T + q0 + lr;
+  const float lse = a.lse[stat];
+
+  uint4 qf[4][2], gf[4][2];   // B operands (k = d, column = query): scale * Q x 2^eq and dO x 2^eg
+  int eq, eg;
+  float dl = 0.f;
+  {
+    const float* __restrict__ Op = a.o + (rb + q0 + lr) * a.ldo + hd * DH;
+    Raw8 rq[4], rg[4];
+    unsigned mq = 0u, mg = 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      rq[s] = raw_row(Q, ld, rb + q0 + lr, 0, s, h);
+      rg[s] = raw_row(dO, a.lddout, rb + q0 + lr, 0, s, h);
+      mq = max8_bits(rq[s].a, rq[s].b, mq);
+      mg = max8_bits(rg[s].a, rg[s].b, mg);
+      const float4 o0 = *reinterpret_cast<const float4*>(Op + 16 * s + 8 * h), o1 = *reinterpret_cast<const float4*>(Op + 16 * s + 8 * h + 4);
+      const float4 g0 = rg[s].a, g1 = rg[s].b;
+      dl += (g0.x * o0.x + g0.y * o0.y) + (g0.z * o0.z + g0.w * o0.w) + (g1.x * o1.x + g1.y * o1.y) + (g1.z * o1.z + g1.w * o1.w);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (wave == 0 && h == 0) a.delta[stat] = dl;
+    eq = scale_exp_of(abs_bits(__uint_as_float(wave_max_bits(mq)) * a.scale));
+    eg = scale_exp_of(wave_max_bits(mg));
+    const float sq = a.scale * pow2i(eq), sg = pow2i(eg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      split_hp(rq[s], sq, qf[s]);
+      split_hp(rg[s], sg, gf[s]);
+    }
+  }
+  f32x16 g0 = zero16(), g1 = zero16();   // dq^T x 2^er: rows d (0..31 | 32..63), column = query
+  int er = 200;                          // running scale exponent of this lane's column (K tile scale + dS column scale)
+  const int kw = a.T / a.nw;
+  const int kend = wave < a.nw ? (wave + 1) * kw : 0;
+  for (int kb = wave * kw; kb < kend; kb += 32) {
+    f32x16 st = zero16(), dp = zero16();
+    Raw8 rk[4];
+    int ek;
+    float c1, c2;
+    {
+      Raw8 rvv[4];
+      unsigned mk = 0u, mv = 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        rk[s] = raw_row(K, ld, rb + kb + lr, 0, s, h);
+        rvv[s] = raw_row(V, ld, rb + kb + lr, 0, s, h);
+        mk = max8_bits(rk[s].a, rk[s].b, mk);
+        mv = max8_bits(rvv[s].a, rvv[s].b, mv);
+      }
+      ek = scale_exp_of(wave_max_bits(mk));
+      const int ev = scale_exp_of(wave_max_bits(mv));
+      const float sk = pow2i(ek), sv = pow2i(ev);
+      c1 = pow2i(-(ek + eq));
+      c2 = pow2i(-(ev + eg));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint4 kf[2], vf[2];
+        split_hp(rk[s], sk, kf);
+        split_hp(rvv[s], sv, vf);
+        st = mma_hp(kf, qf[s], st);
+        dp = mma_hp(vf, gf[s], dp);
+      }
+    }
+    // the gather fragments of the K tile (the same 32 x 64 values, contracted over the keys) go out before the exponentials
+    Raw8 rg2[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      rg2[t][0] = raw_gather(K, ld, rb + kb, lr, t, h);
+      rg2[t][1] = raw_gather(K, ld, rb + kb, 32 + lr, t, h);
+    }
+    unsigned md = 0u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      st[e] = __expf(fmaf(st[e], c1, -lse)) * fmaf(dp[e], c2, -dl);   // dS^T
+      md = max(md, abs_bits(st[e]));
+    }
+    md = max(md, (unsigned)__shfl_xor((int)md, 32, 64));               // the column's other 16 keys
+    const int ern = min(er, ek + scale_exp_of(md));
+    if (__any(ern != er)) {
+      const float f = pow2i(ern - er);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { g0[e] *= f; g1[e] *= f; }
+    }
+    er = ern;
+    const float sd = pow2i(er - ek), sk = pow2i(ek);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 sf[2], k0[2], k1[2];
+      split_acc_hp(st, t, sd, sf);
+      split_hp(rg2[t][0], sk, k0);
+      split_hp(rg2[t][1], sk, k1);
+      g0 = mma_hp(k0, sf, g0);
+      g1 = mma_hp(k1, sf, g1);
+    }
+  }
+  const float un = pow2i(-er);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = g0[e] * un;
+    os[wave][32 + d][lr] = g1[e] * un;
+  }
+  __syncthreads();
+  const int d = tid & 63, qg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int q = qg * (32 / WV) + i;
+    float v = (os[0][d][q] + os[1][d][q]) + (os[2][d][q] + os[3][d][q]);
+    if (WV == 8) v += (os[WV - 4][d][q] + os[WV - 3][d][q]) + (os[WV - 2][d][q] + os[WV - 1][d][q]);
+    a.dqkv[(rb + q0 + q) * a.lddqkv + a.q_off + hd * a.hs + d] = v * a.scale;
+  }
+}
+
+// dk, dv (f16x3): the K / V fragments of the workgroup's 32 keys are split once and live in LDS (16 KB), as in the KVL form above
+template <int WV>
+__global__ __launch_bounds__(64 * WV, 1) void flash_bwd_kv_hp_kernel(FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) float os[WV][2 * DH][33];
+  __shared__ unsigned kvmax[2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int k0r = blockIdx.x * 32, hd = blockIdx.y;
+  const long long rb = (long long)blockIdx.z * a.T;
+  const float* __restrict__ Q = a.qkv + a.q_off + hd * a.hs;
+  const float* __restrict__ K = a.qkv + a.k_off + hd * a.hs;
+  const float* __restrict__ V = a.qkv + a.v_off + hd * a.hs;
+  const float* __restrict__ dO = a.dout + hd * DH;
+  const long long ld = a.ldqkv;
+  const float* __restrict__ lsep = a.lse + ((long long)blockIdx.z * a.heads + hd) * a.T;
+  const float* __restrict__ dlp = a.delta + ((long long)blockIdx.z * a.heads + hd) * a.T;
+
+  uint4* kvs = reinterpret_cast<uint4*>(&os[0][0][0]);      // [K | V][k16-step][plane][lane]
+  static_assert(sizeof(os) >= 2 * 4 * 2 * 64 * sizeof(uint4), "the fragments alias the combine buffer");
+  int ek, ev;
+  {
+    // fragment f = (K | V, k16-step): loaded by wave f % WV; its max goes through LDS so that every wave knows both tile maxima
+    static_assert(WV == 4 || WV == 8, "fragments per wave");
+    constexpr int PER = 8 / WV;
+    Raw8 r[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int f = wave + j * WV;
+      if (f < 8) {
+        r[j] = raw_row(f < 4 ? K : V, ld, rb + k0r + lr, 0, f & 3, h);
+        const unsigned m = wave_max_bits(max8_bits(r[j].a, r[j].b, 0u));
+        if (lane == 0) kvmax[f >> 2][f & 3] = m;
+      }
+    }
+    __syncthreads();
+    ek = scale_exp_of(max(max(kvmax[0][0], kvmax[0][1]), max(kvmax[0][2], kvmax[0][3])));
+    ev = scale_exp_of(max(max(kvmax[1][0], kvmax[1][1]), max(kvmax[1][2], kvmax[1][3])));
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int f = wave + j * WV;
+      if (f < 8) {
+        uint4 t[2];
+        split_hp(r[j], pow2i(f < 4 ? ek : ev), t);
+        kvs[(f * 2 + 0) * 64 + lane] = t[0];
+        kvs[(f * 2 + 1) * 64 + lane] = t[1];
+      }
+    }
+    __syncthreads();
+  }
+  f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+  int erv = 200;        // running scale exponent of the dv accumulators (the dO tile's; wave-uniform)
+  int erk = 200;        // ... of this lane's column of the dk accumulators (Q tile scale + dS column scale)
+  const int qw = a.T / a.nw;
+  const int qend = wave < a.nw ? (wave + 1) * qw : 0;
+  for (int qb = wave * qw; qb < qend; qb += 32) {
+    f32x16 sc = zero16(), dp = zero16();
+    int eq, eg;
+    float c1, c2;
+    {
+      Raw8 rq[4], rg[4];
+      unsigned mq = 0u, mg = 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        rq[s] = raw_row(Q, ld, rb + qb + lr, 0, s, h);
+        rg[s] = raw_row(dO, a.lddout, rb + qb + lr, 0, s, h);
+        mq = max8_bits(rq[s].a, rq[s].b, mq);
+        mg = max8_bits(rg[s].a, rg[s].b, mg);
+      }
+      eq = scale_exp_of(wave_max_bits(mq));          // of the unscaled Q tile (the gather below uses the same exponent)
+      eg = scale_exp_of(wave_max_bits(mg));
+      const float sq = a.scale * pow2i(eq), sg = pow2i(eg);
+      c1 = pow2i(-(eq + ek));
+      c2 = pow2i(-(eg + ev));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint4 qf[2], gf[2], kf[2], vf[2];
+        split_hp(rq[s], sq, qf);
+        split_hp(rg[s], sg, gf);
+        kf[0] = kvs[(s * 2 + 0) * 64 + lane]; kf[1] = kvs[(s * 2 + 1) * 64 + lane];
+        vf[0] = kvs[((4 + s) * 2 + 0) * 64 + lane]; vf[1] = kvs[((4 + s) * 2 + 1) * 64 + lane];
+        sc = mma_hp(qf, kf, sc);
+        dp = mma_hp(gf, vf, dp);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // (the row-pattern tiles are dead here: the gathers below must not be hoisted over them)
+    // gather fragments of the dO tile (contracted over the queries) go out before the exponentials; the Q tile's follow once the
+    // dO ones are in use (all eight at once do not fit 256 registers beside the four accumulators)
+    Raw8 rgo[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      rgo[t][0] = raw_gather(dO, a.lddout, rb + qb, lr, t, h);
+      rgo[t][1] = raw_gather(dO, a.lddout, rb + qb, 32 + lr, t, h);
+    }
+    // rows of the C layout are queries: q = qb + (e&3) + 8 (e>>2) + 4 h
+    unsigned md = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb + 8 * j + 4 * h);
+      const float4 d4 = *reinterpret_cast<const float4*>(dlp + qb + 8 * j + 4 * h);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pr = __expf(fmaf(sc[4 * j + i], c1, -lv[i]));
+        sc[4 * j + i] = pr;                                            // P
+        dp[4 * j + i] = pr * fmaf(dp[4 * j + i], c2, -dv[i]);          // dS
+        md = max(md, abs_bits(dp[4 * j + i]));
+      }
+    }
+    md = max(md, (unsigned)__shfl_xor((int)md, 32, 64));
+    const int ervn = min(erv, eg);
+    if (ervn != erv) {                     // wave-uniform
+      const float f = pow2i(ervn - erv);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dv0[e] *= f; dv1[e] *= f; }
+    }
+    erv = ervn;
+    const int erkn = min(erk, eq + scale_exp_of(md));
+    if (__any(erkn != erk)) {
+      const float f = pow2i(erkn - erk);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dk0[e] *= f; dk1[e] *= f; }
+    }
+    erk = erkn;
+    const float sgo = pow2i(erv), sgq = pow2i(eq), sds = pow2i(erk - eq);
+    Raw8 rgq[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {          // dv^T += dO^T P
+      uint4 pf[2], g0[2], g1[2];
+      rgq[t][0] = raw_gather(Q, ld, rb + qb, lr, t, h);
+      rgq[t][1] = raw_gather(Q, ld, rb + qb, 32 + lr, t, h);
+      split_acc_hp(sc, t, 1.f, pf);
+      split_hp(rgo[t][0], sgo, g0);
+      split_hp(rgo[t][1], sgo, g1);
+      dv0 = mma_hp(g0, pf, dv0);
+      dv1 = mma_hp(g1, pf, dv1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {          // dk^T += Q^T dS
+      uint4 sf[2], q0f[2], q1f[2];
+      split_acc_hp(dp, t, sds, sf);
+      split_hp(rgq[t][0], sgq, q0f);
+      split_hp(rgq[t][1], sgq, q1f);
+      dk0 = mma_hp(q0f, sf, dk0);
+      dk1 = mma_hp(q1f, sf, dk1);
+    }
+  }
+  __syncthreads();     // every wave's last fragment read is over before the combine buffer overwrites them
+  const float unv = pow2i(-erv), unk = pow2i(-erk);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int d = (e & 3) + 8 * (e >> 2) + 4 * h;
+    os[wave][d][lr] = dv0[e] * unv;
+    os[wave][32 + d][lr] = dv1[e] * unv;
+    os[wave][64 + d][lr] = dk0[e] * unk;
+    os[wave][96 + d][lr] = dk1[e] * unk;
+  }
+  __syncthreads();
+  const int d = tid & 63, kg = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 32 / WV; ++i) {
+    const int k = kg * (32 / WV) + i;
+    float dvv = (os[0][d][k] + os[1][d][k]) + (os[2][d][k] + os[3][d][k]);
+    float dkv = (os[0][64 + d][k] + os[1][64 + d][k]) + (os[2][64 + d][k] + os[3][64 + d][k]);
+    if (WV == 8) {
+      dvv += (os[WV - 4][d][k] + os[WV - 3][d][k]) + (os[WV - 2][d][k] + os[WV - 1][d][k]);
+      dkv += (os[WV - 4][64 + d][k] + os[WV - 3][64 + d][k]) + (os[WV - 2][64 + d][k] + os[WV - 1][64 + d][k]);
+    }
+    float* row = a.dqkv + (rb + k0r + k) * a.lddqkv + hd * a.hs;
+    row[a.v_off + d] = dvv;
+    row[a.k_off + d] = dkv * a.scale;
+  }
+}
+
 // waves that split the other sequence axis: up to 8 (two per SIMD) from T = 256.  OSM_FLASH_WAVES=4: round 2's four
 int max_waves() {
   static const int v = [] { const char* e = std::getenv("OSM_FLASH_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
@@ -436,7 +915,7 @@ int check(const osm_attn_desc* d, const char* who) {
   OSM_REQUIRE(d->ch == DH && d->T >= 64 && d->T % (32 * nw_of(d->T)) == 0,
               "%s: needs 64-wide heads and T a multiple of 64 (of 128 from T = 128) (got ch %d, T %d)", who, d->ch, d->T);
   OSM_REQUIRE(d->B > 0 && d->heads > 0, "%s: bad shape", who);
-  OSM_REQUIRE(d->arith == 0 || d->arith == 1, "%s: arith must be 0 (bf16x6) or 1 (fp16)", who);
+  OSM_REQUIRE(d->arith >= 0 && d->arith <= 2, "%s: arith must be 0 (bf16x6), 1 (fp16) or 2 (f16x3)", who);
   OSM_REQUIRE(d->ldqkv % 4 == 0 && d->q_off % 4 == 0 && d->k_off % 4 == 0 && d->v_off % 4 == 0 && d->head_stride % 4 == 0 &&
               osm::aligned16(d->qkv), "%s: qkv columns must be 16-byte aligned", who);
   return OSM_OK;
@@ -476,7 +955,10 @@ extern "C" int osm_attn_flash_fwd(const osm_attn_desc* d, float* lse, void* stre
       hipLaunchKernelGGL((flash_fwd_kernel<P, 1, 4>), g, dim3(256), 0, st, a);
     }
   };
-  if (d->arith == 1) launch(std::integral_constant<int, 1>{});
+  if (d->arith == 2) {       // f16x3: two half planes per operand, ranges found in the kernel
+    if (a.nw == 8) hipLaunchKernelGGL((flash_fwd_hp_kernel<8>), g, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((flash_fwd_hp_kernel<4>), g, dim3(256), 0, st, a);
+  } else if (d->arith == 1) launch(std::integral_constant<int, 1>{});
   else launch(std::integral_constant<int, 3>{});
   return osm::check_launch("flash_fwd_kernel");
 }
@@ -507,7 +989,15 @@ extern "C" int osm_attn_flash_bwd(const osm_attn_desc* d, const float* out, long
       hipLaunchKernelGGL((flash_bwd_kv_kernel<P, 4>), g, dim3(256), 0, st, b);
     }
   };
-  if (d->arith == 1) launch(std::integral_constant<int, 1>{});
+  if (d->arith == 2) {
+    if (a.nw == 8) {
+      hipLaunchKernelGGL((flash_bwd_q_hp_kernel<8>), g, dim3(512), 0, st, a);
+      hipLaunchKernelGGL((flash_bwd_kv_hp_kernel<8>), g, dim3(512), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((flash_bwd_q_hp_kernel<4>), g, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((flash_bwd_kv_hp_kernel<4>), g, dim3(256), 0, st, a);
+    }
+  } else if (d->arith == 1) launch(std::integral_constant<int, 1>{});
   else launch(std::integral_constant<int, 3>{});
   return osm::check_launch("flash_bwd kernels");
 }

@@ -315,6 +315,9 @@ class UNetEngine:
         self.stats_bwd_min_hw = int(os.environ.get("OSM_STATS_BWD_MIN_HW", "1025"))
         self._check_xmax = os.environ.get("OSM_CHECK_XMAX", "0") == "1"
         self._attn_half = self.adt == torch.float16 and os.environ.get("OSM_ATTN_F16", "1") != "0"
+        # f16x3 models: the attention cores in the same arithmetic as the convolutions (two half terms per operand, three fp16
+        # MFMAs per product, ranges found in the kernels: csrc/flash.hip); OSM_ATTN_F16X3=0: bf16x6 (A/B, round-5 behaviour)
+        self._attn_f16x3 = weights.conv_mode == "f16x3" and os.environ.get("OSM_ATTN_F16X3", "1") != "0"
 
         w = weights
         self.te0, self.te2, self.inp, self.mid, self.outb = w.te0, w.te2, w.inp, w.mid, w.outb
@@ -414,11 +417,12 @@ class UNetEngine:
             bool(ops.conv_winograd_ok(H, W, cin, cout, cv.k, cv.wfmt))
 
     def _is_direct_f16(self, cv: _Conv, hw) -> bool:
-        """3x3 layer of an f16x3 model on an image smaller than the Winograd tile (8 <= H, W and one of them < 16): direct f16x3."""
+        """3x3 layer of an f16x3 model on an image the Winograd kernel does not serve (8 <= H, W and one of them below
+        `winograd_min_hw`, 16 unless OSM_WINOGRAD_MIN_HW raises it): direct f16x3."""
         H, W = hw
         # (only where the halo-tile kernel serves the layer: with OSM_CONV_HALO=0, the documented A/B switch, the wfmt-4 direct
         # image has no kernel and the layer keeps its bf16x6 images -- ADVICE r05)
-        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < 16 or W < 16) and \
+        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < self.winograd_min_hw or W < self.winograd_min_hw) and \
             os.environ.get("OSM_CONV_HALO", "1") != "0"
 
     # ---- registry of "max |.| of this gradient buffer was left behind by its last writer" (f16x3 range hand-over)
@@ -733,7 +737,7 @@ class UNetEngine:
             lse = self._small(nmat * T)
             # fp16-storage family: one fp16 MFMA per product, fp32 accumulation and softmax -- what the reference's half attention
             # computes (unet.py:426-433); OSM_ATTN_F16=0 keeps the fp32-class bf16x6 core there too (rounds 2-3)
-            ops.attn_flash_fwd(qkv, a, lse, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half)
+            ops.attn_flash_fwd(qkv, a, lse, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half, f16x3=self._attn_f16x3)
         elif fused:    # 8x8: logits stay on the CU, one launch, nothing kept for the backward
             ops.attn_small_fwd(qkv, a, B, T, nh, ch, (qo, ko, vo), hs, alpha)
         else:
@@ -776,7 +780,8 @@ class UNetEngine:
         dqkv = self._scr("b", M, 3 * C, torch.float32)
         if s["flash"]:
             delta = self._scr_flat("s0", nmat * T)
-            ops.attn_flash_bwd(qkv, s["a"], da, dqkv, s["lse"], delta, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half)
+            ops.attn_flash_bwd(qkv, s["a"], da, dqkv, s["lse"], delta, B, T, nh, ch, (qo, ko, vo), hs, alpha, half=self._attn_half,
+                               f16x3=self._attn_f16x3)
         elif s["fused"]:
             ws = self._scr_flat("s0", 2 * nmat * T * T)
             ops.attn_small_bwd(qkv, da, dqkv, ws, B, T, nh, ch, (qo, ko, vo), hs, alpha)

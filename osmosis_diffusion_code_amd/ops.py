@@ -189,20 +189,22 @@ def attn_flash_supported(T: int, ch: int) -> bool:
     return bool(query("osm_attn_flash_supported", T, ch))
 
 
-def attn_flash_fwd(qkv: Mat, out: Mat, lse: torch.Tensor, B, T, heads, ch, offsets, head_stride, scale, half: bool = False):
+def attn_flash_fwd(qkv: Mat, out: Mat, lse: torch.Tensor, B, T, heads, ch, offsets, head_stride, scale, half: bool = False,
+                   f16x3: bool = False):
     """out = softmax(scale q k^T) v per (image, head) on the matrix cores; lse [B*heads*T] is kept for the backward.
-    half: one fp16 MFMA per product (the reference's use_fp16 attention arithmetic) instead of bf16x6."""
+    half: one fp16 MFMA per product (the reference's use_fp16 attention arithmetic) instead of bf16x6; f16x3: two IEEE-half
+    terms per fp32 operand after a power-of-two scaling found in the kernel, three fp16 MFMAs per product (fp32-class)."""
     d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
-    d.arith = 1 if half else 0
+    d.arith = 1 if half else (2 if f16x3 else 0)
     d.out, d.ldout = out.p, out.ld
     call("osm_attn_flash_fwd", C.byref(d), ptr(lse), _s(), keep=(d, qkv.t, out.t, lse))
 
 
 def attn_flash_bwd(qkv: Mat, out: Mat, dout: Mat, dqkv: Mat, lse, delta, B, T, heads, ch, offsets, head_stride, scale,
-                   half: bool = False):
+                   half: bool = False, f16x3: bool = False):
     """dq | dk | dv (qkv column layout) from d(out), the forward output and its lse; delta: [B*heads*T] scratch."""
     d = _attn_desc(qkv, B, T, heads, ch, offsets, head_stride, scale)
-    d.arith = 1 if half else 0
+    d.arith = 1 if half else (2 if f16x3 else 0)
     d.dout, d.lddout = dout.p, dout.ld
     d.dqkv, d.lddqkv = dqkv.p, dqkv.ld
     call("osm_attn_flash_bwd", C.byref(d), out.p, out.ld, ptr(lse), ptr(delta), _s(),

@@ -369,6 +369,46 @@ def test_attn_flash_fwd_bwd(ops, B, T, heads, new_order):
                        delta, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch), half=True)
     eh = relerr(dqh.cpu().reshape(B, T, 3 * C), dref.float())
     assert eh < 4e-3, eh
+    # the f16x3 arithmetic (round 6): two half terms per operand after a power-of-two scaling found in the kernel, three fp16
+    # MFMAs per product -- fp32-class: the SAME tolerances as bf16x6 above.  Also with operands far outside the fp16 range (the
+    # scaling has to carry them) and tile maxima that differ by orders of magnitude along the sequence (the running rescale)
+    ramp_up, ramp_dn = torch.logspace(-3, 3, T).reshape(1, T, 1), torch.logspace(2, -4, T).reshape(1, T, 1)
+    for amp_q, amp_g, ramp in ((1.0, 1.0, False), (3.0e4, 2.0e-6, False), (1.0, 1.0, True)):
+        q2 = qkv.clone()
+        for hh in range(heads):
+            cq, ck, cv = (slice(offs[c] + hh * hs, offs[c] + hh * hs + ch) for c in range(3))
+            if ramp:          # v grows a million-fold along the sequence (and dO falls): tile scales differ by 2^20 between tiles
+                q2[:, :, cv] *= ramp_up
+            else:             # the logits stay O(1): q and k move in opposite directions, v up
+                q2[:, :, cq] *= amp_q
+                q2[:, :, ck] /= amp_q
+                q2[:, :, cv] *= amp_q
+        d2 = dout * ramp_dn if ramp else dout * amp_g
+        x2 = q2.double().requires_grad_(True)
+        outs2 = []
+        for hh in range(heads):
+            qh, kh, vh = (x2[:, :, offs[c] + hh * hs: offs[c] + hh * hs + ch] for c in range(3))
+            lg = torch.einsum("btc,bsc->bts", qh, kh) / math.sqrt(ch)
+            outs2.append(torch.einsum("bts,bsc->btc", torch.softmax(lg, dim=-1), vh))
+        ref2 = torch.cat(outs2, dim=-1)
+        (dref2,) = torch.autograd.grad(ref2, x2, d2.double())
+        qd2 = q2.reshape(B * T, 3 * C).to(DEV)
+        o3 = torch.full((B * T, C), float("nan"), device=DEV)
+        l3 = torch.full((B * heads * T,), float("nan"), device=DEV)
+        ops.attn_flash_fwd(ops.Mat.of(qd2), ops.Mat.of(o3), l3, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch), f16x3=True)
+        e3 = relerr(o3.cpu().reshape(B, T, C), ref2.float())
+        assert e3 < 5e-6, (amp_q, ramp, e3)
+        dq3 = torch.full((B * T, 3 * C), float("nan"), device=DEV)
+        ops.attn_flash_bwd(ops.Mat.of(qd2), ops.Mat.of(o3), ops.Mat.of(d2.reshape(B * T, C).to(DEV)), ops.Mat.of(dq3), l3,
+                           delta, B, T, heads, ch, offs, hs, 1.0 / math.sqrt(ch), f16x3=True)
+        # per component (dq | dk | dv live on very different scales once the operands are rescaled): each against its own max
+        got, want = dq3.cpu().reshape(B, T, 3 * C), dref2.float()
+        for comp in range(3):
+            for hh in range(heads):
+                sl = slice(offs[comp] + hh * hs, offs[comp] + hh * hs + ch)
+                e3 = relerr(got[:, :, sl], want[:, :, sl])
+                assert e3 < 1e-5, (amp_q, ramp, comp, hh, e3)
+        print("f16x3 attention", (B, T, heads), "amp", amp_q, "ramp", ramp, "ok")
 
 
 def test_attn_small_rejects_other_shapes(ops):
