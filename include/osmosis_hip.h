@@ -310,8 +310,10 @@ typedef struct osm_phys_desc {
   float gamma_val;     /* aux val_loss coefficient (0 = off)                           */
   float eta[3];        /* step size (lr) for phi_a(phi_ab), phi_b, phi_inf             */
   int B, HW;
-  int optimizer;       /* 0: plain gradient descent ('sgd' / 'GD', measurements.py:157-177); 1: torch.optim.Adam with its
-                          defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay; utils.py:494-499), lr = eta per group */
+  int optimizer;       /* 0: plain gradient descent ('sgd' / 'GD', measurements.py:157-177); otherwise the torch.optim class of
+                          utils.py:494-524 with ITS DEFAULT hyper-parameters (the reference passes none) and lr = eta per group:
+                          1 Adam, 2 AdamW (weight_decay 0.01), 3 Adamax, 4 RMSprop, 5 Adagrad, 6 Adadelta, 7 ASGD, 8 Rprop.
+                          ('sparseadam' and 'lbfgs' raise in the reference itself: dense gradients / step() without a closure) */
 } osm_phys_desc;
 /* phi: device float [B][9] = phi_a[3] | phi_b[3] | phi_inf[3]  (kinds 1,2 use phi_a as phi_ab;
  * haze uses phi_a[0] only).  part: workspace B*nblk*16 floats, nblk = osm_phys_nblk(HW).
@@ -320,8 +322,8 @@ typedef struct osm_phys_desc {
 int osm_phys_nblk(int HW);
 int osm_phys_reduce(const osm_phys_desc* d, const float* x0, const float* y, const float* phi,
                     float* part, void* stream);
-/* opt_state: [B][20] floats (exp_avg[9] | exp_avg_sq[9] | step | pad), zero-initialised by the caller, required when
- * d->optimizer == 1 and do_update != 0; NULL otherwise. */
+/* opt_state: [B][20] floats of optimizer state per image (Adam / AdamW: exp_avg[9] | exp_avg_sq[9] | step; the other optimizers:
+ * see csrc/guidance.hip), zero-initialised by the caller, required when d->optimizer != 0 and do_update != 0; NULL otherwise. */
 int osm_phys_finalize(const osm_phys_desc* d, const float* part, float* red, float* phi, int do_update,
                       float* loss_out, float* opt_state, void* stream);
 /* g[B,4,HW] = d(total loss)/d(x0) for the current phi and the reductions in `red`. */

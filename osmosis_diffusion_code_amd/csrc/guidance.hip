@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void phys_reduce_kernel(osm_phys_desc ds, cons
   }
 }
 
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
 __global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__ part, float* __restrict__ red,
                                      float* __restrict__ phi, int do_update, float* __restrict__ loss_out,
                                      float* __restrict__ opt_state, int nblk) {
@@ -171,20 +173,83 @@ __global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__
       }
       for (int c = 0; c < 3; ++c) { g[6 + c] = (float)(tot[7 + c] * gscale); lr[6 + c] = ds.eta[2]; }
       live |= 0x1c0;
-      if (ds.optimizer == 1) {          // torch.optim.Adam (single-tensor path, fp32 state, amsgrad off)
-        float* st = opt_state + b * 20;
+      // torch.optim with its DEFAULT hyper-parameters (utils.py:494-524 passes none), single-tensor path, fp32 state, one parameter
+      // group per phi with lr = eta (measurements.py:132-136, 244-249).  st: [B][20] floats, layout per optimizer below.  A parameter
+      // with learn_flag False has no gradient: the optimizer skips it (its state stays untouched).
+      float* st = opt_state ? opt_state + b * 20 : nullptr;
+      if (ds.optimizer == 1 || ds.optimizer == 2) {          // Adam | AdamW (weight_decay 0.01, decoupled): exp_avg[9] | exp_avg_sq[9] | step
         const float step = st[18] + 1.f;
         st[18] = step;
         const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
         const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
         const float bc2_sqrt = (float)sqrt(bc2);
         for (int i = 0; i < 9; ++i) {
-          if (!((live >> i) & 1) || lr[i] == 0.f) continue;      // learn_flag False: no gradient, the optimizer skips it
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          if (ds.optimizer == 2) ph[i] *= (float)(1.0 - (double)lr[i] * 0.01);      // param.mul_(1 - lr * weight_decay)
           const float m = st[i] + (g[i] - st[i]) * (float)(1.0 - b1);             // exp_avg.lerp_(grad, 1 - beta1)
           const float v = st[9 + i] * (float)b2 + (float)(1.0 - b2) * g[i] * g[i];  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
           st[i] = m; st[9 + i] = v;
           const float denom = sqrtf(v) / bc2_sqrt + (float)eps;
           ph[i] += (float)(-(double)lr[i] / bc1) * (m / denom);                   // param.addcdiv_(exp_avg, denom, value=-step_size)
+        }
+      } else if (ds.optimizer == 3) {   // Adamax (betas 0.9 / 0.999, eps 1e-8): exp_avg[9] | exp_inf[9] | step
+        const float step = st[18] + 1.f;
+        st[18] = step;
+        const double bc = 1.0 - pow(0.9, (double)step);
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          const float m = st[i] + (g[i] - st[i]) * (float)(1.0 - 0.9);            // exp_avg.lerp_(grad, 1 - beta1)
+          const float u = fmaxf(st[9 + i] * (float)0.999, fabsf(g[i]) + (float)1e-8);   // max(exp_inf * beta2, |grad| + eps)
+          st[i] = m; st[9 + i] = u;
+          ph[i] += (float)(-(double)lr[i] / bc) * (m / u);                         // param.addcdiv_(exp_avg, exp_inf, value=-clr)
+        }
+      } else if (ds.optimizer == 4) {   // RMSprop (alpha 0.99, eps 1e-8, no momentum, not centered): square_avg[9]
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          const float sq = st[i] * (float)0.99 + (float)(1.0 - 0.99) * g[i] * g[i];
+          st[i] = sq;
+          ph[i] += -lr[i] * (g[i] / (sqrtf(sq) + (float)1e-8));
+        }
+      } else if (ds.optimizer == 5) {   // Adagrad (lr_decay 0, initial accumulator 0, eps 1e-10): sum[9]
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          const float sm = st[i] + g[i] * g[i];
+          st[i] = sm;
+          ph[i] += -lr[i] * (g[i] / (sqrtf(sm) + (float)1e-10));
+        }
+      } else if (ds.optimizer == 6) {   // Adadelta (rho 0.9, eps 1e-6; lr = eta): square_avg[9] | acc_delta[9]
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          const float sq = st[i] * (float)0.9 + (float)(1.0 - 0.9) * g[i] * g[i];
+          const float sd = sqrtf(sq + (float)1e-6);
+          const float dl = sqrtf(st[9 + i] + (float)1e-6) / sd * g[i];
+          st[i] = sq;
+          st[9 + i] = st[9 + i] * (float)0.9 + (float)(1.0 - 0.9) * dl * dl;
+          ph[i] += -lr[i] * dl;
+        }
+      } else if (ds.optimizer == 7) {   // ASGD (lambd 1e-4, alpha 0.75, t0 1e6): eta[9] | - | step (19); eta starts at lr (0 = not yet set)
+        const float step = st[19] + 1.f;
+        st[19] = step;
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          const float eta = step == 1.f ? lr[i] : st[i];
+          ph[i] *= (float)(1.0 - 1e-4 * (double)eta);                             // param.mul_(1 - lambd * eta)
+          ph[i] += -eta * g[i];                                                    // param.add_(grad, alpha=-eta)
+          st[i] = (float)((double)lr[i] / pow(1.0 + 1e-4 * (double)lr[i] * (double)step, 0.75));
+        }                                                                          // (the averaged iterate `ax` is not what the operator reads)
+      } else if (ds.optimizer == 8) {   // Rprop (etas 0.5 / 1.2, step sizes 1e-6 .. 50): prev[9] | step_size[9] | step
+        const float step = st[18] + 1.f;
+        st[18] = step;
+        for (int i = 0; i < 9; ++i) {
+          if (!((live >> i) & 1) || lr[i] == 0.f) continue;
+          float ss = step == 1.f ? lr[i] : st[9 + i];
+          const float pr = g[i] * st[i];
+          float gi = g[i];
+          ss *= pr > 0.f ? 1.2f : (pr < 0.f ? 0.5f : 1.f);
+          ss = fminf(fmaxf(ss, 1e-6f), 50.f);
+          if (pr < 0.f) gi = 0.f;
+          ph[i] += -(sgn(gi) * ss);
+          st[i] = gi; st[9 + i] = ss;
         }
       } else {
         for (int i = 0; i < 9; ++i)
@@ -194,8 +259,6 @@ __global__ void phys_finalize_kernel(osm_phys_desc ds, const float* __restrict__
     }
   }
 }
-
-__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
 __global__ __launch_bounds__(256) void phys_grad_kernel(osm_phys_desc ds, const float* __restrict__ x0,
                                                          const float* __restrict__ y,
@@ -491,8 +554,8 @@ extern "C" int osm_phys_finalize(const osm_phys_desc* d, const float* part, floa
   int rc = check_desc(d, "osm_phys_finalize");
   if (rc) return rc;
   OSM_REQUIRE(part && red && phi, "osm_phys_finalize: null pointer");
-  OSM_REQUIRE(d->optimizer == 0 || d->optimizer == 1, "osm_phys_finalize: optimizer must be 0 (sgd / GD) or 1 (adam)");
-  OSM_REQUIRE(!(d->optimizer == 1 && do_update) || opt_state, "osm_phys_finalize: the Adam step needs opt_state [B][20]");
+  OSM_REQUIRE(d->optimizer >= 0 && d->optimizer <= 8, "osm_phys_finalize: optimizer must be 0 (sgd / GD) .. 8 (see osm_phys_desc)");
+  OSM_REQUIRE(!(d->optimizer != 0 && do_update) || opt_state, "osm_phys_finalize: a stateful optimizer needs opt_state [B][20]");
   OSM_REQUIRE(!(d->kind == 3 && do_update), "osm_phys_finalize: the identity operator (kind 3) has no parameters to step");
   hipLaunchKernelGGL(phys_finalize_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, *d, part, red, phi,
                      do_update, loss_out, opt_state, osm_phys_nblk(d->HW));

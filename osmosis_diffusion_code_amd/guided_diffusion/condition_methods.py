@@ -146,10 +146,11 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         coefs = self.aux_loss.kernel_coefficients() if self.aux_loss is not None else {"gamma_avrg": 0.0, "gamma_val": 0.0}
         d.gamma_avrg, d.gamma_val = coefs["gamma_avrg"], coefs["gamma_val"]
         d.B, d.HW = B, HW
-        d.optimizer = 1 if getattr(op, "optimizer", "") == "adam" else 0
+        from .measurements import OPTIMIZER_CODES
+        d.optimizer = OPTIMIZER_CODES.get(getattr(op, "optimizer", "") or "", 0)
         nblk = ops.phys_nblk(HW)
-        if d.optimizer == 1 and (self._opt is None or self._opt.shape[0] != op.phi.shape[0] or self._opt.device != op.phi.device):
-            # Adam moments + step of the operator's phi (torch.optim state lives with the optimizer = with the operator,
+        if d.optimizer != 0 and (self._opt is None or self._opt.shape[0] != op.phi.shape[0] or self._opt.device != op.phi.device):
+            # optimizer state (Adam: moments + step) of the operator's phi (torch.optim state lives with the optimizer = with the operator,
             # which the driver rebuilds per image: osmosis_sampling.py:142-155)
             self._opt = torch.zeros(op.phi.shape[0], 20, device=device, dtype=torch.float32)
         st = {"key": (B, HW, str(device)), "desc": d,
@@ -173,7 +174,7 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
             raise ValueError("expected x0 [B,4,H,W] and measurement [B,3,H,W]")
         st = self._prepare(B, HW, x0.device)
         d, part, red, loss = st["desc"], st["part"], st["red"], st["loss"]
-        opt = self._opt if d.optimizer == 1 else None       # read at call time: _prepare may have re-allocated it
+        opt = self._opt if d.optimizer != 0 else None       # read at call time: _prepare may have re-allocated it
         if loss_out is not None:
             loss = loss_out
         phi = self.operator.phi if phi is None else phi

@@ -7,9 +7,10 @@ Reference semantics kept:
     per image) and sets `operator.__name__ = name`; unknown / duplicate names raise NameError.
   * phi values arrive as strings ("1.1,0.95,0.95"), etas as strings or floats ("1e-5"),
     `phi_*_learn_flag=False` freezes a variable (eta 0)            (measurements.py:213-249)
-  * plain SGD `phi <- phi - eta * dL/dphi` (`optimizer: sgd`, or the 'GD' branch: same math), or `optimizer: adam`
-    (torch.optim.Adam defaults, lr = eta per parameter group, state per operator instance = per image): both on device
-    (measurements.py:266-303).  Other torch optimisers are not part of the HIP path.
+  * plain SGD `phi <- phi - eta * dL/dphi` (`optimizer: sgd`, or the 'GD' branch: same math), or any elementwise torch.optim
+    class the reference's factory knows (adam, adamw, adamax, rmsprop, adagrad, adadelta, asgd, rprop: torch defaults, lr = eta
+    per parameter group, state per operator instance = per image), all stepped on device inside osm_phys_finalize
+    (measurements.py:266-303).  'sparseadam' / 'lbfgs' raise (they cannot step these parameters in the reference either).
 
 Device state: `phi` is ONE fp32 device tensor [B][9] = phi_a[3] | phi_b[3] | phi_inf[3]
 (`underwater_physical` and `haze_physical` keep phi_ab in the phi_a slots; haze's scalar is
@@ -103,12 +104,20 @@ def _vec(s, n=3):
     return a
 
 
+# optimizer name (utils.py:494-524) -> osm_phys_desc.optimizer
+OPTIMIZER_CODES = {"": 0, "gd": 0, "sgd": 0, "adam": 1, "adamw": 2, "adamax": 3, "rmsprop": 4, "adagrad": 5, "adadelta": 6,
+                   "asgd": 7, "rprop": 8}
+
+
 def _check_optimizer(name):
     n = (name or "").lower()
-    if n in ("", "gd", "sgd", "adam"):
+    if n in OPTIMIZER_CODES:
         return n
-    if n in ("rmsprop", "adagrad", "adadelta", "adamw", "sparseadam", "adamax", "asgd", "lbfgs", "rprop"):
-        raise NotImplementedError(f"optimizer '{name}' is not available on the HIP path (GD, SGD and Adam only)")
+    if n in ("sparseadam", "lbfgs"):
+        # the reference builds these, and its optimize() then raises: SparseAdam refuses dense gradients, LBFGS.step() needs a
+        # closure (measurements.py:296-297 calls step() without one)
+        raise NotImplementedError(f"optimizer '{name}' cannot step the phi parameters (in the reference either: SparseAdam needs "
+                                  f"sparse gradients, LBFGS a closure)")
     raise ValueError(f"Optimizer '{name}' is not supported.")
 
 
