@@ -492,6 +492,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 #include "conv3_halo.inc.h"
 #include "conv3_wino.inc.h"
 #include "conv3_wino8.inc.h"
+#ifdef OSM_WITH_WINO4     // experiment (round 6): one wave per SIMD, 96-column workgroup tile (tools/experiments/conv3_wino4.inc.h)
+#include "../../tools/experiments/conv3_wino4.inc.h"
+#endif
 #if defined(OSM_WITH_WINO16) && !defined(OSM_ACT_F16)     // measurement builds only (tools/experiments/, profiles/NOTES_r05.md)
 #include "../../tools/experiments/conv3_wino16.inc.h"
 #endif
@@ -564,6 +567,17 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
       const int per = (p.ksteps + p.splitk - 1) / p.splitk;
       // (its staging addresses activations by 32-bit buffer offsets relative to the image, out-of-range = padding: < 2 GiB per image)
       const long long img_bytes = (long long)p.H * p.W * p.lda * (long long)sizeof(act_t);
+#ifdef OSM_WITH_WINO4
+      {
+        static const bool wino4 = [] { const char* e = std::getenv("OSM_WINO4"); return e && atoi(e) == 1; }();
+        if (wino4 && (p.K & 15) == 0 && p.splitk == 1 && !p.colsum && img_bytes < 0x7fffffffLL) {
+          IGemmParams q = p;
+          q.ntiles = (p.N + 32 * W4_NCT - 1) / (32 * W4_NCT);
+          hipLaunchKernelGGL((conv3_wino4_kernel<W4_NCT>), dim3(q.mtiles * q.ntiles, 1, 1), dim3(256), 0, st, q.A, Up, q);
+          return osm::check_launch("conv3_wino4_kernel");
+        }
+      }
+#endif
 #ifdef OSM_WITH_WINO16   // experiment: the 16-wave, one-xi-per-wave instance for the plain case (tools/experiments/conv3_wino16.inc.h)
 #ifdef W16_FORCE
       static const bool wino16 = true;
