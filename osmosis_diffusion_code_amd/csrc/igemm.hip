@@ -569,11 +569,12 @@ int launch(IGemmParams& p, int taps, bool b_kn, hipStream_t st, int wfmt = 0, bo
       const long long img_bytes = (long long)p.H * p.W * p.lda * (long long)sizeof(act_t);
 #ifdef OSM_WITH_WINO4
       {
-        static const bool wino4 = [] { const char* e = std::getenv("OSM_WINO4"); return e && atoi(e) == 1; }();
+        static const int wino4 = [] { const char* e = std::getenv("OSM_WINO4"); return e ? atoi(e) : 0; }();
         if (wino4 && (p.K & 15) == 0 && p.splitk == 1 && !p.colsum && img_bytes < 0x7fffffffLL) {
           IGemmParams q = p;
           q.ntiles = (p.N + 32 * W4_NCT - 1) / (32 * W4_NCT);
-          hipLaunchKernelGGL((conv3_wino4_kernel<W4_NCT>), dim3(q.mtiles * q.ntiles, 1, 1), dim3(256), 0, st, q.A, Up, q);
+          if (wino4 == 2) hipLaunchKernelGGL((conv3_wino4p_kernel<W4_NCT>), dim3(q.mtiles * q.ntiles, 1, 1), dim3(256), 0, st, q.A, Up, q);
+          else hipLaunchKernelGGL((conv3_wino4_kernel<W4_NCT>), dim3(q.mtiles * q.ntiles, 1, 1), dim3(256), 0, st, q.A, Up, q);
           return osm::check_launch("conv3_wino4_kernel");
         }
       }
