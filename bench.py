@@ -522,13 +522,19 @@ def roofline(model, args, reps=3):
     if att:
         ams = sum(v["ms_per_step"] for v in att.values())
         agf = sum(v["gflop_per_step"] for v in att.values())
-        peak_att = BF16_MFMA_PEAK_TFLOPS / 6.0
+        att_f16x3 = args.conv_mode == "f16x3" and os.environ.get("OSM_ATTN_F16X3", "1") != "0"
+        n_att = 1 if args.conv_mode == "f16" else (3 if att_f16x3 else 6)
+        peak_att = BF16_MFMA_PEAK_TFLOPS / n_att
         out["_attention"] = {
             "what": "attention cores (QK^T, softmax, PV and their gradients; T = 64 / 256 / 1024, 64-wide heads)",
+            "arithmetic": {1: "f16 (one fp16 MFMA per product)", 3: "f16x3 (two half terms per operand, three fp16 MFMAs per product; "
+                           "operand ranges found in the kernels)", 6: "bf16x6 (six bf16 MFMAs per product)"}[n_att],
             "ms_per_step": round(ams, 3), "achieved_tflops": round(agf / max(ams, 1e-9), 2),
+            "executed_mfma_tflops": round(n_att * agf / max(ams, 1e-9), 2),
             "peak_tflops": round(peak_att, 1), "mfma_util": round(agf / max(ams, 1e-9) / peak_att, 4),
-            "note": "algorithmic flops / HIP-event time of the launches / (dense bf16 MFMA peak / 6: bf16x6 arithmetic); "
-                    "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: latency-bound, not MFMA-bound; the counter-based "
+            "note": f"algorithmic flops / HIP-event time of the launches / (dense MFMA peak 2500 TF / {n_att} MFMAs per product); "
+                    "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: chains of dependent L2 round trips on one round of workgroups -- "
+                    "halving the MFMAs (bf16x6 -> f16x3, round 6) moved the class by 2 % (profiles/NOTES_r06.md section 3); the counter-based "
                     "matrix-pipe busy fraction of these kernels is in profiles/r03_pmc_mfma_busy.json"}
     lt = c["ms_per_step"] / c["launches_per_step"]
     # kernel-only duration of the same kernel from a kernel trace taken in THIS run (a child run of this script under
@@ -612,7 +618,9 @@ def live_kernel_time(args, kname):
                 if match(r["Kernel_Name"]):
                     tot += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                     n += 1
-                    names.add(r["Kernel_Name"].split("(")[0][-60:])
+                    kn_ = r["Kernel_Name"]
+                    i_ = kn_.find(kname.split("<")[0])
+                    names.add(kn_[i_:kn_.find(">", i_) + 1] if i_ >= 0 else kn_[:60])
         if n == 0:
             return {"error": f"no kernel-trace rows for {kname}"}
         return {"avg_us": tot / n / 1e3, "dispatches": n, "instances": sorted(names)[:4],
