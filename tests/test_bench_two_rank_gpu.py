@@ -44,7 +44,7 @@ def test_bench_eight_ranks_full_size_dry_run(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, OSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OSM_BENCH_DUMP=str(tmp_path))
-    tail = ["--steps", "2", "--warmup", "1", "--cpu-steps", "0", "--secondary-steps", "0", "--pmc", "off"]
+    tail = ["--steps", "2", "--warmup", "1", "--cpu-steps", "0", "--secondary-steps", "0", "--pmc", "off", "--scale-only"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + tail, env=env, capture_output=True,
                          text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -53,7 +53,12 @@ def test_bench_eight_ranks_full_size_dry_run(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["finite_outputs"]
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]
-    assert "cpu_baseline" not in d and "secondary" not in d and "roofline" in d
+    assert "cpu_baseline" not in d and "secondary" not in d and "roofline" in d and "full_chain" not in d and "long_window" not in d
+    # a scaling line says that every rank reported and which device each one drove (here the eight ranks
+    # share cuda:0 by construction -- OSM_BENCH_BACKEND=gloo -- so `devices_distinct` is False and that is not an error), and the
+    # transport negotiation is visible on stderr as soon as it is known
+    assert d["ranks_seen"] == 8 and d["ranks_complete"] is True and d["per_rank_device"] == [0] * 8 and d["devices_distinct"] is False
+    assert out.stderr.count("[RankSync rank") >= 8 and "transport = gloo" in out.stderr
     # start-up of the eight ranks of ONE node: per-rank seconds from process start to the timed window -- host
     # initialisation of 552.8 M parameters (a per-parameter-seeded thread pool since round 5: it was 2 x 8 s of one sequential
     # generator), the 2.2 GB upload, weight-image packing (0.06 s of device kernels: no cache needed), plan recording + graph capture
