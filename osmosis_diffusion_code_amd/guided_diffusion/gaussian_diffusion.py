@@ -259,8 +259,8 @@ class GaussianDiffusion:
     def _fused_loop(self, model, cond, x_start, measurement, sample_pattern, kwargs, record=False, record_every=150):
         """One device-resident step per index, for the Osmosis configuration and for the rgb-guidance ('ps') one (`_fast_path_ok`).
         Per-step noise (gaussian_diffusion.py:266-268 / :497 / :522): by default drawn INSIDE osm_guide_update_rng from the
-        library's Philox-4x32-10 stream (seed: `noise_seed=`, else one draw from torch's CPU generator, so `torch.manual_seed`
-        still fixes the chain); `noise="aten"` (or OSM_STEP_NOISE=aten) draws it with torch on the device in the reference's
+        library's Philox-4x32-10 stream (seed: `noise_seed=`, else one draw per chain from the device's torch generator, so
+        `torch.manual_seed` still fixes the chain); `noise="aten"` (or OSM_STEP_NOISE=aten) draws it with torch on the device in the reference's
         call order instead (the reference's own realisation for the same seed); `noise_fn=` injects it (parity runs)."""
         import os
         from .condition_methods import PosteriorSampling
@@ -321,8 +321,8 @@ class GaussianDiffusion:
         seed = 0
         if source == "library":
             seed = kwargs.get("noise_seed")
-            if seed is None:
-                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            if seed is None:      # one draw per CHAIN from the device's generator (what torch.manual_seed seeds, and only device ops consume)
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev).item())
         img_base, img_stride = int(kwargs.get("image_index0", 0)), 0 if shared else 1
         noise = None if lib_rng else torch.zeros(B, 4, H, W, **f32)
         noise1 = torch.zeros(1, 4, H, W, **f32) if (shared and source == "aten") else None
