@@ -206,6 +206,104 @@ def test_guide_update_kernel(mods):
     assert torch.allclose(out.cpu(), mean - scale4[None, :, None] * grad.clamp(-0.005, 0.005), atol=1e-6)
 
 
+def test_guide_update_rng_equals_guide_update_with_the_same_draws(mods):
+    """osm_guide_update_rng = osm_guide_update fed with what osm_randn draws for the same (seed, image, step): the fused kernel's
+    noise is exactly the tensor form's, the step offset and image stride mean what the header says, index 0 adds no noise."""
+    ops, _, _ = mods
+    g = torch.Generator().manual_seed(14)
+    B, HW = 3, 48
+    mean, lv, gg, dxu = (torch.randn(B, 4, HW, generator=g).to(DEV) * s for s in (1, 0.3, 0.01, 0.01))
+    coef = torch.tensor([1.7, 0.3, 0, 0, 0, 0, 1.0, 5.0], device=DEV)
+    scale4 = torch.tensor([7.0, 7.0, 7.0, 0.9], device=DEV)
+    step = torch.tensor([41], device=DEV, dtype=torch.int32)
+    seed = 0x1234_5678_9abc_def0
+    for img0, stride in ((0, 1), (5, 1), (2, 0)):
+        nz = torch.empty(B, 4, HW, device=DEV)
+        ops.randn(nz, B, 4 * HW, seed, step_const=42, img0=img0, img_stride=stride)
+        ref, gref = torch.empty(B, 4, HW, device=DEV), torch.empty(B, 4, HW, device=DEV)
+        ops.guide_update(mean, lv, gg, dxu, nz, coef, scale4, 0.005, ref, gref, B, HW)
+        out, gout, used = (torch.empty(B, 4, HW, device=DEV) for _ in range(3))
+        ops.guide_update_rng(mean, lv, gg, dxu, coef, scale4, 0.005, out, gout, used, B, HW, seed, step, step_offset=1, img0=img0,
+                             img_stride=stride)
+        assert torch.equal(used, nz) and torch.equal(gout, gref)
+        assert torch.allclose(out, ref, atol=1e-6)
+        if stride == 0:
+            assert torch.equal(used[0], used[1]) and torch.equal(used[1], used[2])
+        else:
+            assert not torch.equal(used[0], used[1])
+    nz2 = torch.empty(B, 4, HW, device=DEV)
+    ops.randn(nz2, B, 4 * HW, seed, step=step, img0=0)             # the device counter (41) instead of the constant
+    ops.randn(nz, B, 4 * HW, seed, step_const=41, img0=0)
+    assert torch.equal(nz, nz2)
+    tail = torch.full((13,), 7.0, device=DEV)                        # B = 1, n % 4 != 0: the scalar tail, nothing past n
+    ops.randn(tail[:10], 1, 10, seed, step_const=3)
+    full = torch.empty(12, device=DEV)
+    ops.randn(full, 1, 12, seed, step_const=3)
+    assert torch.equal(tail[:10], full[:10]) and float(tail[10:].min()) == 7.0
+    coef[6] = 0.0                                                    # index 0 of a chain: no noise (gaussian_diffusion.py:267)
+    ops.guide_update_rng(mean, lv, gg, dxu, coef, scale4, 0.005, out, None, used, B, HW, seed, step)
+    assert float(used.abs().max()) == 0.0
+    assert torch.allclose(out, mean - scale4[None, :, None] * (1.7 * gg + dxu).clamp(-0.005, 0.005), atol=1e-6)
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.7])
+def test_ddim_update_kernel(mods, eta):
+    """osm_ddim_update vs DDIM.p_sample's statements (gaussian_diffusion.py:505-528) in fp32 torch, + the guidance subtraction of
+    condition_methods.py:247-251, for eta = 0 (what p_sample_loop uses) and eta > 0 (noise term), and at index 0 (no noise)."""
+    ops, _, _ = mods
+    g = torch.Generator().manual_seed(8)
+    B, HW = 2, 40
+    x, x0, gg, dxu, nz = (torch.randn(B, 4, HW, generator=g) * s for s in (1, 0.8, 0.01, 0.01, 1))
+    ab, abp = 0.37, 0.52
+    c0, c1 = float(np.float32(np.sqrt(1.0 / ab))), float(np.float32(np.sqrt(1.0 / ab - 1.0)))
+    coef = torch.tensor([c0, c1, 0, 0, 0, 0, 1.0, 5.0], device=DEV)
+    scale4 = torch.tensor([0.6, 0.5, 0.4, 0.0])
+    for noise_on in (1.0, 0.0):
+        dcoef = torch.tensor([ab, abp, eta, noise_on, 0, 0, 0, 5.0], device=DEV)
+        out, gout = torch.empty(B, 4, HW, device=DEV), torch.empty(B, 4, HW, device=DEV)
+        xd = x.to(DEV)
+        ops.ddim_update(x0.to(DEV), xd, gg.to(DEV), dxu.to(DEV), nz.to(DEV), coef, dcoef, scale4.to(DEV), -1.0, out, gout, B, HW)
+        abt, abpt = torch.tensor(ab), torch.tensor(abp)
+        eps = (torch.tensor(c0) * x - x0) / torch.tensor(c1)
+        sigma = eta * torch.sqrt((1 - abpt) / (1 - abt)) * torch.sqrt(1 - abt / abpt)
+        ref = x0 * torch.sqrt(abpt) + torch.sqrt(1 - abpt - sigma ** 2) * eps
+        if noise_on:
+            ref = ref + sigma * nz
+        grad = c0 * gg + dxu
+        ref = ref - grad * scale4[None, :, None]
+        assert torch.allclose(gout.cpu(), grad, atol=1e-7)
+        assert torch.allclose(out.cpu(), ref, atol=2e-6), float((out.cpu() - ref).abs().max())
+        ops.ddim_update(x0.to(DEV), xd, gg.to(DEV), dxu.to(DEV), nz.to(DEV), coef, dcoef, scale4.to(DEV), -1.0, xd, None, B, HW)
+        assert torch.equal(xd, out)                                  # x_next may alias x
+
+
+def test_identity_operator_loss_and_gradient(mods):
+    """osm_phys_desc.kind 3 (the `noise` / `rgb_guidance` operators of the `ps` path): loss[b] = ||y[b] - x0[b, 0:3]||, g = d loss / d x0
+    (zero on depth), per image, vs torch autograd; parameters cannot be stepped."""
+    ops, M, CM = mods
+    from osmosis_diffusion_code_amd._lib import OsmosisHipError
+    g = torch.Generator().manual_seed(2)
+    B, H, W = 2, 24, 40
+    x0 = torch.randn(B, 4, H, W, generator=g)
+    y = torch.rand(B, 3, H, W, generator=g) * 1.6 - 0.8
+    y[1] *= 3.0                                                      # very different norms per image
+    cond = CM.get_conditioning_method("ps", M.get_operator("rgb_guidance", device=DEV, batch_size=B),
+                                      M.get_noise("gaussian", sigma=0.05), scale="0.6,0.5,0.4,0.0")
+    assert cond.hip_ok()
+    gx, loss = cond.loss_grad_x0(x0.to(DEV), y.to(DEV))
+    xr = x0.clone().requires_grad_(True)
+    per = torch.stack([torch.linalg.norm(y[b] - xr[b, 0:3]) for b in range(B)])
+    per.sum().backward()
+    assert torch.allclose(loss.cpu(), per.detach(), rtol=2e-6)
+    assert torch.allclose(gx.cpu(), xr.grad, atol=2e-7 + 1e-5 * float(xr.grad.abs().max()))
+    assert float(gx[:, 3].abs().max()) == 0.0
+    st = cond._states[(B, H * W, DEV)]
+    with pytest.raises(OsmosisHipError, match="no parameters"):
+        ops.phys_finalize(st["desc"], st["part"], st["red"], st["phi"], True, None)
+    assert not CM.get_conditioning_method("ps", M.get_operator("rgb_guidance", device=DEV, batch_size=B),
+                                          M.get_noise("poisson", rate=1.0), scale="1").hip_ok()
+
+
 @pytest.mark.parametrize("t", [999, 500, 3])
 def test_posterior_round_trip_at_full_size(mods, t):
     """Size-independent property at BASELINE size (B = 8, 256x256): noising a clean image with q(x_t | x_0) and handing
