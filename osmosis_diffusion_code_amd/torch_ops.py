@@ -141,6 +141,39 @@ def _guide_update_fake(mean, log_variance, g, dx_unet, noise, coef, scale4, clip
     return torch.empty_like(mean), torch.empty_like(mean)
 
 
+@torch.library.custom_op("osmosis::guide_update_rng", mutates_args=(), device_types="cuda")
+def guide_update_rng(mean: torch.Tensor, log_variance: torch.Tensor, g: torch.Tensor, dx_unet: torch.Tensor, coef: torch.Tensor,
+                     scale4: torch.Tensor, clip: float, seed: int, step: torch.Tensor, step_offset: int, img0: int,
+                     img_stride: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """osmosis::guide_update with the step noise drawn in the kernel (Philox-4x32-10: key = seed, counter = (element / 4,
+    img0 + b * img_stride, step[0] + step_offset)); a pure function of its inputs.  Returns (x_next, grad, the noise drawn)."""
+    B, HW = _chw(mean)
+    x_next, grad, noise = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    ops.guide_update_rng(mean, log_variance, g, dx_unet, coef, scale4, clip, x_next, grad, noise, B, HW, seed, step,
+                         step_offset=step_offset, img0=img0, img_stride=img_stride)
+    return x_next, grad, noise
+
+
+@guide_update_rng.register_fake
+def _guide_update_rng_fake(mean, log_variance, g, dx_unet, coef, scale4, clip, seed, step, step_offset, img0, img_stride):
+    return torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+
+
+@torch.library.custom_op("osmosis::ddim_update", mutates_args=(), device_types="cuda")
+def ddim_update(x0: torch.Tensor, x: torch.Tensor, g: torch.Tensor, dx_unet: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor,
+                dcoef: torch.Tensor, scale4: torch.Tensor, clip: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """DDIM step + guidance (osm_ddim_update): coef = the posterior row, dcoef = row of GaussianDiffusion.ddim_table()."""
+    B, HW = _chw(x0)
+    x_next, grad = torch.empty_like(x0), torch.empty_like(x0)
+    ops.ddim_update(x0, x, g, dx_unet, noise, coef, dcoef, scale4, clip, x_next, grad, B, HW)
+    return x_next, grad
+
+
+@ddim_update.register_fake
+def _ddim_update_fake(x0, x, g, dx_unet, noise, coef, dcoef, scale4, clip):
+    return torch.empty_like(x0), torch.empty_like(x0)
+
+
 PHYS_ICFG = ("kind", "depth_type", "weight_type", "wdepth_type", "loss_type", "optimizer")
 PHYS_FCFG = ("dval0", "dval1", "dval2", "wval0", "wval1", "wval2", "gamma_avrg", "gamma_val", "eta0", "eta1", "eta2")
 
@@ -163,7 +196,9 @@ def phys_loss_grad(x0: torch.Tensor, y: torch.Tensor, phi: torch.Tensor, icfg: L
     for k, v in zip(PHYS_ICFG, icfg):
         setattr(d, k, int(v))
     if d.optimizer != 0:
-        raise OsmosisHipError("osmosis::phys_loss_grad is functional: optimizer state (adam) lives with the conditioning method")
+        raise OsmosisHipError("osmosis::phys_loss_grad is functional: optimizer state (adam, ...) lives with the conditioning method")
+    if d.kind == 3 and not freeze_phi:
+        raise OsmosisHipError("osmosis::phys_loss_grad: the identity operator (kind 3) has no parameters: pass freeze_phi=True")
     for i in range(3):
         d.dval[i], d.wval[i], d.eta[i] = fcfg[i], fcfg[3 + i], fcfg[8 + i]
     d.gamma_avrg, d.gamma_val = fcfg[6], fcfg[7]
@@ -183,4 +218,4 @@ def _phys_loss_grad_fake(x0, y, phi, icfg, fcfg, n_inner, freeze_phi):
     return x0.new_empty((x0.shape[0],)), torch.empty_like(x0), torch.empty_like(phi)
 
 
-OPS = ("unet_fwd", "unet_bwd_data", "posterior", "posterior_bwd", "guide_update", "phys_loss_grad")
+OPS = ("unet_fwd", "unet_bwd_data", "posterior", "posterior_bwd", "guide_update", "guide_update_rng", "ddim_update", "phys_loss_grad")

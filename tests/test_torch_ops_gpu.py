@@ -15,7 +15,7 @@ TINY_KW = dict(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="
 
 
 def test_operators_are_registered_with_schemas():
-    """CPU: importing the package registers the six operators (no GPU, no library call needed for that)."""
+    """CPU: importing the package registers the eight operators (no GPU, no library call needed for that)."""
     from osmosis_diffusion_code_amd import torch_ops
     want = {"unet_fwd": "osmosis::unet_fwd(Tensor x, Tensor t, SymInt engine) -> Tensor",
             "unet_bwd_data": "osmosis::unet_bwd_data(Tensor grad_out, SymInt engine) -> Tensor",
@@ -141,3 +141,28 @@ def test_guidance_operators_match_the_in_place_calls_and_opcheck():
     assert torch.equal(x_next, xr) and torch.equal(grad, gr)
     torch.library.opcheck(torch.ops.osmosis.guide_update.default, (mean, lv, gx0, dx_unet, noise, coef, scale4, float(cond.clip_value)))
     assert np.isfinite(float(loss.sum()))
+    # round 6: the update with the noise drawn in the kernel, the DDIM step, the identity operator of the rgb-guidance path
+    step = torch.tensor([120], device=DEV, dtype=torch.int32)
+    xn2, gr2, nz2 = torch.ops.osmosis.guide_update_rng(mean, lv, gx0, dx_unet, coef, scale4, float(cond.clip_value), 77, step, 0, 0, 1)
+    xr2, _ = torch.ops.osmosis.guide_update(mean, lv, gx0, dx_unet, nz2, coef, scale4, float(cond.clip_value))
+    assert torch.equal(gr2, grad) and torch.allclose(xn2, xr2, atol=1e-6) and abs(float(nz2.double().var()) - 1.0) < 0.1
+    torch.library.opcheck(torch.ops.osmosis.guide_update_rng.default,
+                          (mean, lv, gx0, dx_unet, coef, scale4, float(cond.clip_value), 77, step, 0, 0, 1))
+    ddim = gd.get_sampler("ddim")(use_timesteps=range(0, 1000, 4), betas=gd.get_named_beta_schedule("linear", 1000),
+                                  model_mean_type="epsilon", model_var_type="learned_range", dynamic_threshold=False,
+                                  clip_denoised=False, rescale_timesteps=False)
+    c2 = torch.from_numpy(ddim.coef_table()[120].copy()).to(DEV)
+    d2 = torch.from_numpy(ddim.ddim_table(0.3)[120].copy()).to(DEV)
+    xd, gd_ = torch.ops.osmosis.ddim_update(x0, x, gx0, dx_unet, noise, c2, d2, scale4, -1.0)
+    xe, ge = torch.empty_like(x), torch.empty_like(x)
+    ops.ddim_update(x0, x, gx0, dx_unet, noise, c2, d2, scale4, -1.0, xe, ge, B, H * W)
+    assert torch.equal(xd, xe) and torch.equal(gd_, ge)
+    torch.library.opcheck(torch.ops.osmosis.ddim_update.default, (x0, x, gx0, dx_unet, noise, c2, d2, scale4, -1.0))
+    ps = CM.get_conditioning_method("ps", M.get_operator("rgb_guidance", device=DEV, batch_size=B), M.get_noise("gaussian", sigma=0.05),
+                                    scale="0.6,0.5,0.4,0.0")
+    g_ps, l_ps = ps.loss_grad_x0(x0s, y)
+    icfg3, fcfg3 = torch_ops.phys_config(ps._states[(B, H * W, DEV)]["desc"])
+    l3, g3, _phi3 = torch.ops.osmosis.phys_loss_grad(x0s, y, phi0, icfg3, fcfg3, 1, True)
+    assert torch.equal(g3, g_ps) and torch.equal(l3, l_ps)
+    with pytest.raises(Exception, match="no parameters"):
+        torch.ops.osmosis.phys_loss_grad(x0s, y, phi0, icfg3, fcfg3, 1, False)
