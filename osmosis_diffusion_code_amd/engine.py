@@ -827,6 +827,9 @@ class UNetEngine:
         H, W = hw
         self._xmax_invalidate(dst)
         if isinstance(l, _Down):
+            if H % 2 or W % 2:      # the reference's stride-2, pad-1 conv yields ceil(H / 2); this path keeps every other pixel of an EVEN
+                                    # image (UNetEngine refuses other sizes at construction; a BlockEngine can be handed any) -- ADVICE r05
+                raise ValueError(f"Downsample needs even H and W (got {H} x {W}): odd sizes are not supported")
             ho = (H // 2, W // 2)
             if l.conv is not None:
                 full = self._scr("a", B * H * W, l.ch)
