@@ -20,7 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", action="append", default=[], help="B,T,heads")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--arith", default="bf16x6", choices=["bf16x6", "f16x3"], help="arithmetic of the cores (osm_attn_desc.arith 0 | 2)")
     a = ap.parse_args()
+    kw = dict(f16x3=a.arith == "f16x3")
     dev, ch = "cuda:0", 64
     for s in a.shape or ["1,1024,8", "1,256,16", "1,64,16"]:
         B, T, heads = (int(v) for v in s.split(","))
@@ -33,9 +35,9 @@ def main():
         lse = torch.empty(B * heads * T, device=dev)
         delta = torch.empty(B * heads * T, device=dev)
         offs, hs, sc = (0, ch, 2 * ch), 3 * ch, 1.0 / math.sqrt(ch)
-        fwd = lambda: ops.attn_flash_fwd(ops.Mat.of(qkv), ops.Mat.of(out), lse, B, T, heads, ch, offs, hs, sc)  # noqa: E731
+        fwd = lambda: ops.attn_flash_fwd(ops.Mat.of(qkv), ops.Mat.of(out), lse, B, T, heads, ch, offs, hs, sc, **kw)  # noqa: E731
         bwd = lambda: ops.attn_flash_bwd(ops.Mat.of(qkv), ops.Mat.of(out), ops.Mat.of(dout), ops.Mat.of(dq), lse, delta,  # noqa: E731
-                                         B, T, heads, ch, offs, hs, sc)
+                                         B, T, heads, ch, offs, hs, sc, **kw)
         for name, fn, ngemm in (("fwd", fwd, 2), ("bwd", bwd, 5)):
             for _ in range(3):
                 fn()
@@ -48,7 +50,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             fl = 2.0 * B * heads * T * T * ch * ngemm
-            print(f"flash {name} {s:14s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (algorithmic)", flush=True)
+            print(f"flash {a.arith} {name} {s:14s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (algorithmic)", flush=True)
 
 
 if __name__ == "__main__":
