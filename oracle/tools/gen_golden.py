@@ -17,6 +17,7 @@ Sections (SURVEY.md section 8c recipe):
   loop_<op>.npz   10-step guided p_sample_loop for each of the 3 physical operators with the
                   exact noise tensors the reference drew, per-step traces
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
+  loop_optimizers.npz (round 6) the guided loop with each torch optimizer of utils.get_optimizer on phi: losses, phi, final image
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
   unet_variants.npz   (round 5) tiny UNets with conv up / down-sampling layers, additive conditioning, class conditioning
@@ -272,6 +273,35 @@ def gen_loops():
         out, loss, variables = _loop_trace(m, spec)
         np.savez_compressed(os.path.join(OUT, f"loop_{opname}.npz"), **out)
         print(opname, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+
+
+# eta per optimizer: large enough that phi visibly moves in 10 guided steps x 20 inner iterations, small enough to stay physical
+OPTIMIZER_ETAS = {"adam": "2e-4", "adamw": "2e-4", "adamax": "2e-4", "rmsprop": "1e-4", "adagrad": "2e-3", "adadelta": "0.5",
+                  "asgd": "1e-4", "rprop": "1e-5"}
+
+
+def gen_optimizers():
+    """(round 6) The REAL reference's guided loop with every torch optimizer of utils.get_optimizer that can step phi
+    (utils.py:494-524; measurements.py:244-249 builds it with one parameter group per phi, lr = eta): per-step loss and phi,
+    final image.  x_T, y and the noise are those of loop_underwater_physical_revised.npz (same seeds, same draw order)."""
+    m, cfg, sd = tiny_model()
+    base = OPERATORS["underwater_physical_revised"]
+    out = {}
+    for name, eta in OPTIMIZER_ETAS.items():
+        spec = dict(base, operator=dict(base["operator"], optimizer=name, phi_a_eta=eta, phi_b_eta=eta, phi_inf_eta=eta))
+        tr, loss, variables = _loop_trace(m, spec)
+        if not out:
+            out.update({"x_T": tr["x_T"], "y": tr["y"], "noise": tr["noise"]})
+        else:
+            assert np.array_equal(out["noise"], tr["noise"]) and np.array_equal(out["x_T"], tr["x_T"])
+        out[f"{name}.eta"] = np.array(float(eta))
+        out[f"{name}.final_img"] = tr["final_img"]
+        out[f"{name}.final_x0"] = tr["final_x0"]
+        out[f"{name}.loss"] = tr["trace.loss"]
+        for k in ("phi_a", "phi_b", "phi_inf"):
+            out[f"{name}.{k}"] = tr[f"trace.{k}"]
+        print(name, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+    np.savez_compressed(os.path.join(OUT, "loop_optimizers.npz"), **out)
 
 
 def gen_fp16():
@@ -673,6 +703,7 @@ if __name__ == "__main__":
     gen_outputs()
     gen_configs()
     gen_ps()
+    gen_optimizers()
     gen_fp16()
     gen_full_unet()
     gen_full_step()

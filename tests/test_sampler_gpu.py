@@ -103,6 +103,41 @@ def test_fused_loop_matches_reference_trace(pkg, opname, conv_mode):
         assert torch.allclose(v.cpu(), torch.from_numpy(g[f"final.{n}"]), atol=2e-6), n
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "adamw", "adamax", "rmsprop", "adagrad", "adadelta", "asgd", "rprop"])
+def test_fused_loop_with_every_phi_optimizer_matches_the_reference(pkg, optimizer):
+    """Round 6: `optimizer: <name>` of the operator config (utils.py:494-524) through the fused loop vs the REAL reference's guided
+    loop with that torch optimizer (tests/golden/loop_optimizers.npz: 10 steps, 7 of them with 20 inner iterations; phi moves by
+    1e-2 ... 3e-1): per-step loss and phi, final image and pred_xstart."""
+    unet, gd, M, CM = pkg
+    g = np.load(os.path.join(GOLD, "loop_optimizers.npz"))
+    spec = OPERATORS["underwater_physical_revised"]
+    eta = repr(float(g[f"{optimizer}.eta"]))
+    model = make_model(unet)
+    operator = M.get_operator("underwater_physical_revised", device=DEV, batch_size=1,
+                              **{**spec["operator"], "optimizer": optimizer, "phi_a_eta": eta, "phi_b_eta": eta, "phi_inf_eta": eta})
+    cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    noise = torch.from_numpy(g["noise"]).to(DEV)
+    trace = []
+    img, variables, loss, x0 = make_sampler(gd).p_sample_loop(
+        model=model, x_start=torch.from_numpy(g["x_T"]).to(DEV), measurement=torch.from_numpy(g["y"]).to(DEV),
+        measurement_cond_fn=cond.conditioning, record=False, save_root=None, pretrain_model="osmosis",
+        rgb_guidance=False, sample_pattern=PATTERN, noise_fn=lambda k, shape: noise[k], trace=trace)
+    moved = max(float(np.abs(g[f"{optimizer}.{n}"][-1] - g[f"{optimizer}.{n}"][0]).max()) for n in ("phi_a", "phi_b", "phi_inf"))
+    e_loss = max(abs(float(rec["loss"][0]) - float(g[f"{optimizer}.loss"][k].reshape(-1)[0])) / float(g[f"{optimizer}.loss"][k].reshape(-1)[0])
+                 for k, rec in enumerate(trace))
+    e_phi = 0.0
+    for k, rec in enumerate(trace):
+        ph = rec["phi"].cpu().reshape(9)
+        ref = np.concatenate([g[f"{optimizer}.{n}"][k].reshape(-1) for n in ("phi_a", "phi_b", "phi_inf")])
+        e_phi = max(e_phi, float(np.abs(ph.numpy() - ref).max()))
+    e_img = float((img.cpu() - torch.from_numpy(g[f"{optimizer}.final_img"])).abs().max())
+    e_x0 = float((x0 - torch.from_numpy(g[f"{optimizer}.final_x0"])).abs().max())
+    print(f"{optimizer}: phi moved {moved:.3f}; errors vs the reference: loss(rel) {e_loss:.1e} phi {e_phi:.1e} img {e_img:.1e} x0 {e_x0:.1e}")
+    assert moved > 5e-3
+    # measured (round 6): loss 1.0e-7 ... 2.1e-7, phi 0 ... 3.6e-7, image / x0 7.7e-7 ... 9.8e-7; bars at ~5x
+    assert e_loss < 1e-6 and e_phi < 2e-6 and e_img < 5e-6 and e_x0 < 5e-6
+
+
 def test_reference_api_generic_path_matches_fused(pkg):
     """The reference call pattern (model(x,t) -> p_mean_variance -> conditioning(...)) through
     torch.autograd gives the same step as the fused path."""
