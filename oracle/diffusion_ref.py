@@ -163,6 +163,17 @@ class PhysOperator:
         self.phi = {n: vec(kw[n]) for n in self.names}
         self.eta = {n: (float(kw.get(n + "_eta", 1e-5)) if kw.get(n + "_learn_flag", True) else 0.0)
                     for n in self.names}
+        # measurements.py:244-249 / utils.py:494-524: `optimizer: <name>` = the torch.optim class with ITS defaults over one parameter
+        # group per phi (lr = eta); None / "GD" / "sgd" with default momentum 0 = plain phi -= eta * grad (measurements.py:272-280)
+        name = (kw.get("optimizer") or "").lower()
+        classes = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adamax": torch.optim.Adamax, "rmsprop": torch.optim.RMSprop,
+                   "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta, "asgd": torch.optim.ASGD, "rprop": torch.optim.Rprop}
+        if name in ("", "gd", "sgd"):
+            self.optimizer = None
+        elif name in classes:
+            self.optimizer = classes[name]([{"params": self.phi[n], "lr": self.eta[n]} for n in self.names])
+        else:
+            raise ValueError(f"Optimizer '{name}' is not supported.")
 
     def forward(self, data):
         rgb01 = 0.5 * (data[:, 0:-1] + 1)
@@ -178,6 +189,11 @@ class PhysOperator:
             p.requires_grad_(flag)
 
     def sgd_step(self):
+        """measurements.py:266-303 `optimize`: the GD branch, or optimizer.step() + zero_grad()."""
+        if self.optimizer is not None:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            return
         with torch.no_grad():
             for n, p in self.phi.items():
                 if p.grad is not None:

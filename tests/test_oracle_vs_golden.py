@@ -144,6 +144,29 @@ def test_guided_loop_10_steps(opname):
         assert torch.allclose(v, T(g[f"final.{n}"]), atol=1e-6), n
 
 
+@pytest.mark.parametrize("optimizer", ["adamw", "rmsprop", "asgd", "rprop"])
+def test_guided_loop_with_a_torch_optimizer_on_phi(optimizer):
+    """Round 6: the oracle's phi step with `optimizer: <name>` (measurements.py:244-249, utils.py:494-524) against the REAL reference's
+    guided loop with that optimizer (loop_optimizers.npz): the checker of the device-side optimizer steps is itself pinned."""
+    g = load("loop_optimizers.npz")
+    cfg, sd = tiny()
+    okw, ckw = OPS["underwater_physical_revised"]
+    eta = float(g[f"{optimizer}.eta"])
+    op = D.PhysOperator("underwater_physical_revised", batch_size=1, optimizer=optimizer, phi_a_eta=eta, phi_b_eta=eta, phi_inf_eta=eta,
+                        **okw)
+    guide = D.OsmosisGuidance(op, n_iter=20, **ckw)
+    tb = D.Tables(D.named_beta_schedule("linear", 1000), range(0, 100, 10))
+    trace = []
+    img, variables, loss, x0 = D.p_sample_loop(lambda x, t: U.unet_forward(sd, cfg, x, t), tb, T(g["x_T"]), T(g["y"]), guide, PATTERN,
+                                               [T(n) for n in g["noise"]], trace)
+    for k, rec in enumerate(trace):
+        assert np.allclose(rec["loss"], g[f"{optimizer}.loss"][k], rtol=1e-5), (k, "loss")
+        for n in ("phi_a", "phi_b", "phi_inf"):
+            assert torch.allclose(rec["phi"][n], T(g[f"{optimizer}.{n}"][k]), atol=2e-6), (k, n)
+    assert torch.allclose(img, T(g[f"{optimizer}.final_img"]), atol=5e-5)
+    assert float((variables["phi_inf"] - T(g[f"{optimizer}.phi_inf"][0])).abs().max()) > 5e-3      # phi really moved
+
+
 def test_fp16_reference_fixture_is_consistent():
     """tests/golden/fp16_reference.npz (round 4: the real reference with convert_to_fp16() applied): its fp32 half is the same
     network on the same inputs -- the oracle reproduces it -- and its fp16 half differs from it by the half-precision amount."""
