@@ -95,12 +95,14 @@ def main():
     # attention cores (a counter behind bench.py's attention_mfma_util): per kernel of the flash family
     for shape in ATTN:
         B, T, heads = (int(v) for v in shape.split(","))
-        subs = ["flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_kernel"]
-        accs = collect([os.path.join(REPO, "tools", "attn_probe.py"), "--shape", shape, "--iters", "10"], subs)
         per = 2.0 * B * heads * T * T * 64
-        for sub, ngemm in (("flash_fwd_kernel", 2), ("flash_bwd_q_kernel", 3), ("flash_bwd_kv_kernel", 4)):
-            # forward: S, PV; bwd_q: S, dP, dq; bwd_kv: S, dP, dv, dk (S and dP are recomputed by both backward kernels)
-            rows.append(row(sub + " (bf16x6)", accs[sub], per * ngemm, 6, 1.0, {"shape_B,T,heads": shape, "gemms_executed": ngemm}))
+        # round 6: the product's cores are the f16x3 instances (three MFMAs per product); the bf16x6 ones (OSM_ATTN_F16X3=0) beside them
+        for arith, suffix, nm in (("f16x3", "_hp_kernel", 3), ("bf16x6", "_kernel", 6)):
+            subs = ["flash_fwd" + suffix, "flash_bwd_q" + suffix, "flash_bwd_kv" + suffix]
+            accs = collect([os.path.join(REPO, "tools", "attn_probe.py"), "--shape", shape, "--iters", "10", "--arith", arith], subs)
+            for sub, ngemm in zip(subs, (2, 3, 4)):
+                # forward: S, PV; bwd_q: S, dP, dq; bwd_kv: S, dP, dv, dk (S and dP are recomputed by both backward kernels)
+                rows.append(row(f"{sub} ({arith})", accs[sub], per * ngemm, nm, 1.0, {"shape_B,T,heads": shape, "gemms_executed": ngemm}))
     json.dump({"note": __doc__.split("Counters:")[1].strip(), "rows": rows}, open(out_json, "w"), indent=1)
     print(json.dumps(rows, indent=1))
 
