@@ -535,7 +535,7 @@ def roofline(model, args, reps=3):
             "note": f"algorithmic flops / HIP-event time of the launches / (dense MFMA peak 2500 TF / {n_att} MFMAs per product); "
                     "B = 1 has 8-16 (image, head) pairs of <= 1024 tokens: chains of dependent L2 round trips on one round of workgroups -- "
                     "halving the MFMAs (bf16x6 -> f16x3, round 6) moved the class by 2 % (profiles/NOTES_r06.md section 3); the counter-based "
-                    "matrix-pipe busy fraction of these kernels is in profiles/r03_pmc_mfma_busy.json"}
+                    "matrix-pipe busy fraction of these kernels is in profiles/r06_pmc_mfma_busy.json (0.094-0.098 at T = 1024)"}
     lt = c["ms_per_step"] / c["launches_per_step"]
     # kernel-only duration of the same kernel from a kernel trace taken in THIS run (a child run of this script under
     # `rocprofv3 --kernel-trace`, one guided step): what profiles/rNN_rocprofv3_kernel_stats.csv reports.  The HIP-event time
