@@ -422,7 +422,11 @@ class UNetEngine:
         H, W = hw
         # (only where the halo-tile kernel serves the layer: with OSM_CONV_HALO=0, the documented A/B switch, the wfmt-4 direct
         # image has no kernel and the layer keeps its bf16x6 images -- ADVICE r05)
-        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (H < self.winograd_min_hw or W < self.winograd_min_hw) and \
+        small = H < self.winograd_min_hw or W < self.winograd_min_hw
+        # the layers the Winograd kernel never serves (stem 4 -> 256, the head's data-gradient 8 -> 256, the stem's 256 -> 4) take
+        # the same image on the halo-tile kernel (round 6: -0.04 ms per step, same-box tools/step_ab.py; OSM_F16X3_HEADSTEM=0: bf16x6)
+        never = cv.wwf is None and os.environ.get("OSM_F16X3_HEADSTEM", "1") != "0"
+        return cv.k == 3 and cv._slot is not None and min(H, W) >= 8 and (small or never) and \
             os.environ.get("OSM_CONV_HALO", "1") != "0"
 
     # ---- registry of "max |.| of this gradient buffer was left behind by its last writer" (f16x3 range hand-over)
