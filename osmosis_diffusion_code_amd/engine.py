@@ -306,6 +306,8 @@ class UNetEngine:
         # the finishing phase it was +0.18 ms); "all": from the direct halo-tile kernel as well (4-byte accesses in the MFMA C
         # layout: +1.3 ms of convolution for -1.5 ms of GroupNorm at B = 1, round 2; fp16 family +0.9 ms at B = 32); "0": neither
         self.winograd_min_hw = int(os.environ.get("OSM_WINOGRAD_MIN_HW", "16"))   # smallest H, W served by the Winograd kernel
+        self.f16x3_1x1_min_hw = int(os.environ.get("OSM_F16X3_1X1_MIN_HW", "4096"))   # smallest H * W whose 1x1 layers take the f16x3 image (>= 1024: the
+        # range hand-over needs the chunked statistics pass; measured round 6: 1024 instead of 4096 moves the step by +0.001 ms)
         fs = os.environ.get("OSM_FUSE_STATS", "fwd" if self.adt == torch.float16 else "wino")
         self.fuse_gn_wino = os.environ.get("OSM_FUSE_GN_WINO", "0") == "1"
         self.fuse_stats = self.fuse_gn and fs != "0"
@@ -383,7 +385,7 @@ class UNetEngine:
                 if xm is None:
                     xm = self._xmax_slot(ws_slot)
                     ops.maxabs(x, self.B, xm)
-        elif cv.wf16 is not None and xmax is not None and H * W >= 4096 and (H * W) % 128 == 0:
+        elif cv.wf16 is not None and xmax is not None and H * W >= self.f16x3_1x1_min_hw and (H * W) % 128 == 0:
             wfmt, wimg, xm = 4, (cv.wd16 if dgrad else cv.wf16), xmax     # 1x1 f16x3: only where the range is already known
         elif gn_table is None and self._is_direct_f16(cv, hw):
             wfmt, wimg, xm = 4, cv.direct_f16x3(dgrad), xmax
@@ -596,7 +598,7 @@ class UNetEngine:
             # the skip connection's 1x1 convolution reads x itself: where it has an f16x3 image, the statistics pass of the first
             # GroupNorm (which reads every element of x anyway) leaves max |x| behind for it -- so it runs AFTER that pass
             xin = None
-            if blk.skip is not None and blk.skip.wf16 is not None and HW >= 4096 and HW % 128 == 0 and \
+            if blk.skip is not None and blk.skip.wf16 is not None and HW >= self.f16x3_1x1_min_hw and HW % 128 == 0 and \
                     not self._gn_fusable(blk.c1, hw) and ops.gn_nchunk(HW) <= ops.MAXABS_PARTS:
                 xin = self._xmax_slot("skip")
             cs1 = self._gn_conv(x, blk.n1, st1, blk.c1, h1, hw, table=tab1,
