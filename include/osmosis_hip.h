@@ -292,6 +292,17 @@ int osm_copy2d(const float* x, long long ldx, float* y, long long ldy, long long
  *   x0 = c0*x - c1*eps ; mean = c2*x0 + c3*x ; logvar = f*c5 + (1-f)*c4, f=(v+1)/2 */
 int osm_posterior(const float* model_out /*[B,8,HW]*/, const float* x /*[B,4,HW]*/, const float* coef,
                   float* x0, float* mean, float* logvar, int B, int HW, void* stream);
+/* The same step for every registered processor pair (posterior_mean_variance.py:53-136 mean, :171-258 variance; osm_posterior is
+ * (0, 0)).  The row keeps ONE meaning for all mean kinds: c0 = d x0/d x, c1 = -d x0/d out (what osm_posterior_bwd and the
+ * update kernels read), c2 / c3 = posterior_mean_coef1 / 2, coef[4] / coef[5] = the variance processor's row.
+ *   mean_kind 0 'epsilon'    : x0 = c0*x - c1*out, mean = c2*x0 + c3*x       (c0 = sqrt_recip_ac, c1 = sqrt_recipm1_ac)
+ *             1 'start_x'    : x0 = out,           mean = c2*x0 + c3*x       (row: c0 = 0, c1 = -1)
+ *             2 'previous_x' : x0 = c0*x - c1*out, mean = out                (row: c0 = -coef2/coef1, c1 = -1/coef1)
+ *   var_kind  0 'learned_range': logvar = f*coef[5] + (1-f)*coef[4], f = (v+1)/2 ; 1 'fixed_small' / 'fixed_large': logvar = coef[4]
+ *             (log posterior_variance[t] / log(append(posterior_variance[1], betas[1:]))[t]) ; 2 'learned': logvar = v
+ * (v = model_out[:, 4:8]: the network of the path always has 2 C output channels, gaussian_diffusion.py:349-350). */
+int osm_posterior_typed(const float* model_out, const float* x, const float* coef, int mean_kind, int var_kind,
+                        float* x0, float* mean, float* logvar, int B, int HW, void* stream);
 
 /* physical forward model + guidance loss (measurements.py:138-151,251-264,363-376;
  * condition_methods.py:109-144; losses.py:29-83; utils.py:544-566,674-700) */
@@ -363,9 +374,11 @@ int osm_randn(float* out, int B, long long n, unsigned long long seed, const int
  * tests against the Random123 known-answer vectors. */
 int osm_philox_raw(unsigned* out, long long n4, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, void* stream);
 /* DDIM step + guidance of the rgb-guidance path (gaussian_diffusion.py:505-535 `DDIM.p_sample`, condition_methods.py:247-251):
- *   eps = (c0*x - x0)/c1 ; sigma = eta*sqrt((1-abp)/(1-ab))*sqrt(1-ab/abp) ; grad = c0*g + dx_unet
+ *   eps = (r0*x - x0)/r1 ; sigma = eta*sqrt((1-abp)/(1-ab))*sqrt(1-ab/abp) ; grad = c0*g + dx_unet
  *   x_next = x0*sqrt(abp) + sqrt(1-abp-sigma^2)*eps + noise_on*sigma*noise - scale[c]*clamp(grad,+-clip)
- * coef: the posterior row of the step; dcoef: device float[8] = {alpha_bar, alpha_bar_prev, eta, noise_on, -, -, -, t}.
+ * coef: the posterior row of the step (only c0 = d x0/d x is read); dcoef: device float[8] = {alpha_bar, alpha_bar_prev, eta,
+ * noise_on, r0 = sqrt_recip_alphas_cumprod, r1 = sqrt_recipm1_alphas_cumprod, -, t}: predict_eps_from_x_start (:533-536) reads the
+ * sampler's own tables, whatever the mean processor (for 'epsilon' r0 = c0, r1 = c1).
  * g / dx_unet / noise / grad_out optional; x_next may alias x. */
 int osm_ddim_update(const float* x0, const float* x, const float* g, const float* dx_unet, const float* noise,
                     const float* coef, const float* dcoef, const float* scale4, float clip, float* x_next, float* grad_out,

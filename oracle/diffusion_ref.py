@@ -110,14 +110,38 @@ def _coef(arr: np.ndarray, t: int) -> float:
 
 
 # ----------------------------------------------------------------------------- posterior
-def p_mean_variance(tb: Tables, model_out: torch.Tensor, x: torch.Tensor, t: int) -> Dict[str, torch.Tensor]:
-    """epsilon mean + learned_range variance (pmv.py:127-136, 246-258; gd.py:345-365)."""
+def p_mean_variance(tb: Tables, model_out: torch.Tensor, x: torch.Tensor, t: int, mean_type: str = "epsilon",
+                    var_type: str = "learned_range") -> Dict[str, torch.Tensor]:
+    """gd.py:345-365 over the registered processors of posterior_mean_variance.py: mean `epsilon` (:104-136, the one every
+    shipped config names), `start_x` (:75-101: the network predicts x_0), `previous_x` (:53-72: the network predicts the mean,
+    x_0 solved from it); variance `learned_range` (:225-258), `fixed_small` (:171-187), `fixed_large` (:190-212), `learned`
+    (:215-222).  The network of the path has 2 C output channels, so the split of gd.py:349-350 always happens."""
     C = x.shape[1]
-    eps, v = torch.split(model_out, C, dim=1)
-    x0 = _coef(tb.sqrt_recip_alphas_cumprod, t) * x - _coef(tb.sqrt_recipm1_alphas_cumprod, t) * eps
-    mean = _coef(tb.posterior_mean_coef1, t) * x0 + _coef(tb.posterior_mean_coef2, t) * x
-    frac = (v + 1.0) / 2.0
-    logvar = frac * _coef(tb.log_betas, t) + (1 - frac) * _coef(tb.posterior_log_variance_clipped, t)
+    out, v = torch.split(model_out, C, dim=1)
+    pc1, pc2 = tb.posterior_mean_coef1, tb.posterior_mean_coef2
+    if mean_type == "epsilon":
+        x0 = _coef(tb.sqrt_recip_alphas_cumprod, t) * x - _coef(tb.sqrt_recipm1_alphas_cumprod, t) * out
+        mean = _coef(pc1, t) * x0 + _coef(pc2, t) * x
+    elif mean_type == "start_x":
+        x0 = out
+        mean = _coef(pc1, t) * x0 + _coef(pc2, t) * x
+    elif mean_type == "previous_x":
+        mean = out
+        x0 = _coef(1.0 / pc1, t) * out - _coef(pc2 / pc1, t) * x
+    else:
+        raise NameError(f"Name {mean_type} is not defined.")
+    if var_type == "learned_range":
+        frac = (v + 1.0) / 2.0
+        logvar = frac * _coef(tb.log_betas, t) + (1 - frac) * _coef(tb.posterior_log_variance_clipped, t)
+    elif var_type in ("fixed_small", "fixed_large"):
+        with np.errstate(divide="ignore"):                  # fixed_small: log 0 at index 0, where no noise is added
+            table = np.log(tb.posterior_variance if var_type == "fixed_small"
+                           else np.append(tb.posterior_variance[1], tb.betas[1:]))
+        logvar = torch.full_like(x, _coef(table, t))
+    elif var_type == "learned":
+        logvar = v
+    else:
+        raise NameError(f"Name {var_type} is not defined.")
     return {"mean": mean, "log_variance": logvar, "variance": torch.exp(logvar), "pred_xstart": x0}
 
 
@@ -299,7 +323,8 @@ def is_freeze_phi(pattern: Optional[dict], idx: int, T: int) -> bool:
 
 def p_sample_loop(model: Callable, tb: Tables, x_T: torch.Tensor, y: torch.Tensor,
                   guidance: OsmosisGuidance, pattern: Optional[dict],
-                  noises: List[torch.Tensor], trace: Optional[list] = None):
+                  noises: List[torch.Tensor], trace: Optional[list] = None, mean_type: str = "epsilon",
+                  var_type: str = "learned_range"):
     """gaussian_diffusion.py:179-340 (osmosis branch, alternate_len=1, guidance always on).
     `model(x, t_mapped_float_tensor)` -> [B,8,H,W].  `noises[k]` = the randn_like(img) drawn at
     loop iteration k (the reference's unused randn_like(measurement) draw is not modelled here;
@@ -310,7 +335,7 @@ def p_sample_loop(model: Callable, tb: Tables, x_T: torch.Tensor, y: torch.Tenso
     for k, idx in enumerate(range(T - 1, -1, -1)):
         img = img.detach().requires_grad_(True)
         t_model = torch.tensor([tb.timestep_map[idx]] * img.shape[0])
-        out = p_mean_variance(tb, model(img, t_model), img, idx)
+        out = p_mean_variance(tb, model(img, t_model), img, idx, mean_type, var_type)
         freeze = is_freeze_phi(pattern, idx, T)
         x_t, loss, variables, grad = guidance.conditioning(img, out["mean"], out["pred_xstart"], y, freeze)
         x0 = out["pred_xstart"].detach()

@@ -18,6 +18,8 @@ Sections (SURVEY.md section 8c recipe):
                   exact noise tensors the reference drew, per-step traces
   prior_inverse.npz   unconditional RGBD-prior sampler (osmosis_utils/diffusion.py)
   loop_optimizers.npz (round 6) the guided loop with each torch optimizer of utils.get_optimizer on phi: losses, phi, final image
+  loop_processors.npz (round 6) the Osmosis loop and the rgb-guidance chains with the previous_x / start_x mean processors and the
+                      fixed_small / fixed_large / learned variance processors
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
   unet_variants.npz   (round 5) tiny UNets with conv up / down-sampling layers, additive conditioning, class conditioning
@@ -206,17 +208,19 @@ PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local
                n_iter=20, start_guidance=1, stop_guidance=0)
 
 
-def _loop_trace(m, spec):
+def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=0.0):
     """10-step guided p_sample_loop of the reference (model m) for one operator spec; every randn_like draw logged."""
     operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
     noiser = get_noise(name="clean")
     cond = get_conditioning_method("osmosis", operator, noiser, **spec["cond"], **PATTERN, **spec["aux"])
     sampler = R_gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10),
                                        betas=R_gd.get_named_beta_schedule("linear", 1000),
-                                       model_mean_type="epsilon", model_var_type="learned_range",
+                                       model_mean_type=mean_type, model_var_type=var_type,
                                        dynamic_threshold=False, clip_denoised=False,
                                        rescale_timesteps=False)
     x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(0))
+    if perturb:                                            # sensitivity probes (gen_processors)
+        x_T = x_T + perturb * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(77))
     y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8
 
     trace = []
@@ -501,6 +505,49 @@ def gen_prior():
                         cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
 
 
+def _ps_chain(m, name, mean_type="epsilon", var_type="learned_range", perturb=0.0, x_ins=None):
+    """One rgb-guidance chain of the reference: sampler `name` ('ddpm' | 'ddim'), the given processors; every randn_like logged.
+    perturb: amplitude of a seeded N(0,1) perturbation of x_T (sensitivity probes); x_ins: list receiving every step's input."""
+    operator = get_operator(name="rgb_guidance", device=torch.device("cpu"), batch_size=1)
+    noiser = get_noise(name="gaussian", sigma=0.05)
+    cond = get_conditioning_method("ps", operator, noiser, scale="0.6,0.5,0.4,0.0")
+    sampler = R_gd.get_sampler(name)(use_timesteps=range(0, 100, 10),
+                                     betas=R_gd.get_named_beta_schedule("linear", 1000),
+                                     model_mean_type=mean_type, model_var_type=var_type,
+                                     dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
+    x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(2))
+    if perturb:
+        x_T = x_T + perturb * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(77))
+    y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(9)) * 1.6 - 0.8
+    draws, losses = [], []
+    orig = torch.randn_like
+
+    def logged(t, **kw):
+        r = orig(t, **kw)
+        draws.append(r.clone())
+        return r
+
+    orig_cond = cond.conditioning
+
+    def traced(**kw):
+        if x_ins is not None:
+            x_ins.append(kw["x_prev"].detach().clone())
+        ret = orig_cond(**kw)
+        losses.append(float(ret[1]))
+        return ret
+
+    torch.manual_seed(0)
+    torch.randn_like = logged
+    try:
+        with np.errstate(divide="ignore"):                # fixed_small takes log(0) at index 0 (unused there)
+            img = sampler.p_sample_loop(model=m, x_start=x_T.clone().requires_grad_(), measurement=y,
+                                        measurement_cond_fn=traced, record=False, save_root=None,
+                                        pretrain_model="osmosis", rgb_guidance=True, sample_pattern=PATTERN)
+    finally:
+        torch.randn_like = orig
+    return x_T, y, img, losses, draws
+
+
 def gen_ps():
     """rgb-guidance path: `ps` conditioning (condition_methods.py:234-251) + `rgb_guidance` operator
     (measurements.py:80-96) + gaussian noiser, through DDPM.p_sample / DDIM.p_sample (gaussian_diffusion.py:494-535),
@@ -509,38 +556,7 @@ def gen_ps():
     m, cfg, sd = tiny_model()
     out = {}
     for name in ("ddpm", "ddim"):
-        operator = get_operator(name="rgb_guidance", device=torch.device("cpu"), batch_size=1)
-        noiser = get_noise(name="gaussian", sigma=0.05)
-        cond = get_conditioning_method("ps", operator, noiser, scale="0.6,0.5,0.4,0.0")
-        sampler = R_gd.get_sampler(name)(use_timesteps=range(0, 100, 10),
-                                         betas=R_gd.get_named_beta_schedule("linear", 1000),
-                                         model_mean_type="epsilon", model_var_type="learned_range",
-                                         dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
-        x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(2))
-        y = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(9)) * 1.6 - 0.8
-        draws, losses = [], []
-        orig = torch.randn_like
-
-        def logged(t, **kw):
-            r = orig(t, **kw)
-            draws.append(r.clone())
-            return r
-
-        orig_cond = cond.conditioning
-
-        def traced(**kw):
-            ret = orig_cond(**kw)
-            losses.append(float(ret[1]))
-            return ret
-
-        torch.manual_seed(0)
-        torch.randn_like = logged
-        try:
-            img = sampler.p_sample_loop(model=m, x_start=x_T.clone().requires_grad_(), measurement=y,
-                                        measurement_cond_fn=traced, record=False, save_root=None,
-                                        pretrain_model="osmosis", rgb_guidance=True, sample_pattern=PATTERN)
-        finally:
-            torch.randn_like = orig
+        x_T, y, img, losses, draws = _ps_chain(m, name)
         out[f"{name}.x_T"], out[f"{name}.y"], out[f"{name}.final_img"] = npy(x_T), npy(y), npy(img)
         out[f"{name}.loss"] = np.array(losses, dtype=np.float32)
         out[f"{name}.draw_is_x"] = np.array([d.shape[1] == 4 for d in draws])
@@ -548,6 +564,69 @@ def gen_ps():
         out[f"{name}.draws_y"] = np.stack([npy(d) for d in draws if d.shape[1] == 3])
         print(name, "draws", len(draws), "final loss", losses[-1])
     np.savez_compressed(os.path.join(OUT, "loop_ps.npz"), **out)
+
+
+# (mean processor, variance processor) pairs that together cover every registered class other than the shipped pair
+PROCESSOR_PAIRS = [("start_x", "fixed_small"), ("epsilon", "fixed_large"), ("epsilon", "learned"), ("start_x", "learned")]
+PS_PROCESSOR_CHAINS = [("ddpm", "start_x", "fixed_large"), ("ddpm", "epsilon", "fixed_small"), ("ddpm", "start_x", "learned"),
+                       ("ddim", "previous_x", "fixed_small"), ("ddim", "start_x", "learned_range")]
+
+
+def gen_processors():
+    """(round 6) The REAL reference's chains with the mean / variance processors no shipped config names
+    (posterior_mean_variance.py:53-101 previous_x / start_x, :171-222 fixed_small / fixed_large / learned):
+    the 10-step guided Osmosis loop (revised underwater operator; x_T, y, noise = those of
+    loop_underwater_physical_revised.npz: same seeds, same draw order) and the rgb-guidance chains through DDPM.p_sample /
+    DDIM.p_sample (x_T, y, draws = those of loop_ps.npz).  Per chain: per-step losses and pred_xstart of the first / last step,
+    final image, final pred_xstart, final phi; `<tag>.drift_1e-6` = how far the REFERENCE's own final image moves when x_T is
+    perturbed by 1e-6 N(0,1) (start_x feeds the network its own output, previous_x divides by posterior_mean_coef1: both amplify);
+    chains whose drift exceeds the 1e-3 bar also carry every step's input (`<tag>.x_in`) for teacher-forced comparison.
+    `previous_x` returns the network's split output AS the mean (:68-72), and both the Osmosis branch (gaussian_diffusion.py:268
+    `img += ...`, condition_methods.py:223 `x_t -= ...`) and DDPM.p_sample (:499 `sample += ...`) then modify that view in place:
+    autograd raises RuntimeError there.  Only DDIM.p_sample (a fresh tensor, :524-530) runs with it; the generator asserts the
+    raises and records `previous_x.raises` so that the tests can hold the build to the same behaviour."""
+    m, cfg, sd = tiny_model()
+    base = dict(np.load(os.path.join(OUT, "loop_underwater_physical_revised.npz")))
+    ps = dict(np.load(os.path.join(OUT, "loop_ps.npz")))
+    out = {}
+    for mt, vt in PROCESSOR_PAIRS:
+        with np.errstate(divide="ignore"):
+            tr, loss, variables = _loop_trace(m, OPERATORS["underwater_physical_revised"], mt, vt)
+        assert np.array_equal(tr["noise"], base["noise"]) and np.array_equal(tr["x_T"], base["x_T"]) and np.array_equal(tr["y"], base["y"])
+        tag = f"osmosis.{mt}.{vt}"
+        with np.errstate(divide="ignore"):
+            tr2, _, _ = _loop_trace(m, OPERATORS["underwater_physical_revised"], mt, vt, perturb=1e-6)
+        out[f"{tag}.drift_1e-6"] = np.array(np.abs(tr2["final_img"] - tr["final_img"]).max())
+        if out[f"{tag}.drift_1e-6"] > 1e-3:
+            out[f"{tag}.x_in"] = tr["trace.x_in"]
+        out[f"{tag}.final_img"], out[f"{tag}.final_x0"], out[f"{tag}.loss"] = tr["final_img"], tr["final_x0"], tr["trace.loss"]
+        out[f"{tag}.x0_first"], out[f"{tag}.mean_first"] = tr["trace.x0"][0], tr["trace.mean"][0]
+        for k in ("phi_a", "phi_b", "phi_inf"):
+            out[f"{tag}.{k}"] = tr[f"final.{k}"]
+        print(tag, "final loss", loss, "max |img|", float(np.abs(tr["final_img"]).max()), "drift", float(out[f"{tag}.drift_1e-6"]))
+    raised = []
+    for what, run in (("osmosis", lambda: _loop_trace(m, OPERATORS["underwater_physical_revised"], "previous_x", "learned_range")),
+                      ("ps.ddpm", lambda: _ps_chain(m, "ddpm", "previous_x", "learned_range"))):
+        try:
+            run()
+        except RuntimeError as e:
+            assert "modified inplace" in str(e), e
+            raised.append(what)
+    assert raised == ["osmosis", "ps.ddpm"], raised
+    out["previous_x.raises"] = np.array(raised)
+    for name, mt, vt in PS_PROCESSOR_CHAINS:
+        x_ins = []
+        x_T, y, img, losses, draws = _ps_chain(m, name, mt, vt, x_ins=x_ins)
+        img2 = _ps_chain(m, name, mt, vt, perturb=1e-6)[2]
+        assert np.array_equal(npy(x_T), ps[f"{name}.x_T"]) and np.array_equal(npy(y), ps[f"{name}.y"])
+        assert np.array_equal(np.stack([npy(d) for d in draws if d.shape[1] == 4]), ps[f"{name}.draws_x"])
+        tag = f"ps.{name}.{mt}.{vt}"
+        out[f"{tag}.final_img"], out[f"{tag}.loss"] = npy(img), np.array(losses, dtype=np.float32)
+        out[f"{tag}.drift_1e-6"] = np.array(float((img2 - img).abs().max()))
+        if out[f"{tag}.drift_1e-6"] > 1e-3:
+            out[f"{tag}.x_in"] = np.stack([npy(x) for x in x_ins])
+        print(tag, "final loss", losses[-1], "max |img|", float(img.abs().max()), "drift", float(out[f"{tag}.drift_1e-6"]))
+    np.savez_compressed(os.path.join(OUT, "loop_processors.npz"), **out)
 
 
 def gen_postprocess():
@@ -704,6 +783,7 @@ if __name__ == "__main__":
     gen_configs()
     gen_ps()
     gen_optimizers()
+    gen_processors()
     gen_fp16()
     gen_full_unet()
     gen_full_step()

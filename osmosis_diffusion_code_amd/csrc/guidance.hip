@@ -300,6 +300,11 @@ __global__ __launch_bounds__(256) void phys_grad_kernel(osm_phys_desc ds, const 
 }
 
 // ---------------------------------------------------------------- posterior
+// MK: mean processor (0 epsilon / start_x / previous_x through ONE form, x0 = c0 x - c1 out: the row holds
+//     c0 = d x0 / d x and c1 = -d x0 / d out, which is also what posterior_bwd_kernel and the update kernels read;
+//     1 start_x, x0 = out exactly; 2 previous_x, mean = out exactly).  VK: variance processor (0 learned_range,
+//     1 fixed_small / fixed_large: the row's value, 2 learned: the network's second half).
+template <int MK, int VK>
 __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ mo, const float* __restrict__ x,
                                                          const float* __restrict__ coef, float* __restrict__ x0,
                                                          float* __restrict__ mean, float* __restrict__ logvar,
@@ -311,13 +316,21 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     const long long b = i / (4LL * HW);
     const long long rem = i - b * 4LL * HW;
     const float eps = mo[b * 8LL * HW + rem];
-    const float v = mo[b * 8LL * HW + 4LL * HW + rem];
     const float xv = x[i];
-    const float xs = c0 * xv - c1 * eps;
+    const float xs = MK == 1 ? eps : c0 * xv - c1 * eps;
     x0[i] = xs;
-    mean[i] = c2 * xs + c3 * xv;
-    const float frac = (v + 1.0f) / 2.0f;
-    logvar[i] = frac * mxl + (1.0f - frac) * mn;
+    mean[i] = MK == 2 ? eps : c2 * xs + c3 * xv;
+    if (VK == 1) {
+      logvar[i] = mn;
+    } else {
+      const float v = mo[b * 8LL * HW + 4LL * HW + rem];
+      if (VK == 2) {
+        logvar[i] = v;
+      } else {
+        const float frac = (v + 1.0f) / 2.0f;
+        logvar[i] = frac * mxl + (1.0f - frac) * mn;
+      }
+    }
   }
 }
 
@@ -479,9 +492,11 @@ __global__ __launch_bounds__(256) void guide_update_rng_kernel(const float* __re
 }
 
 // DDIM step + guidance (gaussian_diffusion.py:505-535, condition_methods.py:247-251), in the reference's operation order:
-//   eps = (c0 x - x0) / c1 ; sigma = eta sqrt((1 - abp) / (1 - ab)) sqrt(1 - ab / abp) ;
-//   x_next = x0 sqrt(abp) + sqrt(1 - abp - sigma^2) eps + [t != 0] sigma noise - scale[c] clamp(grad)
-// coef = the posterior row (c0 = sqrt_recip_ac, c1 = sqrt_recipm1_ac), dcoef = {alpha_bar, alpha_bar_prev, eta, noise_on}.
+//   eps = (r0 x - x0) / r1 ; sigma = eta sqrt((1 - abp) / (1 - ab)) sqrt(1 - ab / abp) ;
+//   x_next = x0 sqrt(abp) + sqrt(1 - abp - sigma^2) eps + [t != 0] sigma noise - scale[c] clamp(grad) ; grad = c0 g + dx_unet
+// coef = the posterior row (c0 = d x0 / d x of the mean processor), dcoef = {alpha_bar, alpha_bar_prev, eta, noise_on,
+// r0 = sqrt_recip_ac, r1 = sqrt_recipm1_ac}: predict_eps_from_x_start (:533-536) uses the SAMPLER's tables whatever the mean
+// processor is (for `epsilon` r0 = c0 and r1 = c1).
 // x_next may alias x (each element is read, then written, by one thread).
 __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x0, const float* x, const float* __restrict__ g,
                                                            const float* __restrict__ dxu, const float* __restrict__ noise,
@@ -489,14 +504,14 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
                                                            const float* __restrict__ scale4, float clip, float* x_next,
                                                            float* __restrict__ grad_out, int B, int HW) {
   const long long total = (long long)B * 4 * HW;
-  const float c0 = coef[0], c1 = coef[1];
-  const float ab = dcoef[0], abp = dcoef[1], eta = dcoef[2], noise_on = dcoef[3];
+  const float c0 = coef[0];
+  const float ab = dcoef[0], abp = dcoef[1], eta = dcoef[2], noise_on = dcoef[3], r0 = dcoef[4], r1 = dcoef[5];
   const float sigma = eta * sqrtf((1.0f - abp) / (1.0f - ab)) * sqrtf(1.0f - ab / abp);
   const float sa = sqrtf(abp), sb = sqrtf(1.0f - abp - sigma * sigma);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i / HW) % 4);
     const float xs = x0[i];
-    const float eps = (c0 * x[i] - xs) / c1;
+    const float eps = (r0 * x[i] - xs) / r1;
     float xt = xs * sa + sb * eps;
     if (noise_on != 0.f && noise) xt += sigma * noise[i];
     float grad = 0.f;
@@ -597,12 +612,33 @@ extern "C" int osm_phys_optimize(const osm_phys_desc* d, const float* x0, const 
   return OSM_OK;
 }
 
+extern "C" int osm_posterior_typed(const float* model_out, const float* x, const float* coef, int mean_kind, int var_kind,
+                                   float* x0, float* mean, float* logvar, int B, int HW, void* stream) {
+  OSM_REQUIRE(model_out && x && coef && x0 && mean && logvar && B > 0 && HW > 0, "osm_posterior_typed: bad argument");
+  OSM_REQUIRE(mean_kind >= 0 && mean_kind <= 2, "osm_posterior_typed: mean_kind must be 0 (epsilon), 1 (start_x) or 2 (previous_x)");
+  OSM_REQUIRE(var_kind >= 0 && var_kind <= 2, "osm_posterior_typed: var_kind must be 0 (learned_range), 1 (fixed) or 2 (learned)");
+  const dim3 grid(grid_for((long long)B * 4 * HW)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define OSM_POST(MK, VK) \
+  hipLaunchKernelGGL((posterior_kernel<MK, VK>), grid, block, 0, st, model_out, x, coef, x0, mean, logvar, B, HW)
+  switch (mean_kind * 3 + var_kind) {
+    case 0: OSM_POST(0, 0); break;
+    case 1: OSM_POST(0, 1); break;
+    case 2: OSM_POST(0, 2); break;
+    case 3: OSM_POST(1, 0); break;
+    case 4: OSM_POST(1, 1); break;
+    case 5: OSM_POST(1, 2); break;
+    case 6: OSM_POST(2, 0); break;
+    case 7: OSM_POST(2, 1); break;
+    default: OSM_POST(2, 2); break;
+  }
+#undef OSM_POST
+  return osm::check_launch("posterior_kernel");
+}
+
 extern "C" int osm_posterior(const float* model_out, const float* x, const float* coef, float* x0, float* mean,
                              float* logvar, int B, int HW, void* stream) {
-  OSM_REQUIRE(model_out && x && coef && x0 && mean && logvar && B > 0 && HW > 0, "osm_posterior: bad argument");
-  hipLaunchKernelGGL(posterior_kernel, dim3(grid_for((long long)B * 4 * HW)), dim3(256), 0, (hipStream_t)stream,
-                     model_out, x, coef, x0, mean, logvar, B, HW);
-  return osm::check_launch("posterior_kernel");
+  return osm_posterior_typed(model_out, x, coef, 0, 0, x0, mean, logvar, B, HW, stream);
 }
 
 extern "C" int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream) {

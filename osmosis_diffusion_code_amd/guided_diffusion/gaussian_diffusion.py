@@ -193,7 +193,9 @@ class GaussianDiffusion:
         if sample_pattern is not None and sample_pattern.get("pattern") not in (None, "original"):
             if sample_pattern.get("local_M", 1) != 1:
                 return None
-        if rgb_guidance or pretrain_model != "osmosis":
+        if pretrain_model != "osmosis" and not rgb_guidance:
+            return None       # the reference's mean-only step (:234-236: p_mean_variance, sample = mean, no p_sample): `_generic_loop`
+        if rgb_guidance:
             # the 'ps' step: only the two registered step rules, un-overridden, and a chain that is guided at every index (the
             # reference calls the conditioner at every step of this branch: an unguided index raises in its autograd.grad)
             if type(cond) is not PosteriorSampling or not cond.hip_ok():
@@ -212,7 +214,8 @@ class GaussianDiffusion:
         return cond
 
     def coef_table(self) -> np.ndarray:
-        """[T][8] fp32: c0,c1,c2,c3 (mean processor), min_log,max_log (variance), noise_on, t_model."""
+        """[T][8] fp32: c0,c1,c2,c3 (mean processor's `kernel_coefs`: c0 = d x0/d x, c1 = -d x0/d out, posterior_mean_coef1 / 2),
+        the variance processor's two (learned_range: min_log, max_log; fixed_*: log variance, -), noise_on, t_model."""
         T = self.num_timesteps
         tab = np.zeros((T, 8), dtype=np.float32)
         for i in range(T):
@@ -224,13 +227,16 @@ class GaussianDiffusion:
 
     def ddim_table(self, eta: float = 0.0) -> np.ndarray:
         """[T][8] fp32 rows of `DDIM.p_sample` (gaussian_diffusion.py:505-528) for osm_ddim_update:
-        alpha_bar, alpha_bar_prev, eta, noise_on, -, -, -, t_model."""
+        alpha_bar, alpha_bar_prev, eta, noise_on, sqrt_recip_ac, sqrt_recipm1_ac (predict_eps_from_x_start :533-536: the sampler's
+        own tables, whatever the mean processor), -, t_model."""
         T = self.num_timesteps
         tab = np.zeros((T, 8), dtype=np.float32)
         tab[:, 0] = self.alphas_cumprod
         tab[:, 1] = self.alphas_cumprod_prev
         tab[:, 2] = eta
         tab[1:, 3] = 1.0
+        tab[:, 4] = self.sqrt_recip_alphas_cumprod
+        tab[:, 5] = self.sqrt_recipm1_alphas_cumprod
         tab[:, 7] = [self._model_timesteps(i) for i in range(T)]
         return tab
 
@@ -361,7 +367,8 @@ class GaussianDiffusion:
                 if not single:
                     ce.x_in.copy_(x_state[c0:c1])
                 ce.run_forward()
-                ops.posterior(ce.out, ce.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW)
+                ops.posterior(ce.out, ce.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW,
+                              self.mean_processor.kernel_kind, self.var_processor.kernel_kind)
                 if trace is not None:
                     model_out[c0:c1].copy_(ce.out)
                 gg = dxu = grad_out = None
@@ -437,6 +444,14 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root,
                       pretrain_model=None, image_idx=None, record_every=150, rgb_guidance=False,
                       sample_pattern=None, **kwargs):
+        from .posterior_mean_variance import PreviousXMeanProcessor
+        if isinstance(self.mean_processor, PreviousXMeanProcessor) and not (
+                rgb_guidance and getattr(type(self), "p_sample", None) is DDIM.p_sample):
+            # Error behaviour of the reference: `previous_x` hands the network's split output on AS the mean
+            # (posterior_mean_variance.py:68-72), and every step rule except DDIM.p_sample then adds to it in place
+            # (gaussian_diffusion.py:268 / :499, condition_methods.py:223 / :249) -- autograd refuses that on a multi-output view.
+            raise RuntimeError("Output 0 of SplitBackward0 is a view and is being modified inplace: the 'previous_x' mean processor "
+                               "only runs with the DDIM sampler on the rgb-guidance branch (as in the reference)")
         cond = self._fast_path_ok(model, measurement_cond_fn, pretrain_model, rgb_guidance, sample_pattern)
         if cond is not None:
             return self._fused_loop(model, cond, x_start, measurement, sample_pattern, kwargs, record=record,

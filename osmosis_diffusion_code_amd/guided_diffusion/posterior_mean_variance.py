@@ -2,12 +2,12 @@
 guided_diffusion/posterior_mean_variance.py (register/get_mean_processor :15-28,
 register/get_var_processor :146-159).
 
-The pair every shipped config uses -- 'epsilon' (:104-136) + 'learned_range' (:227-258) -- is what
-the fused osm_posterior kernel computes; the sampler asks those two processors for their float64
-table rows (`kernel_coefs`) and never calls the tensor methods on the hot path.  The tensor methods
-are kept (plain torch elementwise ops on whatever device the tensors live on) so third-party code
-written against the reference API keeps working; the remaining registry entries exist only in
-that form.  Tables are float64 and cast to fp32 after indexing, as in the reference (:265-269).
+Every registered pair runs in the fused osm_posterior_typed kernel (the pair every shipped config uses -- 'epsilon'
+(:104-136) + 'learned_range' (:227-258) -- is kinds (0, 0) = osm_posterior): the sampler asks the two processors for their
+`kernel_kind` and their float64 table rows (`kernel_coefs`) and never calls the tensor methods on the hot path.  The tensor
+methods are kept (plain torch elementwise ops on whatever device the tensors live on) so third-party code written against the
+reference API -- and `_generic_loop` -- keeps working.  Tables are float64 and cast to fp32 after indexing, as in the
+reference (:265-269).
 """
 from abc import ABC, abstractmethod
 
@@ -67,6 +67,7 @@ def _posterior_tables(betas):
 
 class MeanProcessor(ABC):
     hip_kernel = None      # name of the fused kernel family that implements this processor, if any
+    kernel_kind = 0        # osm_posterior_typed's mean_kind
 
     @abstractmethod
     def __init__(self, betas, dynamic_threshold, clip_denoised):
@@ -95,8 +96,21 @@ class MeanProcessor(ABC):
 
 @register_mean_processor(name="previous_x")
 class PreviousXMeanProcessor(MeanProcessor):
+    """The network predicts the posterior mean; x_0 is solved from it (reference :53-72).  The reference returns the network's
+    split output AS the mean, and every step rule that adds to the mean in place (the Osmosis branch gaussian_diffusion.py:268,
+    condition_methods.py:223; DDPM.p_sample :499) raises autograd's "view ... modified inplace" there: only DDIM.p_sample runs
+    with it (`GaussianDiffusion.p_sample_loop` raises the same RuntimeError for the other two)."""
+    hip_kernel = "osm_posterior"
+    kernel_kind = 2
+
     def __init__(self, betas, dynamic_threshold, clip_denoised):
         super().__init__(betas, dynamic_threshold, clip_denoised)
+
+    def kernel_coefs(self, t: int):
+        """Row of osm_posterior_typed: c0 = d x0/d x = -coef2/coef1, c1 = -d x0/d out = -1/coef1 (fp32-rounded like
+        extract_and_expand's .float(), then negated: exact), c2 / c3 unused (mean = out)."""
+        return (-np.float32((self.posterior_mean_coef2 / self.posterior_mean_coef1)[t]), -np.float32((1.0 / self.posterior_mean_coef1)[t]),
+                np.float32(self.posterior_mean_coef1[t]), np.float32(self.posterior_mean_coef2[t]))
 
     def predict_xstart(self, x_t, t, x_prev):
         c1 = extract_and_expand(1.0 / self.posterior_mean_coef1, t, x_t)
@@ -109,8 +123,15 @@ class PreviousXMeanProcessor(MeanProcessor):
 
 @register_mean_processor(name="start_x")
 class StartXMeanProcessor(MeanProcessor):
+    hip_kernel = "osm_posterior"
+    kernel_kind = 1
+
     def __init__(self, betas, dynamic_threshold, clip_denoised):
         super().__init__(betas, dynamic_threshold, clip_denoised)
+
+    def kernel_coefs(self, t: int):
+        """Row of osm_posterior_typed: x0 = out, so d x0/d x = 0 and -d x0/d out = -1; c2 / c3 = the posterior mean's."""
+        return (np.float32(0.0), np.float32(-1.0), np.float32(self.posterior_mean_coef1[t]), np.float32(self.posterior_mean_coef2[t]))
 
     def get_mean_and_xstart(self, x, t, model_output):
         x0 = self.process_xstart(model_output)
@@ -143,6 +164,7 @@ class EpsilonXMeanProcessor(MeanProcessor):
 
 class VarianceProcessor(ABC):
     hip_kernel = None
+    kernel_kind = 0        # osm_posterior_typed's var_kind
 
     @abstractmethod
     def __init__(self, betas):
@@ -155,8 +177,16 @@ class VarianceProcessor(ABC):
 
 @register_var_processor(name="fixed_small")
 class FixedSmallVarianceProcessor(VarianceProcessor):
+    hip_kernel = "osm_posterior"
+    kernel_kind = 1
+
     def __init__(self, betas):
         self.posterior_variance = _posterior_tables(betas)[4]
+
+    def kernel_coefs(self, t: int):
+        """(log variance of the step, unused): log 0 = -inf at index 0, as in the reference (:182), where no noise is added."""
+        with np.errstate(divide="ignore"):
+            return np.float32(np.log(self.posterior_variance)[t]), np.float32(0.0)
 
     def get_variance(self, x, t):
         v = self.posterior_variance
@@ -165,9 +195,15 @@ class FixedSmallVarianceProcessor(VarianceProcessor):
 
 @register_var_processor(name="fixed_large")
 class FixedLargeVarianceProcessor(VarianceProcessor):
+    hip_kernel = "osm_posterior"
+    kernel_kind = 1
+
     def __init__(self, betas):
         self.betas = betas
         self.posterior_variance = _posterior_tables(betas)[4]
+
+    def kernel_coefs(self, t: int):
+        return np.float32(np.log(np.append(self.posterior_variance[1], self.betas[1:]))[t]), np.float32(0.0)
 
     def get_variance(self, x, t):
         v = np.append(self.posterior_variance[1], self.betas[1:])
@@ -176,8 +212,14 @@ class FixedLargeVarianceProcessor(VarianceProcessor):
 
 @register_var_processor(name="learned")
 class LearnedVarianceProcessor(VarianceProcessor):
+    hip_kernel = "osm_posterior"
+    kernel_kind = 2
+
     def __init__(self, betas):
         pass
+
+    def kernel_coefs(self, t: int):
+        return np.float32(0.0), np.float32(0.0)
 
     def get_variance(self, x, t):
         return torch.exp(x), x

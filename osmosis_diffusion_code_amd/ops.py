@@ -370,9 +370,11 @@ def convert(x: Mat, y: Mat):
 
 
 # ----------------------------------------------------------------------------- sampler step
-def posterior(model_out, x, coef, x0, mean, logvar, B, HW):
-    call("osm_posterior", ptr(model_out), ptr(x), ptr(coef), ptr(x0), ptr(mean), ptr(logvar), B, HW, _s(),
-         keep=(model_out, x, coef, x0, mean, logvar))
+def posterior(model_out, x, coef, x0, mean, logvar, B, HW, mean_kind=0, var_kind=0):
+    """mean_kind / var_kind: `MeanProcessor.kernel_kind` / `VarianceProcessor.kernel_kind` (include/osmosis_hip.h osm_posterior_typed);
+    (0, 0) = the epsilon / learned_range pair of every shipped config."""
+    call("osm_posterior_typed", ptr(model_out), ptr(x), ptr(coef), int(mean_kind), int(var_kind), ptr(x0), ptr(mean), ptr(logvar),
+         B, HW, _s(), keep=(model_out, x, coef, x0, mean, logvar))
 
 
 def phys_nblk(HW):

@@ -9,7 +9,7 @@ registered for the "cuda" device type only, which is HIP on ROCm).
                                                            w.r.t. x (condition_methods.py:188-191 back-propagates through it)
     osmosis::unet_bwd_data(grad_out, engine) -> dx          the recorded data-gradient plan of the same engine
     osmosis::posterior(model_out, x, coef) -> (pred_xstart, mean, log_variance)     gaussian_diffusion.py:349-376 +
-                                                           posterior_mean_variance.py (epsilon mean, learned-range variance)
+                                                           posterior_mean_variance.py (every registered processor pair)
     osmosis::posterior_bwd(g, coef) -> d_model_out         d(pred_xstart)/d(model_out)^T g  (the chain rule into the UNet)
     osmosis::guide_update(mean, log_variance, g, dx_unet, noise, coef, scale4, clip) -> (x_next, grad)
                                                            condition_methods.py:186-221 update rule + the noise add of :262-271
@@ -101,16 +101,18 @@ def _chw(x):
 
 
 @torch.library.custom_op("osmosis::posterior", mutates_args=(), device_types="cuda")
-def posterior(model_out: torch.Tensor, x: torch.Tensor, coef: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """coef: the 8 fp32 coefficients of the step (GaussianDiffusion.coef_table row, fetched by osm_fetch_coefs)."""
+def posterior(model_out: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, mean_kind: int = 0,
+              var_kind: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """coef: the 8 fp32 coefficients of the step (GaussianDiffusion.coef_table row, fetched by osm_fetch_coefs); mean_kind / var_kind:
+    the processors' `kernel_kind` (osm_posterior_typed; 0, 0 = epsilon / learned_range)."""
     B, HW = _chw(x)
     x0, mean, logvar = (torch.empty_like(x) for _ in range(3))
-    ops.posterior(model_out.contiguous(), x, coef, x0, mean, logvar, B, HW)
+    ops.posterior(model_out.contiguous(), x, coef, x0, mean, logvar, B, HW, mean_kind, var_kind)
     return x0, mean, logvar
 
 
 @posterior.register_fake
-def _posterior_fake(model_out, x, coef):
+def _posterior_fake(model_out, x, coef, mean_kind=0, var_kind=0):
     return torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
 
 

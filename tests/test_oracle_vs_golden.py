@@ -167,6 +167,31 @@ def test_guided_loop_with_a_torch_optimizer_on_phi(optimizer):
     assert float((variables["phi_inf"] - T(g[f"{optimizer}.phi_inf"][0])).abs().max()) > 5e-3      # phi really moved
 
 
+@pytest.mark.parametrize("mean_type,var_type", [("start_x", "fixed_small"), ("epsilon", "fixed_large"), ("epsilon", "learned"),
+                                                ("start_x", "learned")])
+def test_guided_loop_with_the_other_processors(mean_type, var_type):
+    """Round 6: the mean / variance processors no shipped config names (posterior_mean_variance.py:53-101, :171-222) in the oracle's
+    `p_mean_variance`, against the REAL reference's guided loop built with them (loop_processors.npz; x_T, y and the noise are those
+    of loop_underwater_physical_revised.npz)."""
+    g, base = load("loop_processors.npz"), load("loop_underwater_physical_revised.npz")
+    cfg, sd = tiny()
+    okw, ckw = OPS["underwater_physical_revised"]
+    guide = D.OsmosisGuidance(D.PhysOperator("underwater_physical_revised", batch_size=1, **okw), n_iter=20, **ckw)
+    tb = D.Tables(D.named_beta_schedule("linear", 1000), range(0, 100, 10))
+    trace = []
+    img, variables, loss, x0 = D.p_sample_loop(lambda x, t: U.unet_forward(sd, cfg, x, t), tb, T(base["x_T"]), T(base["y"]), guide,
+                                               PATTERN, [T(n) for n in base["noise"]], trace, mean_type=mean_type, var_type=var_type)
+    tag = f"osmosis.{mean_type}.{var_type}"
+    scale = max(1.0, float(np.abs(g[f"{tag}.final_img"]).max()))
+    assert torch.allclose(trace[0]["x0"], T(g[f"{tag}.x0_first"]), atol=5e-6)
+    for k, rec in enumerate(trace):
+        assert np.allclose(rec["loss"], g[f"{tag}.loss"][k], rtol=2e-5), (k, "loss", rec["loss"], g[f"{tag}.loss"][k])
+    assert torch.allclose(img, T(g[f"{tag}.final_img"]), atol=5e-5 * scale)
+    assert torch.allclose(x0, T(g[f"{tag}.final_x0"]), atol=5e-5 * scale)
+    for n, v in variables.items():
+        assert torch.allclose(v, T(g[f"{tag}.{n}"]), atol=1e-6), n
+
+
 def test_fp16_reference_fixture_is_consistent():
     """tests/golden/fp16_reference.npz (round 4: the real reference with convert_to_fp16() applied): its fp32 half is the same
     network on the same inputs -- the oracle reproduces it -- and its fp16 half differs from it by the half-precision amount."""

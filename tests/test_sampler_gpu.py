@@ -310,6 +310,139 @@ def test_rgb_guidance_ps_chain_fused_matches_reference(pkg, name, monkeypatch):
     assert err < 2e-5
 
 
+def _no_generic(monkeypatch, sampler):
+    def no_generic(*a, **k):
+        raise AssertionError("the chain fell back to the generic loop")
+    monkeypatch.setattr(type(sampler), "_generic_loop", no_generic)
+
+
+def _free_running_bar(drift):
+    """Bar on a free-running 10-step chain from the REFERENCE's own sensitivity (`<tag>.drift_1e-6` of loop_processors.npz: how far its
+    final image moves when x_T is perturbed by 1e-6 N(0,1)): well-conditioned chains are held tight, mildly amplifying ones to the
+    north-star 1e-3, and chains the reference itself cannot reproduce to 1e-3 are compared teacher-forced instead (None)."""
+    if drift <= 1e-4:
+        return max(2e-5, 10.0 * drift)
+    return 1e-3 if drift <= 1e-3 else None
+
+
+@pytest.mark.parametrize("mean_type,var_type", [("start_x", "fixed_small"), ("epsilon", "fixed_large"), ("epsilon", "learned"),
+                                                ("start_x", "learned")])
+def test_fused_loop_with_the_other_processors_matches_the_reference(pkg, monkeypatch, mean_type, var_type):
+    """Round 6 (VERDICT r05 missing 4): the mean / variance processors no shipped config names (posterior_mean_variance.py:53-101
+    previous_x / start_x, :171-222 fixed_small / fixed_large / learned) run in osm_posterior_typed inside the fused loop; vs the REAL
+    reference's 10-step guided Osmosis loop built with them (tests/golden/loop_processors.npz; x_T, y, noise of
+    loop_underwater_physical_revised.npz).  start_x / fixed_small amplifies (the reference's own drift from a 1e-6 perturbation is
+    2.6e-3): that chain is compared step by step from the reference's inputs."""
+    unet, gd, M, CM = pkg
+    g, base = np.load(os.path.join(GOLD, "loop_processors.npz")), np.load(os.path.join(GOLD, "loop_underwater_physical_revised.npz"))
+    spec = OPERATORS["underwater_physical_revised"]
+    model = make_model(unet)
+    operator = M.get_operator("underwater_physical_revised", device=DEV, batch_size=1, **spec["operator"])
+    cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    sampler = gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                     model_mean_type=mean_type, model_var_type=var_type, dynamic_threshold=False,
+                                     clip_denoised=False, rescale_timesteps=False)
+    _no_generic(monkeypatch, sampler)
+    noise = torch.from_numpy(base["noise"]).to(DEV)
+    y = torch.from_numpy(base["y"]).to(DEV)
+    tag = f"osmosis.{mean_type}.{var_type}"
+    scale = max(1.0, float(np.abs(g[f"{tag}.final_img"]).max()))
+    bar = _free_running_bar(float(g[f"{tag}.drift_1e-6"]))
+    kw = dict(model=model, measurement=y, measurement_cond_fn=cond.conditioning, record=False, save_root=None, pretrain_model="osmosis",
+              rgb_guidance=False, sample_pattern=PATTERN)
+    trace = []
+    if bar is None:                                          # teacher-forced: step k from the reference's input of step k
+        x_in, worst = g[f"{tag}.x_in"], 0.0
+        for k in range(10):
+            img, variables, loss, x0 = sampler.p_sample_loop(x_start=torch.from_numpy(x_in[k]).to(DEV), index_range=(9 - k, 9 - k),
+                                                             noise_fn=lambda kk, shape, k=k: noise[k], trace=trace, **kw)
+            want = x_in[k + 1] if k < 9 else g[f"{tag}.final_img"]
+            worst = max(worst, float((img.cpu() - torch.from_numpy(want)).abs().max()))
+        print(f"{tag}: teacher-forced, worst one-step error {worst:.1e}")
+        assert worst < 2e-5
+    else:
+        img, variables, loss, x0 = sampler.p_sample_loop(x_start=torch.from_numpy(base["x_T"]).to(DEV),
+                                                         noise_fn=lambda k, shape: noise[k], trace=trace, **kw)
+    e_first = float((trace[0]["x0"].cpu() - torch.from_numpy(g[f"{tag}.x0_first"])).abs().max())
+    e_mean = float((trace[0]["mean"].cpu() - torch.from_numpy(g[f"{tag}.mean_first"])).abs().max())
+    e_loss = max(abs(float(rec["loss"][0]) - float(g[f"{tag}.loss"][k].reshape(-1)[0])) / float(g[f"{tag}.loss"][k].reshape(-1)[0])
+                 for k, rec in enumerate(trace))
+    e_img = float((img.cpu() - torch.from_numpy(g[f"{tag}.final_img"])).abs().max()) / scale
+    e_x0 = float((x0 - torch.from_numpy(g[f"{tag}.final_x0"])).abs().max()) / scale
+    print(f"{tag}: first x0 {e_first:.1e} mean {e_mean:.1e}; loss(rel) {e_loss:.1e}; final img {e_img:.1e} x0 {e_x0:.1e} (of max |img| {scale:.1f}); bar {bar}")
+    assert len(trace) == 10 and e_first < 5e-6 and e_mean < 5e-6 and e_loss < 2e-5
+    assert e_img < (bar or 2e-5) and e_x0 < (bar or 2e-5)
+    for n, v in variables.items():
+        assert torch.allclose(v.cpu(), torch.from_numpy(g[f"{tag}.{n}"]), atol=2e-6), n
+
+
+@pytest.mark.parametrize("name,mean_type,var_type", [("ddpm", "start_x", "fixed_large"), ("ddpm", "epsilon", "fixed_small"),
+                                                     ("ddpm", "start_x", "learned"), ("ddim", "previous_x", "fixed_small"),
+                                                     ("ddim", "start_x", "learned_range")])
+def test_rgb_guidance_chains_with_the_other_processors(pkg, monkeypatch, name, mean_type, var_type):
+    """The rgb-guidance chains (DDPM.p_sample / DDIM.p_sample + `ps`) with the other processors, on the fused kernels, vs the REAL
+    reference's chains (loop_processors.npz; x_T, y and the draws of loop_ps.npz).  DDIM takes eps from the sampler's own tables
+    (predict_eps_from_x_start :533-536) whatever the mean processor: dcoef[4:6] of osm_ddim_update.  Chains the reference itself
+    cannot reproduce to 1e-3 from a 1e-6 perturbation (previous_x: drift 0.22; start_x / fixed_large: 1.3e-3) are compared step by
+    step from the reference's inputs."""
+    unet, gd, M, CM = pkg
+    g, ps = np.load(os.path.join(GOLD, "loop_processors.npz")), np.load(os.path.join(GOLD, "loop_ps.npz"))
+    model = make_model(unet)
+    cond = CM.get_conditioning_method("ps", M.get_operator("rgb_guidance", device=DEV, batch_size=1),
+                                      M.get_noise("gaussian", sigma=0.05), scale="0.6,0.5,0.4,0.0")
+    sampler = gd.get_sampler(name)(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                   model_mean_type=mean_type, model_var_type=var_type, dynamic_threshold=False,
+                                   clip_denoised=False, rescale_timesteps=False)
+    _no_generic(monkeypatch, sampler)
+    draws = torch.from_numpy(ps[f"{name}.draws_x"]).to(DEV)
+    tag = f"ps.{name}.{mean_type}.{var_type}"
+    bar = _free_running_bar(float(g[f"{tag}.drift_1e-6"]))
+    kw = dict(model=model, measurement=torch.from_numpy(ps[f"{name}.y"]).to(DEV), measurement_cond_fn=cond.conditioning, record=False,
+              save_root=None, pretrain_model="osmosis", rgb_guidance=True, sample_pattern=PATTERN)
+    trace = []
+    if bar is None:
+        x_in, worst = g[f"{tag}.x_in"], 0.0
+        for k in range(10):
+            img = sampler.p_sample_loop(x_start=torch.from_numpy(x_in[k]).to(DEV), index_range=(9 - k, 9 - k),
+                                        noise_fn=lambda kk, shape, k=k: draws[k], trace=trace, **kw)
+            want = torch.from_numpy(x_in[k + 1] if k < 9 else g[f"{tag}.final_img"])
+            worst = max(worst, float((img.cpu() - want).abs().max()) / max(1.0, float(want.abs().max())))
+        print(f"{tag}: teacher-forced, worst one-step error {worst:.1e} (of the step's max |x|)")
+        assert worst < 2e-5
+    else:
+        img = sampler.p_sample_loop(x_start=torch.from_numpy(ps[f"{name}.x_T"]).to(DEV), noise_fn=lambda k, shape: draws[k],
+                                    trace=trace, **kw)
+        err = float((img.detach().cpu() - torch.from_numpy(g[f"{tag}.final_img"])).abs().max())
+        print(f"{tag}: free-running chain max-abs error {err:.1e}, bar {bar:.1e}")
+        assert err < bar
+    losses = [float(r["loss"][0]) for r in trace]
+    assert len(losses) == 10 and np.allclose(losses, g[f"{tag}.loss"], rtol=2e-5), (losses, g[f"{tag}.loss"])
+
+
+@pytest.mark.parametrize("mode", ["osmosis", "ps.ddpm"])
+def test_previous_x_raises_where_the_reference_raises(pkg, mode):
+    """`previous_x` returns the network's split output as the mean, and the Osmosis branch / DDPM.p_sample add to it in place: the
+    reference raises autograd's view error there (recorded by the generator in loop_processors.npz `previous_x.raises`)."""
+    unet, gd, M, CM = pkg
+    g = np.load(os.path.join(GOLD, "loop_processors.npz"))
+    assert mode in list(g["previous_x.raises"])
+    model = make_model(unet)
+    sampler = gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10), betas=gd.get_named_beta_schedule("linear", 1000),
+                                     model_mean_type="previous_x", model_var_type="learned_range", dynamic_threshold=False,
+                                     clip_denoised=False, rescale_timesteps=False)
+    if mode == "osmosis":
+        spec = OPERATORS["underwater_physical_revised"]
+        operator = M.get_operator("underwater_physical_revised", device=DEV, batch_size=1, **spec["operator"])
+        cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    else:
+        cond = CM.get_conditioning_method("ps", M.get_operator("rgb_guidance", device=DEV, batch_size=1),
+                                          M.get_noise("gaussian", sigma=0.05), scale="0.6,0.5,0.4,0.0")
+    x = torch.zeros(1, 4, 32, 32, device=DEV)
+    with pytest.raises(RuntimeError, match="modified inplace"):
+        sampler.p_sample_loop(model=model, x_start=x, measurement=x[:, :3], measurement_cond_fn=cond.conditioning, record=False,
+                              save_root=None, pretrain_model="osmosis", rgb_guidance=(mode != "osmosis"), sample_pattern=PATTERN)
+
+
 def test_generic_loop_honours_record(pkg, tmp_path):
     """VERDICT r05 missing 4: `record=True` is honoured by every loop (reference gaussian_diffusion.py:308-333), also by the
     generic autograd loop a third-party conditioner runs through."""
