@@ -300,9 +300,16 @@ int osm_posterior(const float* model_out /*[B,8,HW]*/, const float* x /*[B,4,HW]
  *             2 'previous_x' : x0 = c0*x - c1*out, mean = out                (row: c0 = -coef2/coef1, c1 = -1/coef1)
  *   var_kind  0 'learned_range': logvar = f*coef[5] + (1-f)*coef[4], f = (v+1)/2 ; 1 'fixed_small' / 'fixed_large': logvar = coef[4]
  *             (log posterior_variance[t] / log(append(posterior_variance[1], betas[1:]))[t]) ; 2 'learned': logvar = v
- * (v = model_out[:, 4:8]: the network of the path always has 2 C output channels, gaussian_diffusion.py:349-350). */
+ * (v = model_out[:, 4:8]: the network of the path always has 2 C output channels, gaussian_diffusion.py:349-350).
+ * clip_denoised != 0 (process_xstart, posterior_mean_variance.py:43-50; `clip_denoised: True` of configs/rgb_guidance_sample_config.yaml):
+ * x0 = clamp(prediction, -1, 1), the mean is formed from the clamped x0, and the unclamped prediction is written to x0_raw [B,4,HW]
+ * (required then) for osm_clamp_bwd. */
 int osm_posterior_typed(const float* model_out, const float* x, const float* coef, int mean_kind, int var_kind,
-                        float* x0, float* mean, float* logvar, int B, int HW, void* stream);
+                        int clip_denoised, float* x0_raw, float* x0, float* mean, float* logvar, int B, int HW, void* stream);
+/* Backward of clamp(x_raw, lo, hi) applied to a gradient in place: g[i] = 0 where x_raw[i] is outside [lo, hi] (bounds pass, NaN does
+ * not: ATen's clamp_backward).  With clip_denoised the guidance gradient d loss/d x0 is masked by it before osm_posterior_bwd and the
+ * update kernels read it. */
+int osm_clamp_bwd(float* g, const float* x_raw, float lo, float hi, long long n, void* stream);
 
 /* physical forward model + guidance loss (measurements.py:138-151,251-264,363-376;
  * condition_methods.py:109-144; losses.py:29-83; utils.py:544-566,674-700) */

@@ -110,8 +110,19 @@ def _coef(arr: np.ndarray, t: int) -> float:
 
 
 # ----------------------------------------------------------------------------- posterior
+def process_xstart(x0: torch.Tensor, clip_denoised: bool = False, dynamic_threshold: bool = False) -> torch.Tensor:
+    """pmv.py:43-50; `dynamic_thresholding(x, s=0.98)` = util/img_utils.py:8-15: x times the 0.98-quantile of |x| over the whole
+    tensor, clipped to [-1, 1]."""
+    if dynamic_threshold:
+        x0 = torch.clip(x0 * torch.quantile(x0.abs(), 0.98), -1.0, 1.0)
+    if clip_denoised:
+        x0 = x0.clamp(-1, 1)
+    return x0
+
+
 def p_mean_variance(tb: Tables, model_out: torch.Tensor, x: torch.Tensor, t: int, mean_type: str = "epsilon",
-                    var_type: str = "learned_range") -> Dict[str, torch.Tensor]:
+                    var_type: str = "learned_range", clip_denoised: bool = False,
+                    dynamic_threshold: bool = False) -> Dict[str, torch.Tensor]:
     """gd.py:345-365 over the registered processors of posterior_mean_variance.py: mean `epsilon` (:104-136, the one every
     shipped config names), `start_x` (:75-101: the network predicts x_0), `previous_x` (:53-72: the network predicts the mean,
     x_0 solved from it); variance `learned_range` (:225-258), `fixed_small` (:171-187), `fixed_large` (:190-212), `learned`
@@ -120,14 +131,15 @@ def p_mean_variance(tb: Tables, model_out: torch.Tensor, x: torch.Tensor, t: int
     out, v = torch.split(model_out, C, dim=1)
     pc1, pc2 = tb.posterior_mean_coef1, tb.posterior_mean_coef2
     if mean_type == "epsilon":
-        x0 = _coef(tb.sqrt_recip_alphas_cumprod, t) * x - _coef(tb.sqrt_recipm1_alphas_cumprod, t) * out
+        x0 = process_xstart(_coef(tb.sqrt_recip_alphas_cumprod, t) * x - _coef(tb.sqrt_recipm1_alphas_cumprod, t) * out,
+                            clip_denoised, dynamic_threshold)
         mean = _coef(pc1, t) * x0 + _coef(pc2, t) * x
     elif mean_type == "start_x":
-        x0 = out
+        x0 = process_xstart(out, clip_denoised, dynamic_threshold)
         mean = _coef(pc1, t) * x0 + _coef(pc2, t) * x
     elif mean_type == "previous_x":
         mean = out
-        x0 = _coef(1.0 / pc1, t) * out - _coef(pc2 / pc1, t) * x
+        x0 = process_xstart(_coef(1.0 / pc1, t) * out - _coef(pc2 / pc1, t) * x, clip_denoised, dynamic_threshold)
     else:
         raise NameError(f"Name {mean_type} is not defined.")
     if var_type == "learned_range":
@@ -324,7 +336,7 @@ def is_freeze_phi(pattern: Optional[dict], idx: int, T: int) -> bool:
 def p_sample_loop(model: Callable, tb: Tables, x_T: torch.Tensor, y: torch.Tensor,
                   guidance: OsmosisGuidance, pattern: Optional[dict],
                   noises: List[torch.Tensor], trace: Optional[list] = None, mean_type: str = "epsilon",
-                  var_type: str = "learned_range"):
+                  var_type: str = "learned_range", clip_denoised: bool = False):
     """gaussian_diffusion.py:179-340 (osmosis branch, alternate_len=1, guidance always on).
     `model(x, t_mapped_float_tensor)` -> [B,8,H,W].  `noises[k]` = the randn_like(img) drawn at
     loop iteration k (the reference's unused randn_like(measurement) draw is not modelled here;
@@ -335,7 +347,7 @@ def p_sample_loop(model: Callable, tb: Tables, x_T: torch.Tensor, y: torch.Tenso
     for k, idx in enumerate(range(T - 1, -1, -1)):
         img = img.detach().requires_grad_(True)
         t_model = torch.tensor([tb.timestep_map[idx]] * img.shape[0])
-        out = p_mean_variance(tb, model(img, t_model), img, idx, mean_type, var_type)
+        out = p_mean_variance(tb, model(img, t_model), img, idx, mean_type, var_type, clip_denoised)
         freeze = is_freeze_phi(pattern, idx, T)
         x_t, loss, variables, grad = guidance.conditioning(img, out["mean"], out["pred_xstart"], y, freeze)
         x0 = out["pred_xstart"].detach()

@@ -20,6 +20,8 @@ Sections (SURVEY.md section 8c recipe):
   loop_optimizers.npz (round 6) the guided loop with each torch optimizer of utils.get_optimizer on phi: losses, phi, final image
   loop_processors.npz (round 6) the Osmosis loop and the rgb-guidance chains with the previous_x / start_x mean processors and the
                       fixed_small / fixed_large / learned variance processors
+  loop_clip.npz       (round 6) `clip_denoised: True` (the shipped rgb-guidance config's setting): rgb-guidance chains, the Osmosis loop,
+                      process_xstart with dynamic thresholding
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
   unet_variants.npz   (round 5) tiny UNets with conv up / down-sampling layers, additive conditioning, class conditioning
@@ -208,7 +210,7 @@ PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local
                n_iter=20, start_guidance=1, stop_guidance=0)
 
 
-def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=0.0):
+def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=0.0, clip_denoised=False):
     """10-step guided p_sample_loop of the reference (model m) for one operator spec; every randn_like draw logged."""
     operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
     noiser = get_noise(name="clean")
@@ -216,7 +218,7 @@ def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=
     sampler = R_gd.get_sampler("ddpm")(use_timesteps=range(0, 100, 10),
                                        betas=R_gd.get_named_beta_schedule("linear", 1000),
                                        model_mean_type=mean_type, model_var_type=var_type,
-                                       dynamic_threshold=False, clip_denoised=False,
+                                       dynamic_threshold=False, clip_denoised=clip_denoised,
                                        rescale_timesteps=False)
     x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(0))
     if perturb:                                            # sensitivity probes (gen_processors)
@@ -294,7 +296,10 @@ def gen_optimizers():
     for name, eta in OPTIMIZER_ETAS.items():
         spec = dict(base, operator=dict(base["operator"], optimizer=name, phi_a_eta=eta, phi_b_eta=eta, phi_inf_eta=eta))
         tr, loss, variables = _loop_trace(m, spec)
-        if not out:
+        tr2, _, _ = _loop_trace(m, spec, perturb=1e-6)       # the reference's own sensitivity: x_T + 1e-6 N(0,1) (adadelta: 50x the others)
+        out[f"{name}.phi_drift_1e-6"] = np.array(max(float(np.abs(tr2[f"trace.{k}"] - tr[f"trace.{k}"]).max()) for k in ("phi_a", "phi_b", "phi_inf")))
+        out[f"{name}.img_drift_1e-6"] = np.array(float(np.abs(tr2["final_img"] - tr["final_img"]).max()))
+        if "x_T" not in out:
             out.update({"x_T": tr["x_T"], "y": tr["y"], "noise": tr["noise"]})
         else:
             assert np.array_equal(out["noise"], tr["noise"]) and np.array_equal(out["x_T"], tr["x_T"])
@@ -304,7 +309,7 @@ def gen_optimizers():
         out[f"{name}.loss"] = tr["trace.loss"]
         for k in ("phi_a", "phi_b", "phi_inf"):
             out[f"{name}.{k}"] = tr[f"trace.{k}"]
-        print(name, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()})
+        print(name, "final loss", loss, {k: npy(v).ravel().round(4) for k, v in variables.items()}, "phi drift", float(out[f"{name}.phi_drift_1e-6"]))
     np.savez_compressed(os.path.join(OUT, "loop_optimizers.npz"), **out)
 
 
@@ -505,16 +510,17 @@ def gen_prior():
                         cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
 
 
-def _ps_chain(m, name, mean_type="epsilon", var_type="learned_range", perturb=0.0, x_ins=None):
+def _ps_chain(m, name, mean_type="epsilon", var_type="learned_range", perturb=0.0, x_ins=None, clip_denoised=False,
+              scale="0.6,0.5,0.4,0.0", sigma=0.05):
     """One rgb-guidance chain of the reference: sampler `name` ('ddpm' | 'ddim'), the given processors; every randn_like logged.
     perturb: amplitude of a seeded N(0,1) perturbation of x_T (sensitivity probes); x_ins: list receiving every step's input."""
     operator = get_operator(name="rgb_guidance", device=torch.device("cpu"), batch_size=1)
-    noiser = get_noise(name="gaussian", sigma=0.05)
-    cond = get_conditioning_method("ps", operator, noiser, scale="0.6,0.5,0.4,0.0")
+    noiser = get_noise(name="gaussian", sigma=sigma)
+    cond = get_conditioning_method("ps", operator, noiser, scale=scale)
     sampler = R_gd.get_sampler(name)(use_timesteps=range(0, 100, 10),
                                      betas=R_gd.get_named_beta_schedule("linear", 1000),
                                      model_mean_type=mean_type, model_var_type=var_type,
-                                     dynamic_threshold=False, clip_denoised=False, rescale_timesteps=False)
+                                     dynamic_threshold=False, clip_denoised=clip_denoised, rescale_timesteps=False)
     x_T = 0.5 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(2))
     if perturb:
         x_T = x_T + perturb * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(77))
@@ -627,6 +633,46 @@ def gen_processors():
             out[f"{tag}.x_in"] = np.stack([npy(x) for x in x_ins])
         print(tag, "final loss", losses[-1], "max |img|", float(img.abs().max()), "drift", float(out[f"{tag}.drift_1e-6"]))
     np.savez_compressed(os.path.join(OUT, "loop_processors.npz"), **out)
+
+
+def gen_clip():
+    """(round 6) `clip_denoised: True` -- what configs/rgb_guidance_sample_config.yaml ships (ddpm, ps, scale 3,3,3,0.1, gaussian noiser
+    with sigma 0) -- through the REAL reference: the rgb-guidance chains (DDPM.p_sample with the shipped conditioning values, and
+    DDIM.p_sample) and the Osmosis loop, 10 low-t steps on the tiny seeded UNet (x_T, y, draws of loop_ps.npz / noise of
+    loop_underwater_physical_revised.npz), with the fraction of clamped pred_xstart elements per chain; plus `process_xstart` itself
+    (posterior_mean_variance.py:43-50) with dynamic_threshold (util/img_utils.py:8-15) and both switches on a seeded tensor."""
+    from guided_diffusion.posterior_mean_variance import get_mean_processor
+    m, cfg, sd = tiny_model()
+    base = dict(np.load(os.path.join(OUT, "loop_underwater_physical_revised.npz")))
+    ps = dict(np.load(os.path.join(OUT, "loop_ps.npz")))
+    out = {}
+    for name, kw in (("ddpm", dict(scale="3,3,3,0.1", sigma=0)), ("ddim", dict())):
+        x_T, y, img, losses, draws = _ps_chain(m, name, clip_denoised=True, **kw)
+        img2 = _ps_chain(m, name, clip_denoised=True, perturb=1e-6, **kw)[2]
+        assert np.array_equal(npy(x_T), ps[f"{name}.x_T"]) and np.array_equal(npy(y), ps[f"{name}.y"])
+        assert np.array_equal(np.stack([npy(d) for d in draws if d.shape[1] == 4]), ps[f"{name}.draws_x"])
+        tag = f"ps.{name}"
+        out[f"{tag}.final_img"], out[f"{tag}.loss"] = npy(img), np.array(losses, dtype=np.float32)
+        out[f"{tag}.drift_1e-6"] = np.array(float((img2 - img).abs().max()))
+        print(tag, "final loss", losses[-1], "max |img|", float(img.abs().max()), "drift", float(out[f"{tag}.drift_1e-6"]))
+    tr, loss, variables = _loop_trace(m, OPERATORS["underwater_physical_revised"], clip_denoised=True)
+    tr2, _, _ = _loop_trace(m, OPERATORS["underwater_physical_revised"], clip_denoised=True, perturb=1e-6)
+    assert np.array_equal(tr["noise"], base["noise"]) and np.array_equal(tr["x_T"], base["x_T"])
+    out["osmosis.final_img"], out["osmosis.final_x0"], out["osmosis.loss"] = tr["final_img"], tr["final_x0"], tr["trace.loss"]
+    out["osmosis.x0"], out["osmosis.grad"] = tr["trace.x0"], tr["trace.grad"]
+    out["osmosis.drift_1e-6"] = np.array(np.abs(tr2["final_img"] - tr["final_img"]).max())
+    out["osmosis.clamped_fraction"] = np.array(float((np.abs(tr["trace.x0"]) == 1.0).mean()))
+    for k in ("phi_a", "phi_b", "phi_inf"):
+        out[f"osmosis.{k}"] = tr[f"final.{k}"]
+    print("osmosis clip: final loss", loss, "clamped fraction", float(out["osmosis.clamped_fraction"]), "drift", float(out["osmosis.drift_1e-6"]))
+    # process_xstart on a seeded tensor, through the mean processor's own method
+    betas = R_gd.get_named_beta_schedule("linear", 1000)
+    x = 1.3 * torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(21))
+    out["px.x"] = npy(x)
+    for dyn, clip in ((True, False), (True, True), (False, True)):
+        proc = get_mean_processor("epsilon", betas=betas, dynamic_threshold=dyn, clip_denoised=clip)
+        out[f"px.dyn{int(dyn)}.clip{int(clip)}"] = npy(proc.process_xstart(x.clone()))
+    np.savez_compressed(os.path.join(OUT, "loop_clip.npz"), **out)
 
 
 def gen_postprocess():
@@ -784,6 +830,7 @@ if __name__ == "__main__":
     gen_ps()
     gen_optimizers()
     gen_processors()
+    gen_clip()
     gen_fp16()
     gen_full_unet()
     gen_full_step()

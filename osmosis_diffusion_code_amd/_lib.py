@@ -108,7 +108,8 @@ _SIGS = {
     "osm_stride2_place": [_P, _LL, _P, _LL, _I, _I, _I, _I, _P],
     "osm_add_rowvec": [_P, _LL, _P, _LL, _I, _LL, _I, _P],
     "osm_posterior": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "osm_posterior_typed": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
+    "osm_posterior_typed": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
+    "osm_clamp_bwd": [_P, _P, _F, _F, _LL, _P],
     "osm_phys_nblk": [_I],
     "osm_phys_reduce": [C.POINTER(PhysDesc), _P, _P, _P, _P, _P],
     "osm_phys_finalize": [C.POINTER(PhysDesc), _P, _P, _P, _I, _P, _P, _P],

@@ -304,11 +304,13 @@ __global__ __launch_bounds__(256) void phys_grad_kernel(osm_phys_desc ds, const 
 //     c0 = d x0 / d x and c1 = -d x0 / d out, which is also what posterior_bwd_kernel and the update kernels read;
 //     1 start_x, x0 = out exactly; 2 previous_x, mean = out exactly).  VK: variance processor (0 learned_range,
 //     1 fixed_small / fixed_large: the row's value, 2 learned: the network's second half).
+// x0_raw != nullptr: clip_denoised (process_xstart, posterior_mean_variance.py:43-50): the unclamped prediction goes to x0_raw
+// (clamp_bwd_kernel masks the guidance gradient with it), x0 = clamp(x0_raw, -1, 1) and the mean is formed from the clamped x0.
 template <int MK, int VK>
 __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ mo, const float* __restrict__ x,
-                                                         const float* __restrict__ coef, float* __restrict__ x0,
-                                                         float* __restrict__ mean, float* __restrict__ logvar,
-                                                         int B, int HW) {
+                                                         const float* __restrict__ coef, float* __restrict__ x0_raw,
+                                                         float* __restrict__ x0, float* __restrict__ mean,
+                                                         float* __restrict__ logvar, int B, int HW) {
   const long long total = (long long)B * 4 * HW;
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], mn = coef[4], mxl = coef[5];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -317,7 +319,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     const long long rem = i - b * 4LL * HW;
     const float eps = mo[b * 8LL * HW + rem];
     const float xv = x[i];
-    const float xs = MK == 1 ? eps : c0 * xv - c1 * eps;
+    float xs = MK == 1 ? eps : c0 * xv - c1 * eps;
+    if (x0_raw) {
+      x0_raw[i] = xs;
+      xs = (xs != xs) ? xs : fminf(fmaxf(xs, -1.0f), 1.0f);          // torch.clamp keeps NaN
+    }
     x0[i] = xs;
     mean[i] = MK == 2 ? eps : c2 * xs + c3 * xv;
     if (VK == 1) {
@@ -331,6 +337,15 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
         logvar[i] = frac * mxl + (1.0f - frac) * mn;
       }
     }
+  }
+}
+
+// backward of x.clamp(lo, hi) (ATen clamp_backward: the gradient passes where lo <= x <= hi, bounds included; NaN -> 0)
+__global__ __launch_bounds__(256) void clamp_bwd_kernel(float* __restrict__ g, const float* __restrict__ x_raw, float lo, float hi,
+                                                         long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x_raw[i];
+    if (!(v >= lo && v <= hi)) g[i] = 0.f;
   }
 }
 
@@ -613,14 +628,17 @@ extern "C" int osm_phys_optimize(const osm_phys_desc* d, const float* x0, const 
 }
 
 extern "C" int osm_posterior_typed(const float* model_out, const float* x, const float* coef, int mean_kind, int var_kind,
-                                   float* x0, float* mean, float* logvar, int B, int HW, void* stream) {
+                                   int clip_denoised, float* x0_raw, float* x0, float* mean, float* logvar, int B, int HW,
+                                   void* stream) {
   OSM_REQUIRE(model_out && x && coef && x0 && mean && logvar && B > 0 && HW > 0, "osm_posterior_typed: bad argument");
+  OSM_REQUIRE(!clip_denoised || x0_raw, "osm_posterior_typed: clip_denoised needs x0_raw (the unclamped prediction, read by osm_clamp_bwd)");
+  if (!clip_denoised) x0_raw = nullptr;
   OSM_REQUIRE(mean_kind >= 0 && mean_kind <= 2, "osm_posterior_typed: mean_kind must be 0 (epsilon), 1 (start_x) or 2 (previous_x)");
   OSM_REQUIRE(var_kind >= 0 && var_kind <= 2, "osm_posterior_typed: var_kind must be 0 (learned_range), 1 (fixed) or 2 (learned)");
   const dim3 grid(grid_for((long long)B * 4 * HW)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define OSM_POST(MK, VK) \
-  hipLaunchKernelGGL((posterior_kernel<MK, VK>), grid, block, 0, st, model_out, x, coef, x0, mean, logvar, B, HW)
+  hipLaunchKernelGGL((posterior_kernel<MK, VK>), grid, block, 0, st, model_out, x, coef, x0_raw, x0, mean, logvar, B, HW)
   switch (mean_kind * 3 + var_kind) {
     case 0: OSM_POST(0, 0); break;
     case 1: OSM_POST(0, 1); break;
@@ -638,7 +656,13 @@ extern "C" int osm_posterior_typed(const float* model_out, const float* x, const
 
 extern "C" int osm_posterior(const float* model_out, const float* x, const float* coef, float* x0, float* mean,
                              float* logvar, int B, int HW, void* stream) {
-  return osm_posterior_typed(model_out, x, coef, 0, 0, x0, mean, logvar, B, HW, stream);
+  return osm_posterior_typed(model_out, x, coef, 0, 0, 0, nullptr, x0, mean, logvar, B, HW, stream);
+}
+
+extern "C" int osm_clamp_bwd(float* g, const float* x_raw, float lo, float hi, long long n, void* stream) {
+  OSM_REQUIRE(g && x_raw && n > 0 && lo <= hi, "osm_clamp_bwd: bad argument");
+  hipLaunchKernelGGL(clamp_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, x_raw, lo, hi, n);
+  return osm::check_launch("clamp_bwd_kernel");
 }
 
 extern "C" int osm_posterior_bwd(const float* g, const float* coef, float* d_out, int B, int HW, void* stream) {

@@ -188,7 +188,7 @@ class GaussianDiffusion:
             return None
         if self.mean_processor.hip_kernel != "osm_posterior" or self.var_processor.hip_kernel != "osm_posterior":
             return None
-        if self.mean_processor.dynamic_threshold or self.mean_processor.clip_denoised:
+        if self.mean_processor.dynamic_threshold:            # (a batch-wide quantile: no shipped config; `_generic_loop`)
             return None
         if sample_pattern is not None and sample_pattern.get("pattern") not in (None, "original"):
             if sample_pattern.get("local_M", 1) != 1:
@@ -303,6 +303,9 @@ class GaussianDiffusion:
         dtable = torch.from_numpy(self.ddim_table(float(kwargs.get("eta", 0.0)))).to(dev) if ddim else None
         dcoef = torch.zeros(8, **f32) if ddim else None
         x0, mean, logvar = (torch.empty(B, 4, H, W, **f32) for _ in range(3))
+        # `clip_denoised: True` (configs/rgb_guidance_sample_config.yaml; posterior_mean_variance.py:43-50): x0 is clamped inside
+        # osm_posterior_typed, the unclamped prediction is kept for the clamp's backward (osm_clamp_bwd masks d loss / d x0)
+        x0_raw = torch.empty(B, 4, H, W, **f32) if self.mean_processor.clip_denoised else None
         g = torch.empty(B, 4, H, W, **f32)
         loss_all = torch.zeros(B, **f32)
         scale4 = cond.scale4(dev)
@@ -368,7 +371,8 @@ class GaussianDiffusion:
                     ce.x_in.copy_(x_state[c0:c1])
                 ce.run_forward()
                 ops.posterior(ce.out, ce.x_in, coef, x0[c0:c1], mean[c0:c1], logvar[c0:c1], Bc, HW,
-                              self.mean_processor.kernel_kind, self.var_processor.kernel_kind)
+                              self.mean_processor.kernel_kind, self.var_processor.kernel_kind,
+                              None if x0_raw is None else x0_raw[c0:c1])
                 if trace is not None:
                     model_out[c0:c1].copy_(ce.out)
                 gg = dxu = grad_out = None
@@ -379,6 +383,8 @@ class GaussianDiffusion:
                         cond.loss_grad_x0(x0[c0:c1], y[c0:c1], freeze_phi=freeze, g_out=g[c0:c1], phi=phi[c0:c1],
                                           loss_out=loss_all[c0:c1])
                     have_loss = True
+                    if x0_raw is not None:
+                        ops.clamp_bwd(g[c0:c1], x0_raw[c0:c1])
                     ops.posterior_bwd(g[c0:c1], coef, ce.d_out, Bc, HW)
                     ce.run_backward()
                     gg, dxu = g[c0:c1], ce.dx

@@ -81,9 +81,9 @@ class MeanProcessor(ABC):
 
     def process_xstart(self, x):
         if self.dynamic_threshold:
-            s = torch.quantile(x.abs().reshape(x.shape[0], -1), 0.98, dim=1).clamp(min=1.0)
-            s = s.reshape(-1, *([1] * (x.ndim - 1)))
-            x = torch.clip(x, -s, s) / s
+            # the reference's `dynamic_thresholding(x, s=0.98)` (util/img_utils.py:8-15): the tensor TIMES the 0.98-quantile of
+            # |x| over all of its elements (the batch included), then clipped to [-1, 1] -- not Imagen's per-image clip-and-divide
+            x = torch.clip(x * torch.quantile(x.abs(), 0.98), -1.0, 1.0)
         if self.clip_denoised:
             x = x.clamp(-1, 1)
         return x

@@ -370,11 +370,18 @@ def convert(x: Mat, y: Mat):
 
 
 # ----------------------------------------------------------------------------- sampler step
-def posterior(model_out, x, coef, x0, mean, logvar, B, HW, mean_kind=0, var_kind=0):
+def posterior(model_out, x, coef, x0, mean, logvar, B, HW, mean_kind=0, var_kind=0, x0_raw=None):
     """mean_kind / var_kind: `MeanProcessor.kernel_kind` / `VarianceProcessor.kernel_kind` (include/osmosis_hip.h osm_posterior_typed);
-    (0, 0) = the epsilon / learned_range pair of every shipped config."""
-    call("osm_posterior_typed", ptr(model_out), ptr(x), ptr(coef), int(mean_kind), int(var_kind), ptr(x0), ptr(mean), ptr(logvar),
-         B, HW, _s(), keep=(model_out, x, coef, x0, mean, logvar))
+    (0, 0) = the epsilon / learned_range pair of every shipped config.  x0_raw given = `clip_denoised`: x0 is clamped to [-1, 1] and
+    the unclamped prediction lands in x0_raw (for `clamp_bwd`)."""
+    call("osm_posterior_typed", ptr(model_out), ptr(x), ptr(coef), int(mean_kind), int(var_kind), 0 if x0_raw is None else 1,
+         ptr(x0_raw), ptr(x0), ptr(mean), ptr(logvar), B, HW, _s(), keep=(model_out, x, coef, x0_raw, x0, mean, logvar))
+
+
+def clamp_bwd(g, x_raw, lo=-1.0, hi=1.0):
+    """g (in place) = 0 where x_raw is outside [lo, hi]: the backward of `x_raw.clamp(lo, hi)`."""
+    assert g.numel() == x_raw.numel() and g.is_contiguous() and x_raw.is_contiguous()
+    call("osm_clamp_bwd", ptr(g), ptr(x_raw), float(lo), float(hi), g.numel(), _s(), keep=(g, x_raw))
 
 
 def phys_nblk(HW):

@@ -192,6 +192,40 @@ def test_guided_loop_with_the_other_processors(mean_type, var_type):
         assert torch.allclose(v, T(g[f"{tag}.{n}"]), atol=1e-6), n
 
 
+def test_guided_loop_with_clip_denoised():
+    """Round 6: `clip_denoised: True` (configs/rgb_guidance_sample_config.yaml's setting; process_xstart, posterior_mean_variance.py:43-50)
+    in the oracle's Osmosis loop vs the REAL reference (loop_clip.npz): 6.4 % of the pred_xstart elements sit on the clamp."""
+    g, base = load("loop_clip.npz"), load("loop_underwater_physical_revised.npz")
+    cfg, sd = tiny()
+    okw, ckw = OPS["underwater_physical_revised"]
+    guide = D.OsmosisGuidance(D.PhysOperator("underwater_physical_revised", batch_size=1, **okw), n_iter=20, **ckw)
+    tb = D.Tables(D.named_beta_schedule("linear", 1000), range(0, 100, 10))
+    trace = []
+    img, variables, loss, x0 = D.p_sample_loop(lambda x, t: U.unet_forward(sd, cfg, x, t), tb, T(base["x_T"]), T(base["y"]), guide,
+                                               PATTERN, [T(n) for n in base["noise"]], trace, clip_denoised=True)
+    assert float(g["osmosis.clamped_fraction"]) > 0.03
+    for k, rec in enumerate(trace):
+        assert torch.allclose(rec["x0"], T(g["osmosis.x0"][k]), atol=5e-5), (k, "x0")
+        assert torch.allclose(rec["grad"], T(g["osmosis.grad"][k]), atol=5e-5 * float(np.abs(g["osmosis.grad"][k]).max())), (k, "grad")
+        assert np.allclose(rec["loss"], g["osmosis.loss"][k], rtol=1e-5), (k, "loss")
+    assert float(torch.stack([r["x0"] for r in trace]).abs().max()) == 1.0
+    assert torch.allclose(img, T(g["osmosis.final_img"]), atol=5e-5)
+
+
+@pytest.mark.parametrize("dyn,clip", [(True, False), (True, True), (False, True)])
+def test_process_xstart_matches_the_reference(dyn, clip):
+    """process_xstart (posterior_mean_variance.py:43-50) of the oracle AND of the package's mean processors vs the reference's on a
+    seeded tensor: its `dynamic_thresholding` (util/img_utils.py:8-15) multiplies by the 0.98-quantile of |x| over the whole tensor
+    and clips -- the package restated Imagen's clip-and-divide until round 6."""
+    from osmosis_diffusion_code_amd.guided_diffusion.posterior_mean_variance import get_mean_processor
+    g = load("loop_clip.npz")
+    want = T(g[f"px.dyn{int(dyn)}.clip{int(clip)}"])
+    assert torch.equal(D.process_xstart(T(g["px.x"]), clip, dyn), want)
+    for name in ("epsilon", "start_x", "previous_x"):
+        proc = get_mean_processor(name, betas=D.named_beta_schedule("linear", 1000), dynamic_threshold=dyn, clip_denoised=clip)
+        assert torch.equal(proc.process_xstart(T(g["px.x"])), want), name
+
+
 def test_fp16_reference_fixture_is_consistent():
     """tests/golden/fp16_reference.npz (round 4: the real reference with convert_to_fp16() applied): its fp32 half is the same
     network on the same inputs -- the oracle reproduces it -- and its fp16 half differs from it by the half-precision amount."""
