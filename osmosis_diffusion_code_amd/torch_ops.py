@@ -10,6 +10,8 @@ registered for the "cuda" device type only, which is HIP on ROCm).
     osmosis::unet_bwd_data(grad_out, engine) -> dx          the recorded data-gradient plan of the same engine
     osmosis::posterior(model_out, x, coef) -> (pred_xstart, mean, log_variance)     gaussian_diffusion.py:349-376 +
                                                            posterior_mean_variance.py (every registered processor pair)
+    osmosis::posterior_clip(...) -> (pred_xstart clamped, mean, log_variance, raw prediction), osmosis::clamp_bwd(g, raw) -> masked g
+                                                           (`clip_denoised: True` of the shipped rgb-guidance config)
     osmosis::posterior_bwd(g, coef) -> d_model_out         d(pred_xstart)/d(model_out)^T g  (the chain rule into the UNet)
     osmosis::guide_update(mean, log_variance, g, dx_unet, noise, coef, scale4, clip) -> (x_next, grad)
                                                            condition_methods.py:186-221 update rule + the noise add of :262-271
@@ -116,6 +118,35 @@ def _posterior_fake(model_out, x, coef, mean_kind=0, var_kind=0):
     return torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
 
 
+@torch.library.custom_op("osmosis::posterior_clip", mutates_args=(), device_types="cuda")
+def posterior_clip(model_out: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, mean_kind: int = 0,
+                   var_kind: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """osmosis::posterior with `clip_denoised` (process_xstart, posterior_mean_variance.py:43-50; configs/rgb_guidance_sample_config.yaml):
+    (pred_xstart clamped to [-1, 1], mean formed from it, log_variance, the unclamped prediction for osmosis::clamp_bwd)."""
+    B, HW = _chw(x)
+    x0, mean, logvar, raw = (torch.empty_like(x) for _ in range(4))
+    ops.posterior(model_out.contiguous(), x, coef, x0, mean, logvar, B, HW, mean_kind, var_kind, x0_raw=raw)
+    return x0, mean, logvar, raw
+
+
+@posterior_clip.register_fake
+def _posterior_clip_fake(model_out, x, coef, mean_kind=0, var_kind=0):
+    return torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+
+
+@torch.library.custom_op("osmosis::clamp_bwd", mutates_args=(), device_types="cuda")
+def clamp_bwd(g: torch.Tensor, x_raw: torch.Tensor, lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
+    """g where lo <= x_raw <= hi, 0 elsewhere (NaN included): the backward of x_raw.clamp(lo, hi) on a gradient (osm_clamp_bwd)."""
+    out = g.detach().clone().contiguous()
+    ops.clamp_bwd(out, x_raw.contiguous(), lo, hi)
+    return out
+
+
+@clamp_bwd.register_fake
+def _clamp_bwd_fake(g, x_raw, lo=-1.0, hi=1.0):
+    return torch.empty_like(g)
+
+
 @torch.library.custom_op("osmosis::posterior_bwd", mutates_args=(), device_types="cuda")
 def posterior_bwd(g: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
     B, HW = _chw(g)
@@ -220,4 +251,4 @@ def _phys_loss_grad_fake(x0, y, phi, icfg, fcfg, n_inner, freeze_phi):
     return x0.new_empty((x0.shape[0],)), torch.empty_like(x0), torch.empty_like(phi)
 
 
-OPS = ("unet_fwd", "unet_bwd_data", "posterior", "posterior_bwd", "guide_update", "guide_update_rng", "ddim_update", "phys_loss_grad")
+OPS = ("unet_fwd", "unet_bwd_data", "posterior", "posterior_clip", "clamp_bwd", "posterior_bwd", "guide_update", "guide_update_rng", "ddim_update", "phys_loss_grad")

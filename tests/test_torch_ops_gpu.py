@@ -166,3 +166,10 @@ def test_guidance_operators_match_the_in_place_calls_and_opcheck():
     assert torch.equal(g3, g_ps) and torch.equal(l3, l_ps)
     with pytest.raises(Exception, match="no parameters"):
         torch.ops.osmosis.phys_loss_grad(x0s, y, phi0, icfg3, fcfg3, 1, False)
+    # clip_denoised of the shipped rgb-guidance config: clamped posterior + the clamp's backward as functional operators
+    xc, mc, lc, raw = torch.ops.osmosis.posterior_clip(model_out, x, coef)
+    assert torch.equal(raw, x0) and torch.equal(xc, x0.clamp(-1, 1)) and torch.equal(lc, lv) and float(xc.abs().max()) == 1.0
+    gm = torch.ops.osmosis.clamp_bwd(gx0, raw)
+    assert torch.equal(gm, torch.where(raw.abs() <= 1.0, gx0, torch.zeros_like(gx0))) and not torch.equal(gm, gx0)
+    torch.library.opcheck(torch.ops.osmosis.posterior_clip.default, (model_out, x, coef))
+    torch.library.opcheck(torch.ops.osmosis.clamp_bwd.default, (gx0, raw))
