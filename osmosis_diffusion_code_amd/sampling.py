@@ -153,10 +153,15 @@ def output_images(post, ref_img, gt_rgb_01=None, gt_depth_01=None):
 
 
 def save_outputs(post, ref_img, out_dir, name, global_ii=0, save_singles=True, save_grids=True, gt_rgb_01=None,
-                 gt_depth_01=None):
+                 gt_depth_01=None, rgb_guidance=None):
     """Writes what the reference writes for one image (osmosis_sampling.py:84-104 directory layout, :319-353 files):
     `<out_dir>/single_images/{input,rgb,depth_color,depth_raw}/<name>.png` and `<out_dir>/grid_results/<name>_g<ii>_grid.png`.
-    Returns {kind: path}.  (`<name>_process.png` is written by the sampler itself when `record` is on.)"""
+    Returns {kind: path}.  (`<name>_process.png` is written by the sampler itself when `record` is on.)
+    A result of the rgb-guidance branch (`restore_image` with `rgb_guidance: True`: the dict carries `sample`, no phi; override
+    with `rgb_guidance=`) is written as the reference's second branch writes it (:382-401): the same four single images -- the
+    min-max depth as a three-channel PNG, it is `depth.repeat(3, 1, 1)` there -- and the grid as `<name>.png`."""
+    if rgb_guidance is None:
+        rgb_guidance = "sample" in post and "phi" not in post
     from PIL import Image
     imgs = output_images(post, ref_img, gt_rgb_01, gt_depth_01)
     paths = {}
@@ -169,7 +174,7 @@ def save_outputs(post, ref_img, out_dir, name, global_ii=0, save_singles=True, s
     if save_grids:
         d = os.path.join(out_dir, "grid_results")
         os.makedirs(d, exist_ok=True)
-        paths["grid"] = os.path.join(d, f"{name}_g{global_ii}_grid.png")
+        paths["grid"] = os.path.join(d, f"{name}.png" if rgb_guidance else f"{name}_g{global_ii}_grid.png")
         Image.fromarray(imgs["grid"], mode="RGB").save(paths["grid"])
     return paths
 

@@ -202,6 +202,32 @@ def test_output_grid_with_ground_truth_row(tmp_path):
     assert list(only) == ["grid"]
 
 
+def test_rgb_guidance_result_is_written_like_the_reference_second_branch(tmp_path):
+    """The rgb-guidance branch of the driver (osmosis_sampling.py:361-401): the same `single_images/*` directories -- the min-max depth
+    there is `depth.repeat(3, 1, 1)`, i.e. a three-channel PNG -- and the grid as `<name>.png` (the osmosis branch: `<name>_g<ii>_grid.png`),
+    tiles [input, clipped rgb, viridis depth] through the same make_grid / clip_image / to_pil_image calls."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(12)
+    sample = torch.randn(1, 4, 24, 40, generator=g) * 0.6
+    ref = torch.rand(1, 3, 24, 40, generator=g) * 2 - 1
+    depth3 = sample[0, -1].repeat(3, 1, 1)
+    res = {"sample": sample, "rgb": sample[0, 0:-1], "rgb_01_clip": torch.clamp(0.5 * (sample[0, 0:-1] + 1), 0, 1),
+           "depth_mm": U.min_max_norm_range(depth3, vmin=0, vmax=1, is_uint8=False),
+           "depth_pmm": U.min_max_norm_range_percentile(depth3, percent_low=0.05, percent_high=0.99), "measurement": ref}
+    paths = sampling.save_outputs(res, ref, str(tmp_path), "frame_3")
+    assert paths["grid"].endswith(os.path.join("grid_results", "frame_3.png"))
+    assert sorted(os.listdir(tmp_path / "single_images")) == ["depth_color", "depth_raw", "input", "rgb"]
+    raw = Image.open(paths["depth_raw"])
+    assert raw.mode == "RGB" and raw.size == (40, 24)
+    arr = np.asarray(raw)
+    assert np.array_equal(arr[..., 0], arr[..., 1]) and np.array_equal(arr[..., 0], (res["depth_mm"][0] * 255).to(torch.uint8).numpy())
+    imgs = sampling.output_images(res, ref)
+    assert np.array_equal(np.asarray(Image.open(paths["grid"])), imgs["grid"]) and imgs["grid"].shape == (24 + 4, 3 * 40 + 8, 3)
+    # an explicit override keeps the osmosis naming
+    p2 = sampling.save_outputs(res, ref, str(tmp_path), "frame_3", global_ii=2, save_singles=False, rgb_guidance=False)
+    assert p2["grid"].endswith("frame_3_g2_grid.png")
+
+
 # ----------------------------------------------------------------------------- YAML -> cfg (VERDICT r04 item 5 iv)
 def _ref_configs():
     import json
