@@ -4,11 +4,11 @@
 
 `p_sample_loop` keeps the reference signature and return values.  For the Osmosis configuration
 (pretrain_model == 'osmosis', our UNetModel, the 'osmosis' conditioning method with
-gradient_x_prev, epsilon / learned_range processors) every step runs as ONE device-resident
-sequence with no host synchronisation:
+gradient_x_prev, any registered mean / variance processor pair, clip_denoised or not) every step runs as
+ONE device-resident sequence with no host synchronisation:
 
-    fetch_coefs -> UNet forward plan -> osm_posterior -> [osm_phys_reduce/finalize x n_iter ->
-    osm_phys_grad] -> osm_posterior_bwd -> UNet data-gradient plan -> osm_guide_update
+    fetch_coefs -> UNet forward plan -> osm_posterior_typed -> [osm_phys_reduce/finalize x n_iter ->
+    osm_phys_grad] -> [osm_clamp_bwd] -> osm_posterior_bwd -> UNet data-gradient plan -> osm_guide_update
 
 (the reference performs 4 + n_iter device->host copies per step: gaussian_diffusion.py:216,276,288,
 condition_methods.py:130,224).  Per-timestep coefficients live in a device table indexed by a
@@ -17,8 +17,8 @@ configuration (`rgb_guidance=True`: DDPM / DDIM `p_sample` + 'ps' conditioning o
 gaussian noiser) runs through the same loop: osm_phys_* with the identity operator (kind 3) for
 ||y - x0[:, 0:3]|| and its gradient, osm_guide_update(_rng) or osm_ddim_update for the step.  The per-step
 noise is drawn inside the update kernel (Philox-4x32-10) unless `noise="aten"` asks for torch's stream.
-Any other combination (third-party conditioners / operators / processors) falls back to a generic loop
-that follows the reference control flow on top of the HIP UNet operator through torch.autograd.
+Any other combination (third-party conditioners / operators / processors, dynamic_threshold) falls back to a
+generic loop that follows the reference control flow on top of the HIP UNet operator through torch.autograd.
 """
 import math
 
