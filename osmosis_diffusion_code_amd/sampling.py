@@ -184,6 +184,17 @@ def depth_color(post):
     return utilso.depth_tensor_to_color_image(post["depth_pmm"])
 
 
+def rgb_guidance_result(sample, measurement):
+    """What the reference driver derives from the sample of an rgb-guidance / non-osmosis chain (osmosis_sampling.py:366-380; image 0
+    of `sample`): RGB and depth split, the clipped [0, 1] RGB, the min-max and the percentile-normalised three-channel depth.  No phi,
+    no recomposition.  CPU tensors."""
+    depth3 = sample[0, -1].repeat(3, 1, 1)
+    return {"sample": sample, "rgb": sample[0, 0:-1], "rgb_01_clip": torch.clamp(0.5 * (sample[0, 0:-1] + 1), 0, 1),
+            "depth_mm": utilso.min_max_norm_range(depth3, vmin=0, vmax=1, is_uint8=False),
+            "depth_pmm": utilso.min_max_norm_range_percentile(depth3, percent_low=0.05, percent_high=0.99),
+            "measurement": measurement}
+
+
 def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, same_seed_per_image=False,
                   postprocess_batch=True, **loop_kwargs):
     """One image through the reference's per-image sequence: fresh operator / noiser / conditioning method /
@@ -230,14 +241,7 @@ def restore_image(model, ref_img, cfg, device=None, image_idx=0, x_scale=1.0, sa
         if rgb_guidance or pretrain != "osmosis":
             # the rgb-guidance / non-osmosis chain returns the sample only (gaussian_diffusion.py:340); the
             # reference driver splits it into RGB and depth (osmosis_sampling.py:366-380): no phi, no recomposition
-            sample = ret.detach().cpu()
-            depth3 = sample[0, -1].repeat(3, 1, 1)
-            results.append({"sample": sample, "rgb": sample[0, 0:-1],
-                            "rgb_01_clip": torch.clamp(0.5 * (sample[0, 0:-1] + 1), 0, 1),
-                            "depth_mm": utilso.min_max_norm_range(depth3, vmin=0, vmax=1, is_uint8=False),
-                            "depth_pmm": utilso.min_max_norm_range_percentile(depth3, percent_low=0.05,
-                                                                              percent_high=0.99),
-                            "measurement": y_n.detach().cpu()})
+            results.append(rgb_guidance_result(ret.detach().cpu(), y_n.detach().cpu()))
             continue
         sample, variable_dict, loss, out_xstart = ret
         if postprocess_batch:
@@ -283,8 +287,7 @@ def restore_images(model, images, cfg, rank=0, world=1, device=None, gt_rgb=None
                     r.update(sample=full["sample"][b:b + 1], pred_xstart=full["pred_xstart"][b:b + 1],
                              measurement=full["measurement"][b:b + 1])
             else:
-                res = [{"sample": full["sample"][b:b + 1],
-                        "rgb_01_clip": torch.clamp(0.5 * (full["sample"][b, 0:3] + 1), 0, 1)} for b in range(len(idxs))]
+                res = [rgb_guidance_result(full["sample"][b:b + 1], full["measurement"][b:b + 1]) for b in range(len(idxs))]
         for i, r in zip(idxs, res):
             if gt_rgb is not None:
                 r["psnr"] = float(utilso.psnr(r["rgb_01_clip"], gt_rgb[i]))

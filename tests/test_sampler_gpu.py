@@ -518,6 +518,36 @@ def test_shipped_rgb_guidance_config_runs_on_the_fused_kernels(pkg, monkeypatch)
     assert float((ref.cpu()[0] - a["rgb"]).norm()) < 0.5 * float(ref.cpu().norm())      # the guidance pulled the RGB channels to y
 
 
+def test_shipped_rgb_guidance_config_batched_and_sharded_driver(pkg, tmp_path):
+    """`sampling.restore_images` with the shipped rgb-guidance configuration (respaced to 40 steps to keep the test short): three
+    images as one batch of two + one single give, image by image, what three batch-1 runs give (independent chains: per-image norm,
+    per-image noise stream), and every result -- batched ones included -- is written by `save_outputs` as the reference's second
+    driver branch writes it."""
+    import copy
+    import json
+    unet, gd, M, CM = pkg
+    from osmosis_diffusion_code_amd import sampling
+    with open(os.path.join(GOLD, "configs.json")) as f:
+        cfg = copy.deepcopy(json.load(f)["rgb_guidance_sample_config.yaml"])
+    cfg["diffusion"]["timestep_respacing"] = "40"
+    model = make_model(unet)
+    g = torch.Generator().manual_seed(31)
+    images = [(torch.rand(1, 3, 32, 32, generator=g) * 1.6 - 0.8).to(DEV) for _ in range(3)]
+    one = sampling.restore_images(model, images, cfg, batch_size=1, noise_seed=3)
+    two = sampling.restore_images(model, images, cfg, batch_size=2, noise_seed=3)
+    assert sorted(one) == sorted(two) == [0, 1, 2]
+    for i in range(3):
+        err = float((one[i]["sample"] - two[i]["sample"]).abs().max())
+        assert err < 2e-5, (i, err)
+        assert set(two[i]) >= {"sample", "rgb", "rgb_01_clip", "depth_mm", "depth_pmm", "measurement"}
+        paths = sampling.save_outputs(two[i], images[i], str(tmp_path), f"img{i}")
+        assert paths["grid"].endswith(f"img{i}.png") and all(os.path.getsize(p) > 0 for p in paths.values())
+    assert not torch.equal(one[0]["sample"], one[1]["sample"])
+    # ranks: images[rank::world], no collective
+    r1 = sampling.restore_images(model, images, cfg, rank=1, world=2, batch_size=1, noise_seed=3)
+    assert sorted(r1) == [1] and torch.equal(r1[1]["sample"], one[1]["sample"])
+
+
 @pytest.mark.parametrize("mode", ["osmosis", "ps.ddpm"])
 def test_previous_x_raises_where_the_reference_raises(pkg, mode):
     """`previous_x` returns the network's split output as the mean, and the Osmosis branch / DDPM.p_sample add to it in place: the
