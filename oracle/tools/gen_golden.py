@@ -81,6 +81,32 @@ def randomize_(module, seed):
                 p.copy_(torch.randn(p.shape, generator=g) * (0.5 / np.sqrt(fan)))
 
 
+def to_pil_u8(pic):
+    """torchvision 0.14.1 to_pil_image on a float tensor (absent from this image): pic.mul(255).byte() -- truncation -- then HWC."""
+    if pic.dim() == 2:
+        pic = pic.unsqueeze(0)
+    a = pic.mul(255).byte().permute(1, 2, 0).numpy()
+    return a[:, :, 0] if a.shape[2] == 1 else a
+
+
+def tv_make_grid(lst, nrow=8, pad_value=0.0, padding=2):
+    """torchvision 0.14.1 utils.make_grid for a list of equally sized [C,H,W] tensors, normalize=False."""
+    t = torch.stack(lst, dim=0)
+    nmaps = t.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(np.ceil(float(nmaps) / xmaps))
+    height, width = int(t.size(2) + padding), int(t.size(3) + padding)
+    grid = t.new_full((t.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for yy in range(ymaps):
+        for xx in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, yy * height + padding, height - padding).narrow(2, xx * width + padding, width - padding).copy_(t[k])
+            k += 1
+    return grid
+
+
 def gen_schedules():
     out = {}
     for tag, kw in {"T1000": dict(steps=1000, timestep_respacing=1000),
@@ -471,16 +497,23 @@ def _gen_full_step_one(m, opname, st, fname):
 def gen_prior():
     """Unconditional RGBD-prior sampler (osmosis_utils/diffusion.py:59-130): last 6 steps of the
     1000-step chain (t = 6..1) on the tiny seeded UNet.  The reference only defines its return values
-    when it records, so recording is on with the two visualisation sinks replaced by no-ops."""
+    when it records, so recording is on (record_every = 2: snapshots at t = 6, 4, 2, 1); its two torchvision calls (make_grid,
+    to_pil_image: absent from this image) are served by the 0.14.1 restatements above, and the process grid it "saves"
+    (`image_<idx>_process.png`, :124-128) is captured as a uint8 array."""
     import tempfile
     from osmosis_utils import diffusion as R_diff
     m, cfg, sd = tiny_model()
-    R_diff.make_grid = lambda *a, **k: torch.zeros(3, 4, 4)
+    saved = {}
 
     class _Img:
-        def save(self, *a, **k):
-            pass
-    R_diff.tvtf.to_pil_image = lambda *a, **k: _Img()
+        def __init__(self, arr):
+            self.arr = arr
+
+        def save(self, path, *a, **k):
+            saved[os.path.basename(path)] = self.arr
+    # torchvision is absent: its two calls are served by the restatements above (as gen_outputs does)
+    R_diff.make_grid = lambda lst, nrow=8, pad_value=0.0, **k: tv_make_grid(lst, nrow=nrow, pad_value=pad_value)
+    R_diff.tvtf.to_pil_image = lambda pic, *a, **k: _Img(to_pil_u8(pic))
     diff = R_diff.GaussianDiffusion(T=1000, schedule="linear")
     x_T = 0.3 * torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(3))
     draws, xs = [], []
@@ -499,13 +532,14 @@ def gen_prior():
     torch.randn_like = logged
     try:
         x, (rgb, depth_color) = diff.inverse(net=net, shape=(4, 32, 32), image_channels=4, steps=6, x=x_T.clone(),
-                                             start_t=6, device="cpu", record_process=True, record_every=1000,
-                                             save_path=tempfile.mkdtemp(), image_idx=0)
+                                             start_t=6, device="cpu", record_process=True, record_every=2,
+                                             save_path=tempfile.mkdtemp(), image_idx=7)
     finally:
         torch.randn_like = orig
     assert len(draws) == 5 and len(xs) == 6
     np.savez_compressed(os.path.join(OUT, "prior_inverse.npz"), x_T=npy(x_T), noise=np.stack([npy(d) for d in draws]),
                         x_steps=np.stack([npy(v) for v in xs]), x_final=npy(x), x_start_rgb=npy(rgb),
+                        x_depth_color=npy(depth_color), process_png=saved["image_7_process.png"],
                         beta=diff.beta, alphabar=diff.alphabar,
                         cosine_beta=R_diff.GaussianDiffusion(T=50, schedule="cosine").beta)
 
@@ -751,28 +785,6 @@ def gen_outputs():
     tensor = pic.mul(255).byte() (truncation); make_grid(list, nrow=3, pad_value=1.) = stack, 2-pixel padding, row-major tiles.
     A second case carries the ground-truth row of the simulation config (:341-344)."""
     from osmosis_utils import utils as R_u
-
-    def to_pil_u8(pic):
-        if pic.dim() == 2:
-            pic = pic.unsqueeze(0)
-        a = pic.mul(255).byte().permute(1, 2, 0).numpy()
-        return a[:, :, 0] if a.shape[2] == 1 else a
-
-    def tv_make_grid(lst, nrow, pad_value, padding=2):
-        t = torch.stack(lst, dim=0)
-        nmaps = t.size(0)
-        xmaps = min(nrow, nmaps)
-        ymaps = int(np.ceil(float(nmaps) / xmaps))
-        height, width = int(t.size(2) + padding), int(t.size(3) + padding)
-        grid = t.new_full((t.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
-        k = 0
-        for yy in range(ymaps):
-            for xx in range(xmaps):
-                if k >= nmaps:
-                    break
-                grid.narrow(1, yy * height + padding, height - padding).narrow(2, xx * width + padding, width - padding).copy_(t[k])
-                k += 1
-        return grid
 
     g = torch.Generator().manual_seed(77)
     H, W = 20, 28

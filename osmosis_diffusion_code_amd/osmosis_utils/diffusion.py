@@ -12,16 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
-
-
-def min_max_norm_range_percentile(img, vmin=0, vmax=1, percent_low=0.0, percent_high=1.0):
-    """utils.py:80-114 (float output): clip to the quantiles, then min-max normalise."""
-    lo, hi = torch.quantile(img, q=percent_low), torch.quantile(img, q=percent_high)
-    c = torch.clamp(img, lo, hi)
-    mn, mx = c.min(), c.max()
-    if mn == mx:
-        return torch.zeros_like(c)
-    return (c - mn) * ((float(vmax) - float(vmin)) / (mx - mn)) + float(vmin)
+from . import utils as utilso
 
 
 class GaussianDiffusion:
@@ -81,7 +72,24 @@ class GaussianDiffusion:
         z = torch.zeros(B, C, H, W, device=dev)
         x0 = torch.empty(B, C, H, W, device=dev)
         eng.x_in.copy_(x)
+        # `record_process` (reference :63-71, :106-128): at every t with t % record_every == 0, and at t = 1, keep x_t, the clipped RGB
+        # of the predicted x_0 and its colour-mapped depth; written at the end as ONE grid, `<save_path>/image_<idx>_process.png`
+        record = bool(kwargs.get("record_process", False)) and kwargs.get("save_path", None) is not None
+        record_every = int(kwargs.get("record_every", 200))
+        xt_list, rgb_list, depth_list = [], [], []
+
+        def views(x0_cpu):
+            x0v = 0.5 * (x0_cpu.squeeze() + 1)
+            rgb = torch.clamp(x0v[0:3], 0, 1)
+            dep = None
+            if image_channels == 4:
+                dep = utilso.depth_tensor_to_color_image(
+                    utilso.min_max_norm_range_percentile(x0v[3].unsqueeze(0), percent_low=0.05, percent_high=0.99))
+            return rgb, dep
         for k, t in enumerate(ts):
+            rec = record and ((t % record_every == 0) or t == 1)
+            if rec:
+                xt_list.append(torch.clamp(0.5 * (eng.x_in.detach().cpu().squeeze() + 1), 0, 1)[0:3])
             if t > 1:
                 if noise_fn is not None:
                     z.copy_(noise_fn(k, z.shape))
@@ -92,10 +100,22 @@ class GaussianDiffusion:
             ops.fetch_coefs(table, step, 1, coef, eng.t_dev, B)
             eng.run_forward()
             ops.ancestral_step(eng.out, eng.x_in, z, coef, eng.x_in, x0, B, C, eng.cout, HW)
+            if rec:
+                rgb, dep = views(x0.detach().cpu())
+                rgb_list.append(rgb)
+                if dep is not None:
+                    depth_list.append(dep)
         out = eng.x_in.clone()
-        x0v = 0.5 * (x0[0] + 1)
-        x_start_rgb = torch.clamp(x0v[0:3], 0, 1).cpu()
-        x_depth = None
-        if image_channels == 4:
-            x_depth = min_max_norm_range_percentile(x0v[3].unsqueeze(0).cpu(), percent_low=0.05, percent_high=0.99)
+        if record:
+            import os
+
+            from PIL import Image
+
+            from .. import sampling
+            grid = sampling.make_grid(xt_list + rgb_list + depth_list, nrow=len(xt_list), pad_value=1.0)
+            Image.fromarray(sampling._to_pil_u8(grid)).save(os.path.join(kwargs["save_path"], f"image_{kwargs.get('image_idx', 0)}_process.png"))
+        # the reference returns the LAST recorded views (t = 1 is always recorded) -- the clipped RGB of the predicted x_0 and the
+        # viridis image of its percentile-normalised depth -- and raises UnboundLocalError when it did not record; they are
+        # returned here either way
+        x_start_rgb, x_depth = views(x0[0:1].detach().cpu())
         return out, [x_start_rgb, x_depth]

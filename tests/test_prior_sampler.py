@@ -68,7 +68,30 @@ def test_hip_prior_sampler_matches_reference():
         e = float((x.cpu() - torch.from_numpy(g["x_final"])).abs().max())
         assert e < 1e-4, (mode, e)
         assert float((rgb - torch.from_numpy(g["x_start_rgb"])).abs().max()) < 1e-4
-        assert depth.shape == (1, 32, 32) and float(depth.min()) == 0.0 and abs(float(depth.max()) - 1.0) < 1e-6
+        # the second return value is the viridis image of the percentile-normalised depth (reference :117-120; until round 6 the
+        # un-mapped normalised depth was returned): the colour map is piecewise constant in 1/256 steps of a [0,1] depth, so a
+        # 1e-6 difference of the depth can move a pixel by one table entry (< 0.02 per channel), rarely
+        ref_col = torch.from_numpy(g["x_depth_color"])
+        assert depth.shape == (3, 32, 32) and depth.dtype == ref_col.dtype
+        dcol = (depth - ref_col).abs()
+        assert float(dcol.max()) < 0.03 and float((dcol > 0).float().mean()) < 0.02, (float(dcol.max()), float((dcol > 0).float().mean()))
+    # record_process: `<save_path>/image_<idx>_process.png` = make_grid(x_t | clipped RGB of x_0 | colour depth at t = 6, 4, 2, 1)
+    import tempfile
+
+    from PIL import Image
+    m.conv_mode = "f32"
+    d = tempfile.mkdtemp()
+    GaussianDiffusion(T=1000, schedule="linear").inverse(
+        net=m, shape=(4, 32, 32), image_channels=4, steps=6, x=torch.from_numpy(g["x_T"]).to("cuda:0"), start_t=6, device="cuda:0",
+        noise_fn=lambda k, shape: nz[k], record_process=True, record_every=2, save_path=d, image_idx=7)
+    png = np.asarray(Image.open(os.path.join(d, "image_7_process.png")))
+    want = g["process_png"]
+    assert png.shape == want.shape == (3 * 34 + 2, 4 * 34 + 2, 3)
+    diff = np.abs(png.astype(np.int32) - want.astype(np.int32))
+    print("process grid: pixels differing from the reference's", float((diff > 0).mean()), "max", int(diff.max()))
+    # uint8 truncation of values that differ by 1e-6: a few pixels move by one count (colour-map entries: by one table step)
+    assert float((diff > 0).mean()) < 0.01 and int(diff.max()) <= 6
+    assert np.array_equal(png[:2], want[:2]) and int(png[0, 0, 0]) == 255                     # pad_value = 1
 
 
 FULL_KW = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True, class_cond=False,
@@ -111,4 +134,4 @@ def test_config1_full_size_ten_step_chain_vs_oracle():
         print(f"config 1 full size, {mode}: x_final err {e:.2e} (max {float(rx.abs().max()):.2f})  clipped rgb of pred_xstart err {e_rgb:.2e}")
         assert e < 6e-6, (mode, e)
         assert e_rgb < 1e-3, (mode, e_rgb)
-        assert depth.shape == (1, 256, 256)
+        assert depth.shape == (3, 256, 256)                              # the colour-mapped depth (reference :117-120)
