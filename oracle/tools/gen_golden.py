@@ -22,6 +22,7 @@ Sections (SURVEY.md section 8c recipe):
                       fixed_small / fixed_large / learned variance processors
   loop_clip.npz       (round 6) `clip_denoised: True` (the shipped rgb-guidance config's setting): rgb-guidance chains, the Osmosis loop,
                       process_xstart with dynamic thresholding
+  loop_record.npz     (round 6) the `<name>_process.png` grid of p_sample_loop(record=True) as a uint8 array
   loop_ps.npz         rgb-guidance chains (`ps` conditioning) through DDPM.p_sample and DDIM.p_sample
   postprocess.npz     depth normalisation / colour map / convert_depth helpers of osmosis_utils/utils.py
   unet_variants.npz   (round 5) tiny UNets with conv up / down-sampling layers, additive conditioning, class conditioning
@@ -236,7 +237,7 @@ PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local
                n_iter=20, start_guidance=1, stop_guidance=0)
 
 
-def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=0.0, clip_denoised=False):
+def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=0.0, clip_denoised=False, record_kw=None):
     """10-step guided p_sample_loop of the reference (model m) for one operator spec; every randn_like draw logged."""
     operator = get_operator(device=torch.device("cpu"), batch_size=1, **spec["operator"])
     noiser = get_noise(name="clean")
@@ -278,8 +279,8 @@ def _loop_trace(m, spec, mean_type="epsilon", var_type="learned_range", perturb=
     try:
         img, variables, loss, x0 = sampler.p_sample_loop(
             model=m, x_start=x_T.clone().requires_grad_(), measurement=y, measurement_cond_fn=traced,
-            record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
-            sample_pattern=PATTERN)
+            record=record_kw is not None, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+            sample_pattern=PATTERN, **(record_kw or {}))
     finally:
         torch.randn_like = orig_randn_like
     # draws alternate: randn_like(measurement) [unused], randn_like(img) [used]  
@@ -709,6 +710,35 @@ def gen_clip():
     np.savez_compressed(os.path.join(OUT, "loop_clip.npz"), **out)
 
 
+def gen_record():
+    """(round 6) `record=True` of p_sample_loop (gaussian_diffusion.py:308-333): the 10-step guided loop of
+    loop_underwater_physical_revised.npz again with record_every = 3 -- snapshots of pred_xstart at idx 9, 6, 3, 0 -- and the
+    `<name>_process.png` grid the reference hands to to_pil_image, captured as a uint8 array (torchvision's make_grid / to_pil_image:
+    the 0.14.1 restatements above)."""
+    import tempfile
+    m, cfg, sd = tiny_model()
+    base = dict(np.load(os.path.join(OUT, "loop_underwater_physical_revised.npz")))
+    saved = {}
+
+    class _Img:
+        def __init__(self, arr):
+            self.arr = arr
+
+        def save(self, path, *a, **k):
+            saved[os.path.basename(path)] = self.arr
+    keep = (R_gd.make_grid, R_gd.tvtf.to_pil_image)
+    R_gd.make_grid = lambda lst, nrow=8, pad_value=0.0, **k: tv_make_grid(lst, nrow=nrow, pad_value=pad_value)
+    R_gd.tvtf.to_pil_image = lambda pic, *a, **k: _Img(to_pil_u8(pic))
+    try:
+        tr, loss, variables = _loop_trace(m, OPERATORS["underwater_physical_revised"],
+                                          record_kw=dict(record_every=3, save_grids_path=tempfile.mkdtemp(), original_file_name="frame"))
+    finally:
+        R_gd.make_grid, R_gd.tvtf.to_pil_image = keep
+    assert np.array_equal(tr["final_img"], base["final_img"])          # recording does not touch the chain
+    np.savez_compressed(os.path.join(OUT, "loop_record.npz"), process_png=saved["frame_process.png"])
+    print("process grid", saved["frame_process.png"].shape)
+
+
 def gen_postprocess():
     """Output post-processing helpers of osmosis_utils/utils.py (min_max_norm_range :46-74,
     min_max_norm_range_percentile :77-114, depth_tensor_to_color_image :748-763, convert_depth :544-566)
@@ -843,6 +873,7 @@ if __name__ == "__main__":
     gen_optimizers()
     gen_processors()
     gen_clip()
+    gen_record()
     gen_fp16()
     gen_full_unet()
     gen_full_step()

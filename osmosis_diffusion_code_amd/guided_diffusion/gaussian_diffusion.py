@@ -433,15 +433,10 @@ class GaussianDiffusion:
         dep = [utilso.depth_tensor_to_color_image(
             utilso.min_max_norm_range_percentile(x0[:, 3], percent_low=0.05, percent_high=0.99)) for _, x0 in records]
         dep = [d.reshape(3, *d.shape[-2:]) for d in dep]
-        tiles, ncol, pad = rgb + dep, len(rgb), 2
-        h, w = tiles[0].shape[-2:]
-        nrow = (len(tiles) + ncol - 1) // ncol
-        grid = torch.zeros(3, nrow * (h + pad) + pad, ncol * (w + pad) + pad)
-        for i, t in enumerate(tiles):
-            r, c = divmod(i, ncol)
-            grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + c * (w + pad): pad + c * (w + pad) + w] = t
-        # the reference writes this grid through tvtf.to_pil_image (:330-333), which TRUNCATES: pic.mul(255).byte()
-        arr = grid.clamp(0, 1).mul(255).permute(1, 2, 0).to(torch.uint8).numpy()
+        # torchvision.utils.make_grid(rgb + depth, nrow=len(rgb)) -> tvtf.to_pil_image (:330-333): the stack is float64 (the viridis
+        # depth), the background 0, and to_pil_image TRUNCATES (pic.mul(255).byte())
+        from .. import sampling
+        arr = sampling._to_pil_u8(sampling.make_grid(rgb + dep, nrow=len(rgb)))
         path = os.path.join(save_grids_path, f"{original_file_name}_process.png")
         Image.fromarray(arr).save(path)
         return path

@@ -594,6 +594,32 @@ def test_generic_loop_honours_record(pkg, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "img7_process.png"))
 
 
+def test_record_process_grid_matches_the_reference(pkg, tmp_path):
+    """`record=True` of the fused Osmosis loop: `<name>_process.png` (gaussian_diffusion.py:308-333: clipped RGB of pred_xstart on
+    the first row, viridis of its percentile-normalised depth on the second, make_grid(nrow = snapshots) -> to_pil_image) vs the array
+    the REAL reference hands to to_pil_image for the same 10-step chain (tests/golden/loop_record.npz; record_every = 3)."""
+    from PIL import Image
+    unet, gd, M, CM = pkg
+    g, want = np.load(os.path.join(GOLD, "loop_underwater_physical_revised.npz")), np.load(os.path.join(GOLD, "loop_record.npz"))["process_png"]
+    spec = OPERATORS["underwater_physical_revised"]
+    model = make_model(unet)
+    operator = M.get_operator("underwater_physical_revised", device=DEV, batch_size=1, **spec["operator"])
+    cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    noise = torch.from_numpy(g["noise"]).to(DEV)
+    make_sampler(gd).p_sample_loop(
+        model=model, x_start=torch.from_numpy(g["x_T"]).to(DEV), measurement=torch.from_numpy(g["y"]).to(DEV),
+        measurement_cond_fn=cond.conditioning, record=True, save_root=None, pretrain_model="osmosis", rgb_guidance=False,
+        sample_pattern=PATTERN, noise_fn=lambda k, shape: noise[k], record_every=3, save_grids_path=str(tmp_path),
+        original_file_name="frame")
+    png = np.asarray(Image.open(os.path.join(str(tmp_path), "frame_process.png")))
+    assert png.shape == want.shape == (2 * 34 + 2, 4 * 34 + 2, 3)
+    diff = np.abs(png.astype(np.int32) - want.astype(np.int32))
+    print("process grid: fraction of differing pixels", float((diff > 0).mean()), "max difference", int(diff.max()))
+    # truncation to uint8 of values that differ by ~1e-6, and one-entry moves of the colour map: a handful of pixels, small steps
+    assert float((diff > 0).mean()) < 0.01 and int(diff.max()) <= 6
+    assert int(png[0, 0, 0]) == 0                                                  # make_grid's default pad_value
+
+
 def test_library_step_noise(pkg):
     """Round 6: the per-step noise is drawn inside osm_guide_update_rng (Philox-4x32-10, counter = (element / 4, image, step)).
     (i) the raw generator reproduces the Random123 known-answer vectors; (ii) osm_randn has the moments of N(0, 1) and
