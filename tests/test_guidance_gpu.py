@@ -235,6 +235,50 @@ def test_physics_phi_adam(mods, opname, optimizer):
     assert moved > (5e-3 if optimizer == "adam" else 2e-4)          # the optimizer really stepped
 
 
+@pytest.mark.parametrize("opname", list(OPS))
+def test_conditioning_five_tuple_of_the_reference_api(mods, opname):
+    """`PosteriorSamplingOsmosis.conditioning(x_prev=, x_t=, x_0_hat=, measurement=, freeze_phi=)` as third-party code calls it
+    (condition_methods.py:146-231): x_t updated in place, sep_loss ndarray[B], the variables dict, the unclipped gradient on the
+    CPU, and the auxiliary-loss dictionary (losses.py:67-83: un-weighted terms, detached, on the CPU; avrg_loss :29-45 = sum_c
+    |mean_hw rgb_c|, val_loss :50-62 = mean(max(|rgb| - 0.7, 0)^2)) -- vs the oracle's conditioning and those two formulas."""
+    ops, M, CM = mods
+    okw, ckw = OPS[opname]
+    g = torch.Generator().manual_seed(13)
+    H = W = 24
+    xp = 0.7 * torch.randn(1, 4, H, W, generator=g)
+    y = torch.rand(1, 3, H, W, generator=g) * 1.6 - 0.8
+    mean0 = 0.5 * torch.randn(1, 4, H, W, generator=g)
+    a, b = 0.83, 0.21                                                # pred_xstart as a differentiable function of x_prev
+    # oracle
+    op = D.PhysOperator(opname, batch_size=1, **okw)
+    guide = D.OsmosisGuidance(op, n_iter=20, **ckw)
+    xr = xp.clone().requires_grad_(True)
+    x0r = a * xr + b * torch.tanh(xr)
+    xt_ref, sep_ref, var_ref, g_ref = guide.conditioning(xr, mean0.clone(), x0r, y, freeze_phi=False)
+    # product
+    oper = M.get_operator(opname, device=DEV, batch_size=1, **okw)
+    cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), loss_function="norm", loss_weight="depth",
+                                      weight_function="gamma,1.4,1.4,1", scale=ckw["scale"], gradient_x_prev=True,
+                                      gradient_clip=ckw["gradient_clip"], n_iter=20, aux_loss=ckw["aux"], pattern="pcgs")
+    xd = xp.to(DEV).requires_grad_(True)
+    x0d = a * xd + b * torch.tanh(xd)
+    x_t = mean0.to(DEV).clone()
+    ret = cond.conditioning(x_prev=xd, x_t=x_t, x_0_hat=x0d, measurement=y.to(DEV), noisy_measurement=None, freeze_phi=False,
+                            time_index=0.3)
+    assert len(ret) == 5 and ret[0] is x_t                                      # in place, and returned
+    assert torch.allclose(x_t.cpu(), xt_ref, atol=2e-6)
+    assert isinstance(ret[1], np.ndarray) and ret[1].shape == (1,) and np.allclose(ret[1], sep_ref, rtol=1e-5)
+    assert set(ret[2]) == set(var_ref)
+    for n in var_ref:
+        assert ret[2][n].shape == var_ref[n].shape and torch.allclose(ret[2][n].cpu(), var_ref[n], atol=1e-6), n
+    assert ret[3].device.type == "cpu" and torch.allclose(ret[3], g_ref, atol=2e-6 * float(g_ref.abs().max()) + 1e-7)
+    rgb = x0r.detach()[:, 0:3]
+    want = {"avrg_loss": rgb.mean(dim=(2, 3)).abs().sum(), "val_loss": (torch.clamp(rgb.abs() - 0.7, min=0) ** 2).mean()}
+    assert set(ret[4]) == set(ckw["aux"])
+    for n in ret[4]:
+        assert ret[4][n].device.type == "cpu" and ret[4][n].dim() == 0 and abs(float(ret[4][n]) - float(want[n])) < 1e-6 * max(1.0, float(want[n])), n
+
+
 @pytest.mark.parametrize("optimizer,freeze", [("sgd", False), ("adam", False), ("sgd", True)])
 def test_phys_optimize_equals_the_launch_by_launch_loop(mods, monkeypatch, optimizer, freeze):
     """osm_phys_optimize (the inner phi loop enqueued by ONE C call) issues exactly the launches of the per-launch entry points
