@@ -53,6 +53,15 @@ COND = dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.
 PATTERN = dict(pattern="pcgs", update_start=0.7, update_end=0, global_N=1, local_M=1, s_start=1, s_end=0, n_iter=20,
                start_guidance=1, stop_guidance=0)
 AUX = {"avrg_loss": 0.5, "val_loss": 20}
+# configs/rgb_guidance_sample_config.yaml as the reference parses it (the keys sampling.restore_image reads; pinned to
+# tests/golden/configs.json by tests/test_postprocess.py): ddpm, `ps` conditioning, clip_denoised True, gaussian noiser with sigma 0
+RGB_GUIDANCE = dict(
+    manual_seed=0, degamma_input=False, rgb_guidance=True, sample_pattern=PATTERN, unet_model=dict(pretrain_model="osmosis"),
+    diffusion=dict(DIFFUSION, clip_denoised=True),
+    conditioning=dict(method="ps", params=dict(loss_function="norm", loss_weight="depth", weight_function="gamma,1.4,1.4,1",
+                                               scale="3,3,3,0.1", gradient_x_prev=True, gradient_clip="False,0.001")),
+    aux_loss=dict(aux_loss=None),
+    measurement=dict(operator=dict(name="rgb_guidance"), noise=dict(name="gaussian", sigma=0)))
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 
@@ -252,6 +261,40 @@ def full_chain(args, dev, model):
             "finite_outputs": bool(torch.isfinite(res["pred_xstart"]).all() and torch.isfinite(res["sample"]).all()),
             "finite_note": "seeded synthetic weights: the free-running chain leaves the physical model's range from t ~ 0.7 T in "
                            "every arithmetic and in the reference itself (SURVEY F10); timing is value independent"}
+
+
+def rgb_guidance_chain(args, dev, model):
+    """ONE COMPLETE image of the reference's SHIPPED rgb-guidance configuration (configs/rgb_guidance_sample_config.yaml: DDPM.p_sample
+    + `ps` conditioning on the identity operator, clip_denoised True) through `sampling.restore_image` on the headline
+    network: all 1000 steps on the fused kernels (UNet forward and input gradient, osm_posterior_typed with the clamp, osm_phys_*
+    kind 3, osm_clamp_bwd, osm_guide_update_rng).  The clamp bounds pred_xstart, so this chain stays FINITE on seeded weights from
+    x_T ~ N(0, I) to the end -- the one complete full-size chain of the bench line whose outputs are finite."""
+    from osmosis_diffusion_code_amd import sampling
+    from osmosis_diffusion_code_amd.guided_diffusion import gaussian_diffusion as gd
+    _, y = synthetic_inputs(0, 1, args.image_size)
+    y = y.to(dev)
+    fell_back = []
+    orig = gd.GaussianDiffusion._generic_loop
+
+    def spy(self, *a, **k):
+        fell_back.append(1)
+        return orig(self, *a, **k)
+    gd.GaussianDiffusion._generic_loop = spy
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sampling.restore_image(model, y, RGB_GUIDANCE, noise_seed=0)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gd.GaussianDiffusion._generic_loop = orig
+    T = int(DIFFUSION["steps"])
+    s = res["sample"]
+    return {"workload": "rgb_guidance_sample_config.yaml: one complete 1000-step image (ddpm + ps, clip_denoised), B = 1, seeded weights",
+            "steps": T, "wall_s": round(dt, 3), "denoise_steps_per_sec": round(T / dt, 3), "ms_per_step": round(1e3 * dt / T, 3),
+            "conv_arithmetic": model.conv_mode, "fused_loop": not fell_back, "finite_outputs": bool(torch.isfinite(s).all()),
+            "max_abs_sample": round(float(s.abs().max()), 4),
+            "rel_residual_rgb": round(float((y.cpu()[0] - res["rgb"]).norm() / y.cpu().norm()), 4)}
 
 
 def run_secondary(args, dev):
@@ -859,7 +902,7 @@ def main():
         if rank == 0 and backend == "nccl" and ndev >= world and not line["devices_distinct"]:
             raise SystemExit(f"bench.py: ranks shared a device ({line['per_rank_device']}) on a node with {ndev} GPUs")
     rl = breakdown = None
-    long_window = chain = None
+    long_window = chain = rgb_chain = None
     if rank == 0:               # replays the headline engine's plans: before the config-4 leg replaces that engine
         rl, breakdown = roofline(model, args)
         if world == 1 and not args.tiny and args.secondary_steps > 0 and not args.scale_only:     # (--secondary-steps 0 = the headline leg alone: profiling runs)
@@ -879,6 +922,10 @@ def main():
                     chain = full_chain(args, dev, model)
                 except Exception as e:
                     chain = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    rgb_chain = rgb_guidance_chain(args, dev, model)
+                except Exception as e:
+                    rgb_chain = {"error": f"{type(e).__name__}: {e}"[:300]}
     cfg4 = run_config4(args, dev, model, rank, world, sync) if (args.secondary_steps > 0 and not args.tiny) else None
     if rank == 0:
         line["roofline"] = rl
@@ -891,6 +938,8 @@ def main():
         line["kernel_breakdown_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in breakdown.items()}
         if long_window is not None:
             line["long_window"] = long_window
+        if rgb_chain is not None:
+            line["rgb_guidance_chain"] = rgb_chain
         if chain is not None:
             line["full_chain"] = chain
             if "images_per_sec" in chain:      # north_star's unit, measured over a whole chain (the extrapolation stays beside it)

@@ -282,3 +282,21 @@ def test_transcribed_configs_equal_the_reference_yaml(fname, ours, overrides):
                 continue
             want = overrides.get((sec, k), v)
             assert mine[sec][k] == want, (sec, k, mine[sec][k], want)
+
+
+def test_bench_rgb_guidance_config_equals_the_reference_yaml():
+    """bench.py's `rgb_guidance_chain` leg runs configs/rgb_guidance_sample_config.yaml: every key `sampling.restore_image` reads is the
+    reference's parsed value (tests/golden/configs.json)."""
+    import bench
+    ref, mine = _ref_configs()["rgb_guidance_sample_config.yaml"], bench.RGB_GUIDANCE
+    for sec in ("sample_pattern", "conditioning", "aux_loss", "measurement"):
+        assert mine[sec] == ref[sec], (sec, mine[sec], ref[sec])
+    for key in ("manual_seed", "degamma_input", "rgb_guidance"):
+        assert mine[key] == ref[key], key
+    for k, v in ref["diffusion"].items():
+        if k != "min_max_denoised":                      # read by nothing on the reference's path
+            assert mine["diffusion"][k] == v, (k, mine["diffusion"][k], v)
+    assert mine["unet_model"]["pretrain_model"] == ref["unet_model"]["pretrain_model"] == "osmosis"
+    for k, v in ref["unet_model"].items():               # the network the leg reuses is the headline's: the same architecture keys
+        if k not in ("model_path",):
+            assert bench.UNET_KW[k] == v, (k, bench.UNET_KW[k], v)
