@@ -165,3 +165,60 @@ def psnr(img, ref, data_range=1.0):
     d = (img.double() - ref.double()) ** 2
     mse = d.flatten(1).mean(dim=1) if d.dim() == 4 else d.mean()
     return 10.0 * torch.log10((float(data_range) ** 2) / mse)
+
+
+# ----------------------------------------------------------------------------- driver-side helpers the sampling scripts call
+def clip_image(img, scale=True, move=True, is_uint8=True):
+    """utils.py:138-159: [C,H,W] (or [H,W]) tensor, optionally (img + 1) / 2, to uint8 by clamp-and-truncate or to [0, 1].  The
+    reference multiplies IN PLACE when is_uint8 (a caller's tensor is scaled by 255 unless move / scale made a copy first); this
+    one never touches its argument."""
+    if img.dim() == 2:
+        img = img.unsqueeze(0)
+    if move:
+        img = img + 1
+    if scale:
+        img = 0.5 * img
+    if is_uint8:
+        return (img * 255).clamp(0, 255).to(torch.uint8)
+    return img.clamp(0, 1)
+
+
+def load_yaml(file_path: str) -> dict:
+    """utils.py:357-360 (yaml.FullLoader: '1e-5' and '32, 16, 8' stay strings)."""
+    import yaml
+    with open(file_path) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def arguments_from_file(config_file_path: str) -> argparse.Namespace:
+    """utils.py:466-476: the YAML file's top-level keys as attributes of a Namespace (nested sections stay dictionaries) -- what
+    osmosis_sampling.py / RGBD_prior_sampling.py read as `args.<section>[...]`.  `sampling.load_config` is the dictionary form."""
+    args = argparse.Namespace()
+    for k, v in load_yaml(config_file_path).items():
+        setattr(args, k, v)
+    return args
+
+
+def change_input_output_unet(model, in_channels=4, out_channels=8):
+    """utils.py:265-288 for this package's UNetModel: a new stem convolution (in_channels -> model channels) and a new head
+    convolution (-> out_channels), freshly initialised the way `nn.Conv2d` initialises (the reference swaps in new nn.Conv2d layers:
+    kaiming-uniform weights with a = sqrt(5), uniform bias), every other parameter kept.  `create_model(pretrain_model='osmosis')`
+    builds the 4 -> 8 network directly; this function serves callers that construct `UNetModel(in_channels=3, out_channels=6, ...)`
+    first, as RGBD_prior_sampling.py:62-69 does.  Returns the model."""
+    import math
+
+    from ..guided_diffusion.unet import _Slot
+    stem, head = model.input_blocks[0].at(0), model.out.at(2)
+    dev = stem.weight.device
+
+    def conv_slot(cout, cin):
+        slot = _Slot((cout, cin, 3, 3), (cout,))
+        torch.nn.init.kaiming_uniform_(slot.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * 9)
+        torch.nn.init.uniform_(slot.bias, -bound, bound)
+        return slot.to(dev)
+    model.input_blocks[0].add_module("0", conv_slot(stem.weight.shape[0], in_channels))
+    model.out.add_module("2", conv_slot(out_channels, head.weight.shape[1]))
+    model.in_channels, model.out_channels = in_channels, out_channels
+    model._engines, model._weights = {}, {}              # packed weight images and plans of the old shapes
+    return model

@@ -418,3 +418,46 @@ def test_recorder_suspended_runs_now_and_records_nothing():
                 raise RuntimeError("boom")
         assert _lib._state.recorders == [outer]
     assert _lib._state.recorders == [] and outer.calls == []
+
+
+def test_driver_side_helpers_of_osmosis_utils(tmp_path):
+    """The helpers the reference's sampling scripts call on `osmosis_utils.utils` (osmosis_sampling.py, RGBD_prior_sampling.py):
+    `change_input_output_unet` (utils.py:265-288) on this package's UNetModel, `clip_image` (:138-159), `load_yaml` /
+    `arguments_from_file` (:357-360, :466-476)."""
+    import math
+    from osmosis_diffusion_code_amd.guided_diffusion.unet import UNetModel, create_model
+    from osmosis_diffusion_code_amd.osmosis_utils import utils as U
+    # RGBD_prior_sampling.py:62-69: a 3 -> 6 network, then 4 -> 8
+    m = UNetModel(image_size=256, in_channels=3, out_channels=6, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2),
+                  attention_resolutions=[2, 4], num_head_channels=16, dropout=0.1, resblock_updown=True, use_scale_shift_norm=True)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    assert before["input_blocks.0.0.weight"].shape == (32, 3, 3, 3) and before["out.2.weight"].shape == (6, 32, 3, 3)
+    assert U.change_input_output_unet(m, in_channels=4, out_channels=8) is m
+    sd = m.state_dict()
+    changed = ("input_blocks.0.0.weight", "input_blocks.0.0.bias", "out.2.weight", "out.2.bias")
+    assert sd["input_blocks.0.0.weight"].shape == (32, 4, 3, 3) and sd["out.2.weight"].shape == (8, 32, 3, 3) and sd["out.2.bias"].shape == (8,)
+    assert (m.in_channels, m.out_channels) == (4, 8) and list(sd) == list(before)
+    assert all(torch.equal(before[k], sd[k]) for k in sd if k not in changed)
+    for k, fan_in in (("input_blocks.0.0", 4 * 9), ("out.2", 32 * 9)):           # nn.Conv2d's default initialisation
+        bound = 1.0 / math.sqrt(fan_in)
+        assert float(sd[k + ".weight"].abs().max()) <= bound and float(sd[k + ".bias"].abs().max()) <= bound
+        assert float(sd[k + ".weight"].std()) > 0.3 * bound
+    ref = create_model(image_size=256, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", attention_resolutions="128,64",
+                       num_head_channels=16, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True, pretrain_model="osmosis")
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    m.load_state_dict(ref.state_dict(), strict=True)          # a checkpoint of the 4 -> 8 network loads (RGBD_prior_sampling.py:72)
+    # clip_image
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(3, 5, 7, generator=g) * 1.5
+    keep = img.clone()
+    u8 = U.clip_image(img, scale=True, move=True, is_uint8=True)
+    assert u8.dtype == torch.uint8 and torch.equal(u8, ((0.5 * (img + 1)) * 255).clamp(0, 255).to(torch.uint8)) and torch.equal(img, keep)
+    assert torch.equal(U.clip_image(img, scale=False, move=False, is_uint8=True), (img * 255).clamp(0, 255).to(torch.uint8))
+    f = U.clip_image(img[0], scale=True, move=True, is_uint8=False)
+    assert f.shape == (1, 5, 7) and float(f.min()) >= 0.0 and float(f.max()) <= 1.0 and torch.equal(img, keep)
+    # YAML -> Namespace
+    p = tmp_path / "c.yaml"
+    p.write_text("manual_seed: 4321\nnumber_of_images: 5\ndiffusion:\n  steps: 1000\n  noise_schedule: linear\nunet_model:\n  model_path: ./m.pt\n  attention_resolutions: 32, 16, 8\n")
+    args = U.arguments_from_file(str(p))
+    assert args.manual_seed == 4321 and args.number_of_images == 5 and args.diffusion["steps"] == 1000
+    assert args.unet_model["attention_resolutions"] == "32, 16, 8" and U.load_yaml(str(p))["unet_model"]["model_path"] == "./m.pt"
