@@ -222,3 +222,17 @@ def change_input_output_unet(model, in_channels=4, out_channels=8):
     model.in_channels, model.out_channels = in_channels, out_channels
     model._engines, model._weights = {}, {}              # packed weight images and plans of the old shapes
     return model
+
+
+def get_optimizer(optimizer_name, model_parameters, **kwargs):
+    """utils.py:494-524: the torch optimizer of that (case-insensitive) name over `model_parameters` (parameter groups with their own
+    `lr`), None for 'GD' / '' (plain gradient descent done by hand), ValueError for an unknown name.  For third-party operators written
+    against the reference API; the package's own physical operators step phi inside osm_phys_finalize (measurements.OPTIMIZER_CODES)."""
+    name = optimizer_name.lower()
+    if name in ("gd", ""):
+        return None
+    table = {"adam": "Adam", "sgd": "SGD", "rmsprop": "RMSprop", "adagrad": "Adagrad", "adadelta": "Adadelta", "adamw": "AdamW",
+             "sparseadam": "SparseAdam", "adamax": "Adamax", "asgd": "ASGD", "lbfgs": "LBFGS", "rprop": "Rprop"}
+    if name not in table:
+        raise ValueError(f"Optimizer '{name}' is not supported.")
+    return getattr(torch.optim, table[name])(model_parameters, **kwargs)

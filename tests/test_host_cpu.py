@@ -461,3 +461,21 @@ def test_driver_side_helpers_of_osmosis_utils(tmp_path):
     args = U.arguments_from_file(str(p))
     assert args.manual_seed == 4321 and args.number_of_images == 5 and args.diffusion["steps"] == 1000
     assert args.unet_model["attention_resolutions"] == "32, 16, 8" and U.load_yaml(str(p))["unet_model"]["model_path"] == "./m.pt"
+
+
+def test_get_optimizer_factory():
+    """utils.get_optimizer (utils.py:494-524) as a third-party operator would call it: torch.optim classes by case-insensitive name
+    with per-group learning rates, None for GD, ValueError for an unknown name."""
+    from osmosis_diffusion_code_amd.osmosis_utils import utils as U
+    a, b = torch.zeros(3, requires_grad=True), torch.zeros(3, requires_grad=True)
+    groups = [{"params": a, "lr": 1e-3}, {"params": b, "lr": 2e-3}]
+    for name, cls in (("adam", torch.optim.Adam), ("SGD", torch.optim.SGD), ("RMSprop", torch.optim.RMSprop), ("adagrad", torch.optim.Adagrad),
+                      ("adadelta", torch.optim.Adadelta), ("AdamW", torch.optim.AdamW), ("adamax", torch.optim.Adamax),
+                      ("asgd", torch.optim.ASGD), ("rprop", torch.optim.Rprop), ("lbfgs", torch.optim.LBFGS)):
+        opt = U.get_optimizer(optimizer_name=name, model_parameters=[dict(g) for g in groups] if name != "lbfgs" else [a, b])
+        assert type(opt) is cls, name
+        if name != "lbfgs":
+            assert [g["lr"] for g in opt.param_groups] == [1e-3, 2e-3]
+    assert U.get_optimizer("GD", groups) is None and U.get_optimizer("", groups) is None
+    with pytest.raises(ValueError, match="not supported"):
+        U.get_optimizer("nadam", groups)
