@@ -75,6 +75,33 @@ def test_bench_eight_ranks_full_size_dry_run(tmp_path):
     assert single["image_index"] == 0 and single["sha1"] == ranks[0]["sha1"]
 
 
+def test_bench_single_gpu_line_with_the_whole_chain_legs():
+    """The N = 1 line the driver records (BENCH_rNN.json), with the slow side legs switched off (no PMC child runs, no CPU baseline,
+    one step of the config 3 / 5 legs): the contract fields, `long_window`, `full_chain` (one complete Osmosis image) and
+    `rgb_guidance_chain` (one complete image of the shipped rgb-guidance config: fused, FINITE outputs -- clip_denoised bounds the chain)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-steps", "0", "--pmc", "off",
+                          "--secondary-steps", "1", "--long-window", "8"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "denoise-steps/sec" and d["vs_baseline"] is None
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 4e-3)) < 1e-2 * d["value"] and 30 < d["value"] < 90
+    assert d["long_window"]["steps"] == 8 and d["long_window"]["finite_outputs"]
+    assert d["full_chain"]["steps"] == 1000 and 10 < d["full_chain"]["wall_s"] < 40
+    rg = d["rgb_guidance_chain"]
+    assert "error" not in rg, rg
+    assert rg["fused_loop"] is True and rg["finite_outputs"] is True and rg["steps"] == 1000 and rg["max_abs_sample"] < 1.5
+    assert 10 < rg["wall_s"] < 40 and abs(rg["ms_per_step"] - rg["wall_s"]) < 1e-6 * 1000
+    assert [s["workload"][:8] for s in d["secondary"]] == ["config 4", "config 3", "config 5"]
+
+
 def _bench_two(tmp, env_extra, tag):
     d = tmp / tag
     d.mkdir()
