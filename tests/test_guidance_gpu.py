@@ -184,6 +184,67 @@ def test_physics_loss_grad_and_phi_sgd(mods, opname, loss_function):
     assert float((gx0.cpu() - ref_g).abs().max()) < 2e-5 * scale + 1e-9
 
 
+def _random_case(seed):
+    """One seeded point of the option space of the operator / conditioning configs (measurements.py, condition_methods.py:63-107,
+    utils.py:544-566, :674-700, losses.py): operator, depth type and values, loss function, loss weight and its function, auxiliary
+    losses, learn flags, step sizes, inner iterations, image size."""
+    r = np.random.RandomState(seed)
+    opname = ["underwater_physical_revised", "underwater_physical", "haze_physical"][r.randint(3)]
+    depth_type = ["gamma", "original", "move"][r.randint(3)]
+    value = {"gamma": f"{r.uniform(1.1, 1.6):.3f},{r.uniform(0.8, 1.5):.3f},{[1, 1, 1.5][r.randint(3)]}", "original": "1.4,1.4,1",
+             "move": round(float(r.uniform(1.05, 1.5)), 3)}[depth_type]      # (a YAML number: the reference adds a numpy array to a
+    #                                                                   graph tensor when `value` is a string here, which raises)
+    f3 = lambda lo, hi: ",".join(f"{v:.3f}" for v in r.uniform(lo, hi, 3))   # noqa: E731
+    okw = dict(depth_type=depth_type, value=value, phi_inf=f3(0.1, 0.7), phi_inf_eta=f"{r.choice([1e-3, 1e-4, 5e-3])}",
+               phi_inf_learn_flag=bool(r.rand() > 0.2))
+    if opname == "underwater_physical_revised":
+        okw.update(phi_a=f3(0.7, 1.2), phi_b=f3(0.6, 1.1), phi_a_eta=f"{r.choice([1e-3, 2e-3])}", phi_b_eta=f"{r.choice([1e-3, 5e-4])}",
+                   phi_a_learn_flag=bool(r.rand() > 0.2), phi_b_learn_flag=bool(r.rand() > 0.2))
+    elif opname == "underwater_physical":
+        okw.update(phi_ab=f3(0.7, 1.2), phi_ab_eta=f"{r.choice([1e-3, 2e-3])}", phi_ab_learn_flag=bool(r.rand() > 0.2))
+    else:
+        okw.update(phi_ab=f"{r.uniform(0.6, 1.3):.3f}", phi_ab_eta=f"{r.choice([1e-3, 2e-3])}", phi_ab_learn_flag=bool(r.rand() > 0.2))
+    wtype = ["gamma", "original", "move"][r.randint(3)]
+    wfun = {"gamma": f"gamma,{r.uniform(1.1, 1.6):.3f},{r.uniform(0.8, 1.5):.3f},1", "original": "original,0", "move": f"move,{r.uniform(1.05, 1.5):.3f}"}[wtype]
+    aux = [None, {"avrg_loss": 0.5, "val_loss": 20}, {"val_loss": 40}, {"avrg_loss": 1.5}][r.randint(4)]
+    ckw = dict(loss_function=["norm", "mse"][r.randint(2)], loss_weight=["depth", "none"][int(r.rand() > 0.75)], weight_function=wfun)
+    hw = [(24, 24), (16, 40), (32, 20), (8, 8)][r.randint(4)]
+    return opname, okw, ckw, aux, int(r.choice([1, 3, 20])), hw
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_physics_random_configurations_vs_oracle(mods, seed):
+    """24 seeded points of the configuration space (every operator x depth type x loss x weight function x auxiliary-loss subset x
+    learn flags x inner iterations x non-square sizes): loss, phi after the inner SGD iterations and dL/dx0 of the device path vs
+    autograd through the oracle.  The parametrised tests above walk the shipped configurations; this one walks what a user can
+    write into the YAML."""
+    ops, M, CM = mods
+    opname, okw, ckw, aux, n_iter, (H, W) = _random_case(seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    x0 = (0.6 * torch.randn(1, 4, H, W, generator=g)).clamp(-1.0, 1.0).requires_grad_(True)   # depth >= -1: the gamma bases stay positive
+    y = torch.rand(1, 3, H, W, generator=g) * 1.6 - 0.8
+    op = D.PhysOperator(opname, batch_size=1, **okw)
+    guide = D.OsmosisGuidance(op, n_iter=n_iter, scale="7,7,7,0.9", gradient_clip="False,0", aux=aux, **ckw)
+    op.set_requires_grad(True)
+    for it in range(n_iter):
+        sep, loss = guide.loss(x0, y)
+        a = D.aux_loss(x0, guide.aux)
+        total = loss if a is None else loss + a
+        total.backward(inputs=([x0] if it == n_iter - 1 else []) + list(op.phi.values()))
+        op.sgd_step()
+    ref_g = x0.grad.clone()
+    oper = M.get_operator(opname, device=DEV, batch_size=1, optimizer="sgd", **okw)
+    cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), scale="7,7,7,0.9", gradient_x_prev=True,
+                                      gradient_clip="False,0", n_iter=n_iter, aux_loss=aux, pattern="pcgs", **ckw)
+    gx0, sep_loss = cond.loss_grad_x0(x0.detach().to(DEV), y.to(DEV), freeze_phi=False)
+    tag = (seed, opname, okw["depth_type"], ckw, aux, n_iter, (H, W))
+    assert np.allclose(sep_loss.cpu().numpy(), sep, rtol=3e-5), (tag, sep_loss, sep)
+    for n, v in oper.variables().items():
+        assert torch.allclose(v.cpu(), op.phi[n].detach(), atol=3e-6), (tag, n, v.cpu().flatten(), op.phi[n].detach().flatten())
+    scale = float(ref_g.abs().max())
+    assert float((gx0.cpu() - ref_g).abs().max()) < 3e-5 * scale + 1e-9, (tag, float((gx0.cpu() - ref_g).abs().max()), scale)
+
+
 TORCH_OPTIMIZERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adamax": torch.optim.Adamax,
                     "rmsprop": torch.optim.RMSprop, "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta,
                     "asgd": torch.optim.ASGD, "rprop": torch.optim.Rprop}
