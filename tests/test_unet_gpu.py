@@ -73,6 +73,51 @@ def test_unet_variants_vs_oracle(create_model, kw, hw, B):
     assert float((dxd.cpu() - dxr).abs().max()) < 3e-5 * max(1.0, float(dxr.abs().max()))
 
 
+def _random_arch(seed):
+    """A seeded point of create_model's argument space (unet.py:27-98) that the network of the path can take: widths that are multiples
+    of 32 (GroupNorm32), 1-3 levels, 1-3 blocks per level, attention anywhere, head size by count or by width, both attention orders,
+    FiLM or additive conditioning, ResBlock or layer resampling, non-square inputs, batches of 1-3."""
+    r = np.random.RandomState(1000 + seed)
+    nlev = int(r.choice([2, 3, 3, 4]))
+    mults = [1] + [int(r.choice([1, 2, 2, 3])) for _ in range(nlev - 1)]
+    nc = int(r.choice([32, 64, 96]))
+    size = 256
+    ds_all = [2 ** i for i in range(nlev)]
+    att = [str(size // d) for d in ds_all if r.rand() < 0.5] or [str(size // ds_all[-1])]
+    by_width = bool(r.rand() < 0.5)
+    kw = dict(image_size=size, num_channels=nc, num_res_blocks=int(r.choice([1, 2, 3])), channel_mult=",".join(map(str, mults)),
+              attention_resolutions=",".join(att), num_head_channels=int(r.choice([16, 32])) if by_width else -1,
+              num_heads=int(r.choice([1, 2, 4])), num_heads_upsample=-1, learn_sigma=True, class_cond=False, use_checkpoint=False,
+              use_scale_shift_norm=bool(r.rand() < 0.7), dropout=0.0, resblock_updown=bool(r.rand() < 0.7), use_fp16=False,
+              use_new_attention_order=bool(r.rand() < 0.4), model_path="", pretrain_model="osmosis")
+    unit = 2 ** (nlev - 1)
+    hw = (unit * int(r.choice([2, 4, 8])), unit * int(r.choice([2, 4, 6])))
+    return kw, hw, int(r.choice([1, 1, 2, 3]))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_architectures_vs_oracle(create_model, seed):
+    """12 seeded architectures (see `_random_arch`): forward and input gradient of the planned HIP network vs the oracle's plain-torch
+    restatement on the CPU, exact-fp32 mode, and the default f16x3 arithmetic against its own bar."""
+    kw, hw, B = _random_arch(seed)
+    m, cfg, sd = build(create_model, kw, seed=50 + seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, *hw, generator=g)
+    t = torch.tensor([3.0, 411.0, 998.0][:B])
+    w = torch.randn(B, 8, *hw, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = U.unet_forward(sd, cfg, xr, t)
+    (dxr,) = torch.autograd.grad((yr * w).sum(), xr)
+    sy, sd_ = max(1.0, float(yr.detach().abs().max())), max(1.0, float(dxr.abs().max()))
+    for mode, tol in (("f32", 3e-5), ("f16x3", 6e-5)):
+        m.conv_mode = mode
+        xd = x.to(DEV).requires_grad_(True)
+        yd = m(xd, t.to(DEV))
+        (dxd,) = torch.autograd.grad((yd * w.to(DEV)).sum(), xd)
+        ey, ed = float((yd.detach().cpu() - yr.detach()).abs().max()) / sy, float((dxd.cpu() - dxr).abs().max()) / sd_
+        assert ey < tol and ed < tol, (seed, mode, kw["channel_mult"], kw["num_channels"], hw, B, ey, ed)
+
+
 def test_full_size_unet_256_vs_oracle(create_model):
     """The real architecture (552.8 M parameters) at 1x4x256x256, forward and input gradient."""
     kw = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
