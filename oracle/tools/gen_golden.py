@@ -10,6 +10,7 @@ expected outputs); no reference source is stored.
     python oracle/tools/gen_golden.py            # rewrites tests/golden/*.npz
 
 Sections (SURVEY.md section 8c recipe):
+  spacing.json    (round 6) space_timesteps over every argument form it accepts / refuses
   schedules.npz   float64 tables of create_sampler for T' in {1000, 250, 10}
   blocks.npz      GroupNorm32 / timestep_embedding / ResBlock{plain,skip,up,down} /
                   AttentionBlock{legacy,new}: inputs, params, outputs, input-gradients
@@ -129,6 +130,26 @@ def gen_schedules():
     out["space_1000_10_15_20"] = np.array(sorted(R_gd.space_timesteps(300, [10, 15, 20])), dtype=np.int64)
     out["space_ddim25"] = np.array(sorted(R_gd.space_timesteps(1000, "ddim25")), dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+
+
+def gen_spacing():
+    """(round 6) `space_timesteps` (gaussian_diffusion.py:373-426) over the argument forms it accepts -- an int, a list, comma-separated
+    section counts, the "ddimN" strides -- and the ones it refuses (ValueError), as JSON: {"<num_timesteps>|<spec repr>": sorted steps |
+    "ValueError"}.  Python's banker's round() decides where the fractional strides land (:422)."""
+    import json
+    cases = [(1000, 1000), (1000, 250), (1000, "250"), (1000, "100"), (1000, "10,20,30"), (1000, [10, 15, 20]), (300, "10,15,20"),
+             (1000, "ddim25"), (1000, "ddim50"), (1000, "ddim1000"), (1000, "ddim30"), (1000, "ddim7"), (100, "7"), (100, "3,3,3"),
+             (97, "5,11"), (1000, "333,333,334"), (1000, "1"), (1000, "1,1,1"), (10, "11"), (1000, "500,600"), (50, "ddim13"),
+             (1000, "13,0,27"), (7, [7]), (1000, "999")]
+    out = {}
+    for n, spec in cases:
+        try:
+            out[f"{n}|{spec!r}"] = sorted(int(v) for v in R_gd.space_timesteps(n, spec))
+        except ValueError:
+            out[f"{n}|{spec!r}"] = "ValueError"
+    with open(os.path.join(OUT, "spacing.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("spacing cases", len(out), "refused", sum(v == "ValueError" for v in out.values()))
 
 
 def gen_blocks():
@@ -861,6 +882,7 @@ if __name__ == "__main__":
             globals()["gen_" + name]()
         sys.exit(0)
     gen_schedules()
+    gen_spacing()
     gen_blocks()
     gen_tiny_unet()
     gen_unet_variants()
