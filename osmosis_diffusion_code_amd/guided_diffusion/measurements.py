@@ -140,6 +140,20 @@ class _PhysicalOperator(LearnableOperator):
     def _init_phi(self, a, b, inf):
         row = np.concatenate([a, b, inf]).astype(np.float32)
         self.phi = torch.from_numpy(np.tile(row, (self.batch_size, 1))).to(self.device).contiguous()
+        # The reference's parameter tensors (`self.phi_a`, ... [B,3,1,1]; haze `phi_ab` [B,1,1,1]) as VIEWS of the [B][9] block the
+        # kernels step: leaves of autograd for code written against the reference API (a third-party conditioning method that calls
+        # `operator.forward` under autograd, `loss.backward(inputs=[x_prev] + operator.get_variable_list())`, `operator.optimize()`),
+        # and always the current values whichever side moved them.
+        self._leaves = {}
+        for name, (lo, n) in self._slots().items():
+            leaf = self.phi[:, lo:lo + n].unflatten(1, (n, 1, 1))
+            self._leaves[name] = leaf
+            setattr(self, name, leaf)
+        self._torch_optimizer = None
+
+    def _slots(self):
+        """{variable name: (first column of self.phi, width)}."""
+        raise NotImplementedError
 
     def eta3(self):
         raise NotImplementedError
@@ -156,18 +170,36 @@ class _PhysicalOperator(LearnableOperator):
 
     # -- reference API ----------------------------------------------------------------------
     def forward(self, data, **kwargs):
-        """Image formation on torch tensors (visualisation / API parity; the sampler's hot path
-        evaluates the model inside osm_phys_* kernels)."""
+        """Image formation on torch tensors (measurements.py:138-151, :251-264, :363-376), differentiable w.r.t. `data` AND the
+        parameter tensors (`get_variable_list()`), as in the reference.  The sampler's own hot path evaluates the model inside the
+        osm_phys_* kernels; this is the API for visualisation and for conditioning methods written against the reference."""
         rgb01 = 0.5 * (data[:, 0:-1] + 1)
         d = utilso.convert_depth(depth=data[:, -1:], depth_type=self.depth_type, value=self.value)
-        phi = self.phi.to(data.device)
-        pa = phi[:, 0:3, None, None]
-        pb = phi[:, 3:6, None, None] if self.KIND == 0 else pa
-        pinf = phi[:, 6:9, None, None]
-        return rgb01 * torch.exp(-pa * d) + pinf * (1 - torch.exp(-pb * d))
+        lv = {k: (v if v.device == data.device else v.to(data.device)) for k, v in self._leaves.items()}
+        pa = lv["phi_a"] if "phi_a" in lv else lv["phi_ab"]
+        pb = lv["phi_b"] if "phi_b" in lv else pa
+        return rgb01 * torch.exp(-pa * d) + lv["phi_inf"] * (1 - torch.exp(-pb * d))
 
     def optimize(self, **kwargs):
-        """The SGD step itself runs on device (osm_phys_finalize); this returns the variables."""
+        """measurements.py:266-303.  The package's conditioning method steps phi on the device (osm_phys_finalize) and calls this
+        for the variables dictionary only.  A caller that back-propagated into the parameter tensors itself (their `.grad` is set)
+        gets the reference's step here: plain gradient descent phi -= eta * grad for 'GD' / 'sgd' / '', else the torch optimizer of
+        `optimizer:` over one parameter group per variable (lr = eta), then the gradients are zeroed."""
+        if not kwargs.get("freeze_phi", False) and any(v.grad is not None for v in self._leaves.values()):
+            etas = dict(zip(("phi_a", "phi_b", "phi_inf"), self.eta3()))
+            etas["phi_ab"] = etas["phi_a"]
+            if OPTIMIZER_CODES[self.optimizer] == 0:
+                with torch.no_grad():
+                    for name, v in self._leaves.items():
+                        if v.requires_grad and v.grad is not None:
+                            v.add_(v.grad, alpha=-etas[name])
+            else:
+                if self._torch_optimizer is None:
+                    self._torch_optimizer = utilso.get_optimizer(self.optimizer, [{"params": v, "lr": etas[n]} for n, v in self._leaves.items()])
+                self._torch_optimizer.step()
+            for v in self._leaves.values():
+                if v.grad is not None:
+                    v.grad.zero_()
         return self.variables()
 
     def set_variable_gradients(self, value=None, **kwargs):
@@ -175,12 +207,13 @@ class _PhysicalOperator(LearnableOperator):
             raise ValueError("A value should be specified (True or False for general or dictionary)")
         for v in self.VARS:
             self._requires_grad[v] = bool(value[v] if isinstance(value, dict) else value)
+            self._leaves[v].requires_grad_(self._requires_grad[v])
 
     def get_variable_gradients(self, **kwargs):
-        return dict(self._requires_grad)
+        return {v: self._leaves[v].requires_grad for v in self.VARS}
 
     def get_variable_list(self, **kwargs):
-        return [self.variables()[v] for v in self.VARS]
+        return [self._leaves[v] for v in self.VARS]
 
 
 @register_operator(name="underwater_physical_revised")
@@ -198,6 +231,9 @@ class UnderWaterPhysicalRevisedOperator(_PhysicalOperator):
 
     def eta3(self):
         return (self.phi_a_eta, self.phi_b_eta, self.phi_inf_eta)
+
+    def _slots(self):
+        return {"phi_a": (0, 3), "phi_b": (3, 3), "phi_inf": (6, 3)}
 
     def variables(self):
         return {"phi_a": self._slot(0), "phi_b": self._slot(3), "phi_inf": self._slot(6)}
@@ -222,6 +258,9 @@ class UnderWaterPhysicalOperator(_ABOperator):
         self.phi_ab_eta = float(phi_ab_eta) if phi_ab_learn_flag else 0.0
         self.phi_inf_eta = float(phi_inf_eta) if phi_inf_learn_flag else 0.0
 
+    def _slots(self):
+        return {"phi_ab": (0, 3), "phi_inf": (6, 3)}
+
     def variables(self):
         return {"phi_ab": self._slot(0), "phi_inf": self._slot(6)}
 
@@ -237,6 +276,9 @@ class HazePhysicalOperator(_ABOperator):
         self._init_phi(ab, ab, _vec(phi_inf))
         self.phi_ab_eta = float(phi_ab_eta) if phi_ab_learn_flag else 0.0
         self.phi_inf_eta = float(phi_inf_eta) if phi_inf_learn_flag else 0.0
+
+    def _slots(self):
+        return {"phi_ab": (0, 1), "phi_inf": (6, 3)}
 
     def variables(self):
         return {"phi_ab": self._slot(0, 1), "phi_inf": self._slot(6)}
