@@ -231,12 +231,61 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
         return out
 
     # ---------------------------------------------------------------- reference API
+    def _has_kernels(self) -> bool:
+        """One of the three image-formation models osm_phys_* evaluates (the package's own operators); anything else -- an operator a
+        user registered with `register_operator` -- goes through torch.autograd below."""
+        return hasattr(self.operator, "fill_desc")
+
+    def _loss_autograd(self, x_0_hat, measurement, **kwargs):
+        """condition_methods.py:109-144 on torch tensors, for operators the kernels do not know: (sep_loss ndarray[B], loss, image)."""
+        image = self.operator.forward(x_0_hat, **kwargs)
+        w = utilso.set_loss_weight(loss_weight_type=self.loss_weight, weight_function=self.weight_function,
+                                   degraded_image=image.detach(), x_0_hat=x_0_hat.detach())
+        diff = (measurement - (2 * image - 1)) * w
+        if self.loss_function == "norm":
+            return torch.norm(diff.detach().cpu(), p=2, dim=[1, 2, 3]).numpy(), torch.linalg.norm(diff), image.detach()
+        if self.loss_function == "mse":
+            mse = (diff ** 2).mean(dim=(1, 2, 3))
+            return mse.detach().cpu().numpy(), mse.sum(), image.detach()
+        raise NotImplementedError
+
+    def _conditioning_autograd(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
+        """The reference's step (:146-231) through torch.autograd, for a third-party operator: n_iter x (loss + auxiliary losses,
+        backward into the operator's parameter tensors, `operator.optimize`), the last one also into x_prev; then the update of x_t."""
+        freeze_phi = kwargs.get("freeze_phi", False)
+        if not self.gradient_x_prev:
+            raise NotImplementedError("gradient_x_prev=False raises in the reference too (backward(inputs=[x_prev]) on a tensor whose "
+                                      "requires_grad it has just switched off, condition_methods.py:152-157, :186-191)")
+        with torch.enable_grad():
+            self.operator.set_variable_gradients(value=not freeze_phi)
+            n = 1 if freeze_phi else self.n_iter
+            for it in range(n):
+                sep_loss, loss, _ = self._loss_autograd(x_0_hat, measurement, time_index=kwargs.get("time_index", None))
+                aux_dict = None
+                if self.aux_loss is not None:
+                    aux, aux_dict = self.aux_loss.forward(x_0_hat)
+                    loss = loss + aux
+                phis = [] if freeze_phi else list(self.operator.get_variable_list())
+                last = it == n - 1
+                loss.backward(inputs=([x_prev] if last else []) + phis, retain_graph=not last)
+                variables = self.operator.optimize(freeze_phi=freeze_phi)
+        with torch.no_grad():
+            grads = x_prev.grad
+            if self.gradient_clip:
+                grads = torch.clamp(grads, min=-self.gradient_clip_value, max=self.gradient_clip_value)
+            x_t -= self.scale[None, ..., None, None].to(x_prev.device) * grads
+        return x_t, sep_loss, variables, x_prev.grad.cpu(), aux_dict
+
     def grad_and_value(self, x_prev, x_0_hat, measurement, **kwargs):
+        if not self._has_kernels():
+            return self._loss_autograd(x_0_hat, measurement, **kwargs)
         g, loss = self.loss_grad_x0(x_0_hat.detach(), measurement, freeze_phi=True)
         I = self.operator.forward(x_0_hat.detach())
         return loss.detach().cpu().numpy(), loss.sum(), I
 
     def conditioning(self, x_prev, x_t, x_0_hat, measurement, **kwargs):
+        if not self._has_kernels():
+            return self._conditioning_autograd(x_prev, x_t, x_0_hat, measurement, **kwargs)
         freeze_phi = kwargs.get("freeze_phi", False)
         self.operator.set_variable_gradients(value=not freeze_phi)
         g, loss = self.loss_grad_x0(x_0_hat.detach(), measurement, freeze_phi=freeze_phi)

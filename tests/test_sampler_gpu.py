@@ -250,6 +250,74 @@ def test_third_party_conditioner_on_the_reference_api(pkg, opname, optimizer):
         assert float((v.cpu() - operator.variables()[n].cpu()).abs().max()) == 0.0
 
 
+def test_third_party_operator_with_the_builtin_conditioner(pkg):
+    """The other half of the registry contract: an operator the kernels do not know -- registered with `register_operator`, a plain
+    torch object with the reference's `LearnableOperator` methods (here: the revised underwater model again, so that the reference's
+    trace is the answer) -- under the package's OWN 'osmosis' conditioning method: no `fill_desc`, so `p_sample_loop` takes
+    `_generic_loop` and the conditioner its torch.autograd restatement of condition_methods.py:109-231."""
+    unet, gd, M, CM = pkg
+    from osmosis_diffusion_code_amd.osmosis_utils import utils as OU
+    name = "third_party_revised_model"
+    if name not in M.__OPERATOR__:
+        @M.register_operator(name=name)
+        class Mine(M.LearnableOperator):
+            def __init__(self, device, batch_size=1, **kw):
+                vec = lambda s: torch.tensor([float(v) for v in s.split(",")], device=device).repeat(batch_size, 1)[..., None, None]   # noqa: E731
+                self.p = {n: vec(kw[n]) for n in ("phi_a", "phi_b", "phi_inf")}
+                self.eta = {n: float(kw[n + "_eta"]) for n in self.p}
+                self.value = OU.get_depth_value(kw["value"])
+
+            def forward(self, data, **kw):
+                d = OU.convert_depth(depth=data[:, -1:], depth_type="gamma", value=self.value)
+                return 0.5 * (data[:, :-1] + 1) * torch.exp(-self.p["phi_a"] * d) + self.p["phi_inf"] * (1 - torch.exp(-self.p["phi_b"] * d))
+
+            def set_variable_gradients(self, value=None, **kw):
+                for v in self.p.values():
+                    v.requires_grad_(bool(value))
+
+            def get_variable_list(self, **kw):
+                return list(self.p.values())
+
+            def optimize(self, freeze_phi=False, **kw):
+                if not freeze_phi:
+                    with torch.no_grad():
+                        for n, v in self.p.items():
+                            v.add_(v.grad, alpha=-self.eta[n])
+                            v.grad.zero_()
+                return {n: v.detach() for n, v in self.p.items()}
+    opname = "underwater_physical_revised"
+    g = np.load(os.path.join(GOLD, f"loop_{opname}.npz"))
+    spec = OPERATORS[opname]
+    model = make_model(unet)
+    operator = M.get_operator(name, device=DEV, batch_size=1, **spec["operator"])
+    assert not hasattr(operator, "fill_desc")
+    cond = CM.get_conditioning_method("osmosis", operator, M.get_noise("clean"), **spec["cond"], **PATTERN, **spec["aux"])
+    noise = iter(torch.from_numpy(g["noise"]).to(DEV))
+    losses, aux_seen = [], []
+    orig = cond.conditioning
+
+    def traced(**kw):
+        ret = orig(**kw)
+        losses.append(float(ret[1][0]))
+        aux_seen.append(ret[4])
+        return ret
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: next(noise) if t.shape[1] == 4 else real_randn_like(t, **kw)
+    try:
+        img, variables, loss, x0 = make_sampler(gd).p_sample_loop(
+            model=model, x_start=torch.from_numpy(g["x_T"]).to(DEV).requires_grad_(), measurement=torch.from_numpy(g["y"]).to(DEV),
+            measurement_cond_fn=traced, record=False, save_root=None, pretrain_model="osmosis", rgb_guidance=False, sample_pattern=PATTERN)
+    finally:
+        torch.randn_like = real_randn_like
+    assert len(losses) == 10 and np.allclose(losses, g["trace.loss"].reshape(10), rtol=1e-4)
+    assert set(aux_seen[-1]) == {"avrg_loss", "val_loss"}
+    e_img = float((img.detach().cpu() - torch.from_numpy(g["final_img"])).abs().max())
+    print(f"third-party operator under the built-in conditioner: final image error {e_img:.1e}")
+    assert e_img < 1e-4 and float((x0 - torch.from_numpy(g["final_x0"])).abs().max()) < 1e-4
+    for n, v in variables.items():
+        assert torch.allclose(v.cpu(), torch.from_numpy(g[f"final.{n}"]), atol=5e-6), n
+
+
 def test_batched_images_equal_single_image_runs(pkg):
     """B=2 (two different images) == two B=1 runs (per-image reductions)."""
     unet, gd, M, CM = pkg
