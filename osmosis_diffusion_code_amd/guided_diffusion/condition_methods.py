@@ -232,9 +232,16 @@ class PosteriorSamplingOsmosis(ConditioningMethod):
 
     # ---------------------------------------------------------------- reference API
     def _has_kernels(self) -> bool:
-        """One of the three image-formation models osm_phys_* evaluates (the package's own operators); anything else -- an operator a
-        user registered with `register_operator` -- goes through torch.autograd below."""
-        return hasattr(self.operator, "fill_desc")
+        """Everything of this step is something osm_phys_* evaluates: one of the three image-formation models (the package's own
+        operators), norm / mse, no weight or the depth weight, auxiliary losses with a kernel slot.  Anything else -- an operator or an
+        auxiliary loss a user registered with `register_operator` / `register_loss` -- goes through torch.autograd below."""
+        if not hasattr(self.operator, "fill_desc") or self.loss_function not in ("norm", "mse"):
+            return False
+        if self.loss_weight not in (None, "none", "depth"):
+            return False
+        return self.aux_loss is None or all(getattr(m, "kernel_slot", None) is not None for m in self.aux_loss.losses_list)
+
+    hip_ok = _has_kernels
 
     def _loss_autograd(self, x_0_hat, measurement, **kwargs):
         """condition_methods.py:109-144 on torch tensors, for operators the kernels do not know: (sep_loss ndarray[B], loss, image)."""

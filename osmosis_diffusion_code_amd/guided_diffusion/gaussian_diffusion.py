@@ -209,7 +209,7 @@ class GaussianDiffusion:
             return cond
         if not isinstance(cond, PosteriorSamplingOsmosis):
             return None
-        if not cond.gradient_x_prev or not hasattr(cond.operator, "fill_desc"):
+        if not cond.gradient_x_prev or not cond.hip_ok():       # (a third-party operator / auxiliary loss: autograd conditioning)
             return None
         return cond
 

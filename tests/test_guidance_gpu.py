@@ -340,6 +340,59 @@ def test_conditioning_five_tuple_of_the_reference_api(mods, opname):
         assert ret[4][n].device.type == "cpu" and ret[4][n].dim() == 0 and abs(float(ret[4][n]) - float(want[n])) < 1e-6 * max(1.0, float(want[n])), n
 
 
+def test_third_party_auxiliary_loss_takes_the_autograd_step(mods):
+    """An auxiliary loss added with `register_loss` (losses.py:13-26) has no kernel slot: the 'osmosis' conditioning method reports
+    `hip_ok() == False` (the fused loop is not entered) and takes its torch.autograd step -- through the BUILT-IN operator's autograd API
+    (parameter tensors as leaves, `optimize()` applying the caller-produced gradients) -- vs the same step written out on the CPU."""
+    ops, M, CM = mods
+    from osmosis_diffusion_code_amd.osmosis_utils import losses as L
+    if "tv_loss" not in L.__LOSS__:
+        @L.register_loss(name="tv_loss")
+        class TV(torch.nn.Module):
+            def forward(self, x):
+                rgb = x[:, 0:3]
+                return (rgb[:, :, 1:] - rgb[:, :, :-1]).abs().mean() + (rgb[:, :, :, 1:] - rgb[:, :, :, :-1]).abs().mean()
+    tv = L.get_loss("tv_loss")
+    opname = "underwater_physical_revised"
+    okw, ckw = OPS[opname]
+    eta = {k + "_eta": 1e-3 for k in ("phi_a", "phi_b", "phi_inf")}
+    g = torch.Generator().manual_seed(17)
+    H = W = 24
+    xp = (0.6 * torch.randn(1, 4, H, W, generator=g)).clamp(-1, 1)
+    y = torch.rand(1, 3, H, W, generator=g) * 1.6 - 0.8
+    mean0 = 0.4 * torch.randn(1, 4, H, W, generator=g)
+    # CPU: the oracle's data term + 0.3 tv + 20 val, 5 inner iterations of plain descent, then the update of x_t
+    op = D.PhysOperator(opname, batch_size=1, **okw, **eta)
+    guide = D.OsmosisGuidance(op, n_iter=5, **{**ckw, "aux": {"val_loss": 20}})
+    xr = xp.clone().requires_grad_(True)
+    x0r = 0.9 * xr + 0.1 * torch.tanh(xr)
+    op.set_requires_grad(True)
+    for it in range(5):
+        sep, loss = guide.loss(x0r, y)
+        total = loss + D.aux_loss(x0r, guide.aux) + 0.3 * tv(x0r)
+        total.backward(inputs=([xr] if it == 4 else []) + list(op.phi.values()), retain_graph=it < 4)
+        op.sgd_step()
+    clipv = float(ckw["gradient_clip"].split(",")[1])
+    scale = torch.tensor([float(v) for v in ckw["scale"].split(",")])
+    xt_ref = mean0 - scale[None, :, None, None] * torch.clamp(xr.grad, -clipv, clipv)
+    # device
+    oper = M.get_operator(opname, device=DEV, batch_size=1, optimizer="sgd", **okw, **eta)
+    cond = CM.get_conditioning_method("osmosis", oper, M.get_noise("clean"), loss_function="norm", loss_weight="depth",
+                                      weight_function="gamma,1.4,1.4,1", scale=ckw["scale"], gradient_x_prev=True,
+                                      gradient_clip=ckw["gradient_clip"], n_iter=5, aux_loss={"tv_loss": 0.3, "val_loss": 20}, pattern="pcgs")
+    assert cond.hip_ok() is False
+    xd = xp.to(DEV).requires_grad_(True)
+    x0d = 0.9 * xd + 0.1 * torch.tanh(xd)
+    x_t = mean0.to(DEV).clone()
+    ret = cond.conditioning(x_prev=xd, x_t=x_t, x_0_hat=x0d, measurement=y.to(DEV), freeze_phi=False, time_index=0.2)
+    assert torch.allclose(x_t.cpu(), xt_ref, atol=2e-6) and np.allclose(ret[1], sep, rtol=1e-5)
+    assert torch.allclose(ret[3], xr.grad, atol=2e-6 * float(xr.grad.abs().max()) + 1e-7)
+    for n, v in ret[2].items():
+        assert torch.allclose(v.cpu(), op.phi[n].detach(), atol=1e-6), n
+        assert float((v.cpu() - torch.tensor([float(u) for u in okw[n].split(",")])[None, :, None, None]).abs().max()) > 1e-5   # phi moved
+    assert set(ret[4]) == {"tv_loss", "val_loss"}
+
+
 @pytest.mark.parametrize("optimizer,freeze", [("sgd", False), ("adam", False), ("sgd", True)])
 def test_phys_optimize_equals_the_launch_by_launch_loop(mods, monkeypatch, optimizer, freeze):
     """osm_phys_optimize (the inner phi loop enqueued by ONE C call) issues exactly the launches of the per-launch entry points
